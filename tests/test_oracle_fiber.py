@@ -1,0 +1,168 @@
+"""Pin the CPU oracle's fiber.m restatement with the reference's own known answers.
+
+The reference holds no golden vectors for fiber.m; what it states is:
+  (i)   '--s-' with one field is exact in ONE step            fiber.m:172-174
+  (ii)  'g---' is one step == ifft(fft(u).*exp(-i betat L))    fiber.m:162-165,762-773
+  (iii) alpha=0 => every sub-step is unitary (energy kept)     fiber.m:910-912,837-850
+  (xi)  firstdz / ncycle fingerprints of the step controller   fiber.m:431
+"""
+import numpy as np
+import pytest
+
+
+def _field(n, seed, nfc=1, amp=1.0):
+    r = np.random.default_rng(seed)
+    return np.asfortranarray(amp * (r.standard_normal((n, nfc)) + 1j * r.standard_normal((n, nfc))))
+
+
+def test_fft_matches_numpy(oracle):
+    for n in (1, 2, 8, 64, 1024, 12, 100):
+        x = _field(n, n)[:, 0]
+        np.testing.assert_allclose(oracle.fft(x), np.fft.fft(x), rtol=0, atol=1e-11 * max(1, n))
+        np.testing.assert_allclose(oracle.fft(x, inverse=True), np.fft.ifft(x), rtol=0, atol=1e-12)
+
+
+def test_fastexp(oracle):
+    x = np.concatenate([np.linspace(-10, 10, 101), [1e5, -3e6, 0.0, 1e-300]])
+    y = oracle.fastexp(x)
+    np.testing.assert_array_equal(y.real, np.cos(x))
+    np.testing.assert_array_equal(y.imag, np.sin(x))
+
+
+def test_nextstep_rules(oracle):
+    u = _field(256, 1)
+    umax = np.max(np.abs(u) ** 2)
+    gam, alpha = 1.3e-6, 4.6e-5
+    # phimax = Inf => dzmax (fiber.m:699-703)
+    assert oracle.nextstep(2e4, np.inf, gam, alpha, u) == 2e4
+    assert oracle.nextstep(2e4, np.inf, gam, 0.0, u) == 2e4
+    # finite phimax: -log(1-alpha*leff)/alpha
+    leff = 5e-3 / (gam * umax)
+    exp_dz = min(2e4, -np.log(1 - alpha * leff) / alpha)
+    assert oracle.nextstep(2e4, 5e-3, gam, alpha, u) == pytest.approx(exp_dz, rel=1e-14)
+    assert oracle.nextstep(2e4, 5e-3, gam, 0.0, u) == pytest.approx(min(2e4, leff), rel=1e-14)
+    # dual-pol power is |ux|^2+|uy|^2
+    uy = _field(256, 2)
+    pm = np.max(np.abs(u) ** 2 + np.abs(uy) ** 2)
+    assert oracle.nextstep(1e9, 5e-3, gam, 0.0, u, uy) == pytest.approx(5e-3 / (gam * pm), rel=1e-14)
+    # dl >= 1 => dzmax
+    assert oracle.nextstep(777.0, 1e3, gam, alpha, u) == 777.0
+
+
+def test_checkstep_walk(oracle):
+    # walk 10 plates of 100 m with steps of 130 m: trunk bookkeeping of fiber.m:739-758
+    lcorr, dz = 100.0, 130.0
+    zprop, miss, ntot, covered = dz, 0.0, 0, 0.0
+    for _ in range(6):
+        dzb, miss, nmem, ntrunk = oracle.checkstep(zprop, dz, lcorr, miss, ntot)
+        assert dzb.sum() == pytest.approx(dz)
+        assert (dzb <= lcorr + 1e-9).all() and (dzb > 0).all()
+        ntot += ntrunk - nmem
+        covered += dz
+        assert ntot == int(np.ceil(covered / lcorr))
+        assert miss == pytest.approx(ntot * lcorr - covered)
+        zprop += dz
+    # step that stays inside the trunk: single piece, nmem = 1
+    dzb, miss2, nmem, ntrunk = oracle.checkstep(40.0 + 30.0, 30.0, 100.0, 60.0, 1)
+    assert (ntrunk, nmem) == (1, 1) and dzb[0] == 30.0 and miss2 == 30.0
+
+
+def test_exact_spm_single_step(oracle):
+    """(i) flag '--s-', one field: u*exp(-i*gam*|u|^2*Leff)*exp(-alpha*L/2) in ONE step."""
+    n, L, alpha, gam = 512, 8e4, 4.6e-5, 1.3e-6
+    u = _field(n, 3, amp=30.0)
+    betat = np.zeros((n, 1))
+    first, ncycle, out = oracle.scalar_ssfm(u, betat, L, np.inf, gam, alpha, L, [0, 0, 1, 0])
+    leff = (1 - np.exp(-alpha * L)) / alpha
+    ref = u * np.exp(-1j * gam * np.abs(u) ** 2 * leff) * np.exp(-alpha * L / 2)
+    assert ncycle == 1 and first == L
+    np.testing.assert_allclose(out, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_pure_gvd_single_step(oracle):
+    """(ii) flag 'g---': one step == ifft(fft(u).*exp(-i*betat*L))*exp(-alpha*L/2)."""
+    n, L, alpha = 1024, 8e4, 4.6e-5
+    u = _field(n, 4)
+    fn = np.fft.fftfreq(n, 1 / 64.0)
+    omega = 2 * np.pi * 10 * fn
+    betat = (0.5 * omega ** 2 * -2.17e-8).reshape(n, 1)
+    first, ncycle, out = oracle.scalar_ssfm(u, betat, L, np.inf, 1.3e-6, alpha, L, [1, 0, 0, 0])
+    ref = np.fft.ifft(np.fft.fft(u[:, 0]) * np.exp(-1j * betat[:, 0] * L)) * np.exp(-alpha * L / 2)
+    assert ncycle == 1
+    np.testing.assert_allclose(out[:, 0], ref, rtol=0, atol=1e-11)
+    # dual-pol without 'p' goes through matrix_ssfm with nplates=1 and zero birefringence (fiber.m:291-297)
+    uy = _field(n, 5)
+    rc, first, ncycle, ox, oy = oracle.matrix_ssfm(u, uy, betat, np.zeros((n, 1)), L, np.inf, 1.3e-6, alpha, L,
+                                                   1, False, [1, 0, 0, 0], [0.0], [0.0], [0.0])
+    assert rc == 0 and ncycle == 1
+    np.testing.assert_allclose(ox[:, 0], ref, rtol=0, atol=1e-11)
+    refy = np.fft.ifft(np.fft.fft(uy[:, 0]) * np.exp(-1j * betat[:, 0] * L)) * np.exp(-alpha * L / 2)
+    np.testing.assert_allclose(oy[:, 0], refy, rtol=0, atol=1e-11)
+
+
+def _pmd(nplates, seed):
+    r = np.random.default_rng(seed)
+    db0 = r.random(nplates) * 2 * np.pi - np.pi            # fiber.m:274
+    theta = r.random(nplates) * np.pi - 0.5 * np.pi        # :275
+    eps = 0.5 * np.arcsin(r.random(nplates) * 2 - 1)       # :276
+    return db0, theta, eps
+
+
+@pytest.mark.parametrize("manakov", [False, True])
+def test_energy_conserved_and_step_fingerprint(oracle, manakov):
+    """(iii) alpha = 0: NL (incl. CNLSE rotation), PMD waveplates and GVD are all unitary."""
+    n, L, nplates = 1024, 2e4, 20
+    ux, uy = _field(n, 6, amp=20.0), _field(n, 7, amp=20.0)
+    fn = np.fft.fftfreq(n, 1 / 32.0)
+    omega = 2 * np.pi * 10 * fn
+    betat = (0.5 * omega ** 2 * -2.17e-8).reshape(n, 1)
+    db1 = (np.sqrt(3 * np.pi / 8) * 0.3 / np.sqrt(nplates) / 10 * omega).reshape(n, 1)
+    db0, theta, eps = _pmd(nplates, 8)
+    e0 = np.sum(np.abs(ux) ** 2 + np.abs(uy) ** 2)
+    rc, first, ncycle, ox, oy = oracle.matrix_ssfm(ux, uy, betat, db1, 2e3, 5e-3, 1.3e-6, 0.0, L, nplates,
+                                                   manakov, [1, 1, 1, 0], db0, theta, eps)
+    assert rc == 0 and ncycle > 10
+    e1 = np.sum(np.abs(ox) ** 2 + np.abs(oy) ** 2)
+    assert e1 == pytest.approx(e0, rel=1e-11)
+    # first step obeys nextstep with alpha = 0: dz = phimax/(gam*Pmax)
+    g = 1.3e-6 * (8 / 9 if manakov else 1)
+    pmax = np.max(np.abs(ux) ** 2 + np.abs(uy) ** 2)
+    assert first == pytest.approx(min(2e3, 5e-3 / (g * pmax)), rel=1e-13)
+
+
+def test_xpm_dual_pol_is_an_error(oracle):
+    """fiber.m:854: CNLSE with separate fields + XPM raises."""
+    ux, uy = _field(64, 1, nfc=2), _field(64, 2, nfc=2)
+    rc, *_ = oracle.matrix_ssfm(ux, uy, np.zeros((64, 2)), np.zeros((64, 2)), 1e3, 5e-3, [1e-6, 1e-6], 0.0, 1e3,
+                                1, False, [1, 0, 1, 1], [0.0], [0.0], [0.0])
+    assert rc == -1
+
+
+def test_scalar_xpm_rowsum(oracle):
+    """nl_step XPM weights: 2*sum - own (spm+xpm), 2*(sum-own) (xpm only)  fiber.m:793-798."""
+    n = 128
+    u = _field(n, 9, nfc=3, amp=10.0)
+    gam = np.array([1.1e-6, 1.2e-6, 1.3e-6])
+    p = np.abs(u) ** 2
+    tot = p.sum(axis=1, keepdims=True)
+    out = oracle.nl_step(0.0, gam, 500.0, u, True, True)
+    np.testing.assert_allclose(out, u * np.exp(-1j * gam * (2 * tot - p) * 500.0), rtol=1e-12)
+    out = oracle.nl_step(0.0, gam, 500.0, u, False, True)
+    np.testing.assert_allclose(out, u * np.exp(-1j * gam * 2 * (tot - p) * 500.0), rtol=1e-12)
+    out = oracle.nl_step(0.0, gam, 500.0, u, False, False)
+    np.testing.assert_array_equal(out, u)
+
+
+def test_adaptive_ssfm_converges_to_fine_constant_step(oracle):
+    """scalar_a_ssfm (fiber.m:639-679, 938-1009) agrees with a very fine constant-phase run."""
+    n, L, alpha, gam = 256, 2e4, 4.6e-5, 1.3e-6
+    r = np.random.default_rng(10)
+    t = np.arange(n)
+    u = (12 * np.exp(-0.5 * ((t - n / 2) / 12.0) ** 2) * np.exp(1j * 0.3 * r.standard_normal())).astype(complex)
+    fn = np.fft.fftfreq(n, 1 / 16.0)
+    omega = 2 * np.pi * 10 * fn
+    betat = (0.5 * omega ** 2 * -2.17e-8).reshape(n, 1)
+    f1, nc, nrej, ua = oracle.scalar_a_ssfm(u, betat, L, np.inf, gam, alpha, L, 1e-9, 0.9, [1, 0, 1, 0])
+    f2, nc2, uf = oracle.scalar_ssfm(u, betat, 50.0, 1e-5, gam, alpha, L, [1, 0, 1, 0])
+    assert nc > 2 and nc2 > 100
+    np.testing.assert_allclose(ua, uf, rtol=0, atol=2e-4 * np.abs(uf).max())
