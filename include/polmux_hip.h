@@ -1,0 +1,186 @@
+/*
+ * polmux_hip.h -- C ABI of libpolmux_hip.so: the MI355X (gfx950) implementation
+ * of the Optilux/Polmux hot path.
+ *
+ * The reference's only native seam is the MATLAB MEX gateway
+ *   void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
+ * (fastexp.c:46, cmaadaptivefilter.c:93, easiadaptivefilter.c:95).  A MEX shim
+ * unpacks mxArrays into plain pointers and sizes and forwards to the functions
+ * below; INTEGRATION.md shows those shims and the .m wrappers.  Every entry
+ * point cites the reference interface it replaces.
+ *
+ * Two tiers:
+ *   (A) "gateway" calls  plx_<name>(...)      host pointers, MEX-shaped: the
+ *       arrays are MATLAB column-major, complex data as SEPARATE re/im planes
+ *       (mxGetPr/mxGetPi; an all-real input has im == NULL).  Each call uploads,
+ *       runs the kernels, downloads.  Drop-in for one MATLAB call.
+ *   (B) "resident" calls plx_<name>_dev(...)  device pointers + HIP stream,
+ *       interleaved complex128 (re,im), batched over frames.  This is what the
+ *       Monte-Carlo runner and bench.py use; nothing crosses PCIe per call.
+ *
+ * All functions return 0 (PLX_OK) or a negative PLX_ERR_* code;
+ * plx_last_error() returns the message (the strings of the reference's
+ * error()/mexErrMsgTxt calls where one exists).  Not re-entrant per plan;
+ * different plans may be used from different host threads.
+ */
+#ifndef POLMUX_HIP_H
+#define POLMUX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLX_OK 0
+#define PLX_ERR_HIP (-1)       /* a HIP runtime call failed                         */
+#define PLX_ERR_ARG (-2)       /* bad argument (message mirrors the reference)      */
+#define PLX_ERR_UNSUPPORTED (-3)
+#define PLX_ERR_REFERENCE (-4) /* the reference itself raises here, e.g. fiber.m:854 */
+
+const char *plx_last_error(void);
+/* ABI version of this header: major*1000 + minor */
+int plx_abi_version(void);
+/* number of visible HIP devices, and selection of the one this process uses */
+int plx_device_count(int *count);
+int plx_set_device(int device);
+
+/* ------------------------------------------------------------------ fastexp --- */
+/* fastexp.c:37-47 / fastexp.m:28: y = cos(x) + i*sin(x), x real [m x n].           */
+int plx_fastexp(const double *x, double *yr, double *yi, size_t count);
+/* resident: y interleaved complex128 */
+int plx_fastexp_dev(const double *d_x, double *d_y, size_t count, void *stream);
+
+/* ------------------------------------------------------------ SSFM propagator --- */
+/* One plan = one fibre type on a fixed grid: the arguments fiber.m:372-389 hands
+ * to matrix_ssfm / scalar_ssfm (fiber.m:459-460, 557-558), minus the field.       */
+typedef struct plx_ssfm_desc {
+    int64_t nfft;        /* Nfft = NSYMB*NT, power of two, 256 .. 2^20            */
+    int32_t nfc;         /* columns of GSTATE.FIELDX (1 = 'unique' field)         */
+    int32_t dual_pol;    /* 1: matrix_ssfm (FIELDY present or 'p' flag), 0: scalar */
+    int32_t max_frames;  /* batch capacity: independent frames per call           */
+    int32_t fls[4];      /* flag -> [gvd pmd spm xpm], fiber.m:157-251            */
+    double dzmaxt;       /* fiber.m:160-247                                       */
+    double dphimaxt;     /* Inf allowed                                           */
+    double alphalin;     /* [1/m] fiber.m:302                                     */
+    double length;       /* Lf [m]                                                */
+    int32_t nplates;     /* x.nplates (1 when PMD is off, fiber.m:297)            */
+    int32_t manakov;     /* strcmp(x.manakov,'yes')                               */
+    const double *gam;   /* [nfc] host, [1/mW/m] fiber.m:325,328                  */
+    const double *betat; /* [nfft x nfc] host column-major, fiber.m:355-356       */
+    const double *db1;   /* [nfft x nfc] host (zeros/NULL without PMD) :358       */
+} plx_ssfm_desc;
+
+typedef struct plx_ssfm plx_ssfm;
+
+int plx_ssfm_create(plx_ssfm **plan, const plx_ssfm_desc *desc);
+int plx_ssfm_destroy(plx_ssfm *plan);
+/* brf.db0/theta/epsilon (fiber.m:266-276): host arrays [nplates x nsets]; set s is
+ * used by frame f = s (nsets == 1: shared by all frames).                          */
+int plx_ssfm_set_birefringence(plx_ssfm *plan, const double *db0, const double *theta,
+                               const double *epsilon, int nsets);
+/* Propagate nframes frames in place.  d_ux/d_uy: device, interleaved complex128,
+ * layout [frame][channel][nfft]; d_uy NULL for a scalar plan.  Asynchronous on
+ * `stream` except for the bounded polling of the data-dependent step loop.         */
+int plx_ssfm_propagate_dev(plx_ssfm *plan, double *d_ux, double *d_uy, int nframes, void *stream);
+/* per-frame results of the last propagate: firstdz, ncycle (fiber.m:431)           */
+int plx_ssfm_results(plx_ssfm *plan, int nframes, double *firstdz, int32_t *ncycle);
+/* kernel-time accounting of the last propagate: launches of the dominant
+ * (row-pass) kernel and sample-steps processed                                     */
+int plx_ssfm_stats(plx_ssfm *plan, int64_t *row_pass_launches, int64_t *sample_steps);
+
+/* gateway forms: [firstdz,ncycle,ux,uy,brf]=matrix_ssfm(...) fiber.m:459-460 and
+ * [firstdz,ncycle,u]=scalar_ssfm(...) :557-558 on one frame; split planes in/out
+ * ([nfft x nfc] each; *_i may be NULL on input only if the out planes are given).   */
+int plx_matrix_ssfm(double *uxr, double *uxi, double *uyr, double *uyi, const plx_ssfm_desc *desc,
+                    const double *db0, const double *theta, const double *epsilon,
+                    double *firstdz, int32_t *ncycle);
+int plx_scalar_ssfm(double *ur, double *ui, const plx_ssfm_desc *desc, double *firstdz, int32_t *ncycle);
+
+/* ------------------------------------------------------ overlap-save CD equaliser --- */
+/* y = OverlapBothTrans(x, H, L)  CDE_OFDE.m:62-125, batched: x [nsig][nx], H [N] on
+ * the fftshift-ordered grid (CDE_OFDE.m:30-38), both interleaved complex128.       */
+typedef struct plx_cde plx_cde;
+int plx_cde_create(plx_cde **plan, int64_t fft_len, int64_t L, const double *H_interleaved);
+int plx_cde_destroy(plx_cde *plan);
+int plx_cde_apply_dev(plx_cde *plan, const double *d_x, double *d_y, int64_t nx, int nsig, void *stream);
+/* gateway: the whole CDE_OFDE(inX, inY, fs, lambdaRef, span, D, S, fftLength, L) call,
+ * CDE_OFDE.m:16-47 (H built on the device side of the ABI in double, host code).   */
+int plx_cde_ofde(const double *xr, const double *xi, const double *yr, const double *yi, int64_t nx,
+                 double fs, double lambda_ref, double span, double D, double S, int64_t fft_len,
+                 int64_t L, double *oxr, double *oxi, double *oyr, double *oyi);
+/* the reference display()s a message and returns [] on bad arguments (:63-85): the
+ * gateway returns PLX_ERR_ARG with that message and leaves the outputs untouched.  */
+
+/* -------------------------------------------------- CMA / EASI 2x2 butterfly --- */
+/* [Y,h1,h2] = cmaadaptivefilter(xx,h1,h2,taps,mu,R,sps)  cmaadaptivefilter.c:93-174.
+ * xx [Mdim x 2], h1/h2 [taps x 2], y [Mdim-taps+1 x 2]; split planes.  Like the
+ * reference, h1/h2 are UPDATED IN PLACE (the MEX shim then returns 0,0 in plhs[1..2],
+ * cmaadaptivefilter.c:166-171).  Errors: "Ntaps should be an ODD INTEGER." /
+ * "Samples x symbol should be either 1 or 2."                                      */
+int plx_cmaadaptivefilter(const double *xr, const double *xi, int32_t Mdim, double *h1r, double *h1i,
+                          double *h2r, double *h2i, double Ntap, double mu, const double *R, double sps,
+                          double *yr, double *yi);
+/* [Y,h1,h2] = easiadaptivefilter(xx,h1,h2,taps,mu,sps)  easiadaptivefilter.c:95-169 */
+int plx_easiadaptivefilter(const double *xr, const double *xi, int32_t Mdim, double *h1r, double *h1i,
+                           double *h2r, double *h2i, double Ntap, double mu, double sps, double *yr,
+                           double *yi);
+
+/* resident, batched pol-demux driver: cmapolardemux / easipolardemux
+ * (DspPdmCohQpsk.m:142-244 == dsp4cohdec.m:374-478): cyclic extension, centre-tap
+ * init from M, pass loop with the 5e-5 convergence test, all on the device.
+ * d_x, d_y: [frame][2][L] interleaved complex128.  d_M: [frame][4] complex (row-major
+ * 2x2) initial centre taps; d_h (optional out): [frame][2][2*taps] final taps;
+ * d_passes (optional out): int32 [frame].                                          */
+#define PLX_DEMUX_CMA 1
+#define PLX_DEMUX_EASI 2
+int plx_poldemux_dev(int method, const double *d_x, double *d_y, int64_t L, int nframes, int32_t taps,
+                     double mu, const double *R /* host [2], CMA only */, const double *d_M,
+                     double *d_h, int32_t *d_passes, void *stream);
+
+/* ------------------------------------------- DspPdmCohQpsk body (resident) --- */
+typedef struct plx_dsp_params {
+    int32_t workatbaudrate; /* DspPdmCohQpsk.m:12 */
+    int32_t applynlr;       /* :17 (NLRotation)   */
+    double nlralpha;
+    double power_mw;        /* GSTATE.POWER(chNum) :22 */
+    int32_t applypol;       /* :26 */
+    int32_t polmethod;      /* 0 singlepol 1 cma 2 easi 3 combo */
+    double cma_R[2];
+    double cma_mu;
+    int32_t cma_taps;
+    int32_t cma_txpolars;
+    double cma_phizero;
+    double easi_mu;
+    int32_t easi_txpolars;
+    double easi_phizero;
+    int32_t modorder, freqavg, phasavg, poworder;
+} plx_dsp_params;
+
+typedef struct plx_dsp plx_dsp;
+/* Lin: samples per polarisation handed to DspPdmCohQpsk (2 sps unless workatbaudrate) */
+int plx_dsp_create(plx_dsp **plan, int64_t Lin, int32_t ncol, int32_t max_frames, const plx_dsp_params *p);
+int plx_dsp_destroy(plx_dsp *plan);
+/* d_in [frame][ncol][Lin] -> d_out [frame][ncol][Lout], Lout = Lin or ceil(Lin/2)  */
+int plx_dsp_run_dev(plx_dsp *plan, const double *d_in, double *d_out, int nframes, void *stream);
+int64_t plx_dsp_out_len(const plx_dsp *plan);
+
+/* samp2pat 'coherent' decisions (samp2pat.m:61-66) + error count against the
+ * transmitted pattern (ber_estimate.m:119 err = sum(sum(pat ~= pat_hat))):
+ * d_sym [frame][ncol][L] complex; d_pat uint8 [ncol*2][L] (shared by frames, may be
+ * NULL); d_pat_hat (optional) uint8 [frame][ncol*2][L]; d_err int64 [frame].       */
+int plx_decide_count_dev(const double *d_sym, int64_t L, int32_t ncol, int nframes, const uint8_t *d_pat,
+                         uint8_t *d_pat_hat, int64_t *d_err, void *stream);
+
+/* ------------------------------------------------------------ small helpers --- */
+/* strided pick + scale used between fibre and CDE when the full front end
+ * (receiver_cohmix + decimate) is not in the chain:
+ * out[f][c][i] = scale * in[f][c][offset + i*stride]                                */
+int plx_pick_dev(const double *d_in, double *d_out, int64_t n_in, int64_t n_out, int64_t offset,
+                 int64_t stride, double scale, int nsig, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI declared in include/polmux_hip.h.
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc,
+--offload-arch=gfx950) as ``polmux_amd/lib/libpolmux_hip.so``.  There is no
+fallback of any kind: if the library is missing or a call fails, a
+``PolmuxError`` is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpolmux_hip.so")
+
+PLX_OK = 0
+PLX_ERR_HIP = -1
+PLX_ERR_ARG = -2
+PLX_ERR_UNSUPPORTED = -3
+PLX_ERR_REFERENCE = -4
+
+
+class PolmuxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+class SsfmDesc(C.Structure):
+    _fields_ = [("nfft", C.c_int64), ("nfc", C.c_int32), ("dual_pol", C.c_int32), ("max_frames", C.c_int32),
+                ("fls", C.c_int32 * 4), ("dzmaxt", C.c_double), ("dphimaxt", C.c_double),
+                ("alphalin", C.c_double), ("length", C.c_double), ("nplates", C.c_int32),
+                ("manakov", C.c_int32), ("gam", C.c_void_p), ("betat", C.c_void_p), ("db1", C.c_void_p)]
+
+
+class DspParams(C.Structure):
+    _fields_ = [("workatbaudrate", C.c_int32), ("applynlr", C.c_int32), ("nlralpha", C.c_double),
+                ("power_mw", C.c_double), ("applypol", C.c_int32), ("polmethod", C.c_int32),
+                ("cma_R", C.c_double * 2), ("cma_mu", C.c_double), ("cma_taps", C.c_int32),
+                ("cma_txpolars", C.c_int32), ("cma_phizero", C.c_double), ("easi_mu", C.c_double),
+                ("easi_txpolars", C.c_int32), ("easi_phizero", C.c_double), ("modorder", C.c_int32),
+                ("freqavg", C.c_int32), ("phasavg", C.c_int32), ("poworder", C.c_int32)]
+
+
+_vp, _i32, _i64, _dbl, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_size_t
+
+# name -> argtypes; every symbol include/polmux_hip.h declares (tests check the list
+# against the header and against the built library)
+SIGNATURES = {
+    "plx_abi_version": [],
+    "plx_device_count": [C.POINTER(C.c_int)],
+    "plx_set_device": [C.c_int],
+    "plx_fastexp": [_vp, _vp, _vp, _sz],
+    "plx_fastexp_dev": [_vp, _vp, _sz, _vp],
+    "plx_ssfm_create": [C.POINTER(_vp), C.POINTER(SsfmDesc)],
+    "plx_ssfm_destroy": [_vp],
+    "plx_ssfm_set_birefringence": [_vp, _vp, _vp, _vp, C.c_int],
+    "plx_ssfm_propagate_dev": [_vp, _vp, _vp, C.c_int, _vp],
+    "plx_ssfm_results": [_vp, C.c_int, _vp, _vp],
+    "plx_ssfm_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
+    "plx_matrix_ssfm": [_vp, _vp, _vp, _vp, C.POINTER(SsfmDesc), _vp, _vp, _vp, C.POINTER(_dbl),
+                        C.POINTER(_i32)],
+    "plx_scalar_ssfm": [_vp, _vp, C.POINTER(SsfmDesc), C.POINTER(_dbl), C.POINTER(_i32)],
+    "plx_cde_create": [C.POINTER(_vp), _i64, _i64, _vp],
+    "plx_cde_destroy": [_vp],
+    "plx_cde_apply_dev": [_vp, _vp, _vp, _i64, C.c_int, _vp],
+    "plx_cde_ofde": [_vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _i64, _vp, _vp, _vp, _vp],
+    "plx_cmaadaptivefilter": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, _dbl, _vp, _vp],
+    "plx_easiadaptivefilter": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _vp, _vp],
+    "plx_poldemux_dev": [C.c_int, _vp, _vp, _i64, C.c_int, _i32, _dbl, _vp, _vp, _vp, _vp, _vp],
+    "plx_dsp_create": [C.POINTER(_vp), _i64, _i32, _i32, C.POINTER(DspParams)],
+    "plx_dsp_destroy": [_vp],
+    "plx_dsp_run_dev": [_vp, _vp, _vp, C.c_int, _vp],
+    "plx_dsp_out_len": [_vp],
+    "plx_decide_count_dev": [_vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _vp],
+    "plx_pick_dev": [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, C.c_int, _vp],
+}
+_RESTYPES = {"plx_dsp_out_len": _i64}
+
+
+class Binding:
+    """One loaded copy of the library with checked calls."""
+
+    def __init__(self, path=None):
+        path = path or LIB_PATH
+        if not os.path.exists(path):
+            raise PolmuxError(PLX_ERR_HIP,
+                              "libpolmux_hip.so not found at %s: build it with "
+                              "`python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
+        self.path = path
+        self.lib = C.CDLL(path)
+        self.lib.plx_last_error.restype = C.c_char_p
+        for name, args in SIGNATURES.items():
+            fn = getattr(self.lib, name)          # AttributeError if a symbol is missing
+            fn.argtypes = args
+            fn.restype = _RESTYPES.get(name, C.c_int)
+
+    def last_error(self):
+        return self.lib.plx_last_error().decode("utf-8", "replace")
+
+    def call(self, name, *args):
+        rc = getattr(self.lib, name)(*args)
+        if rc != PLX_OK:
+            raise PolmuxError(rc, self.last_error() or ("%s failed with code %d" % (name, rc)))
+        return rc
+
+
+_default = None
+
+
+def get():
+    """The process-wide binding of the real (hipcc-built) library."""
+    global _default
+    if _default is None:
+        _default = Binding()
+    return _default

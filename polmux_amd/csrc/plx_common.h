@@ -1,0 +1,51 @@
+// plx_common.h -- shared definitions for the gfx950 kernels of libpolmux_hip.
+//
+// The kernels are written for CDNA4 only (64-lane waves, 160 KiB LDS per CU).
+// -DPLX_EMU swaps the HIP runtime header for tests/emu/hip_emu.h, a host-side
+// emulator used exclusively by the sanitizer/unit tests; the shipped library is
+// always the hipcc build.
+#pragma once
+#ifdef PLX_EMU
+#include "hip_emu.h"
+#define PLX_LAUNCH(kern, grid, block, shmem, stream, ...) PLX_EMU_LAUNCH(kern, grid, block, shmem, stream, __VA_ARGS__)
+#define PLX_DYN_LDS(name) char *name = emu::dyn_lds()
+#else
+#include <hip/hip_runtime.h>
+#define PLX_LAUNCH(kern, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kern, grid, block, shmem, (hipStream_t)(stream), __VA_ARGS__)
+// all LDS lives in the dynamic region, base 16-byte aligned (guide G17)
+#define PLX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#endif
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+
+typedef double2 cplx; // interleaved complex128: x = re, y = im
+
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cplx cmulc(cplx a, cplx b) { return make_double2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); } // a*conj(b)
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx cscale(cplx a, double s) { return make_double2(a.x * s, a.y * s); }
+__device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
+__device__ __forceinline__ cplx cmuli(cplx a) { return make_double2(-a.y, a.x); }  // a * i
+__device__ __forceinline__ cplx cmulni(cplx a) { return make_double2(a.y, -a.x); } // a * (-i)
+__device__ __forceinline__ cplx cexpi(double a)
+{
+    double s, c;
+    sincos(a, &s, &c);
+    return make_double2(c, s);
+}
+
+// ---- error plumbing (host) ------------------------------------------------------
+void plx_set_error(const std::string &msg);
+#define PLX_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            plx_set_error(std::string(#call) + ": " + hipGetErrorString(e_));                  \
+            return PLX_ERR_HIP;                                                                \
+        }                                                                                      \
+    } while (0)
+#define PLX_FAIL(code, msg) do { plx_set_error(msg); return (code); } while (0)

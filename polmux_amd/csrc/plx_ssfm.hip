@@ -1,0 +1,751 @@
+// plx_ssfm.hip -- split-step Fourier propagator of fiber.m on gfx950.
+//
+// Reference: /root/reference/fiber.m:459-935 (matrix_ssfm, scalar_ssfm, nextstep,
+// checkstep, lin_step, nl_step, matrix_nl_step, matrix_step).
+//
+// MI355X design (not a translation of the MATLAB): one SSFM step is THREE sweeps
+// over the field, organised around a four-step FFT  N = N1 x N2  whose forward
+// half is decimation-in-frequency and whose inverse half is decimation-in-time,
+// so the spectrum is only ever held in (bit-reversed, transposed) order and no
+// reorder pass exists:
+//
+//   k_col_fwd  load N1 x 16 column tile -> [Kerr step fused on load] -> N1-point
+//              DIF in LDS -> store in place
+//   k_row      load rows -> x inter-pass twiddle -> N2-point DIF in LDS ->
+//              x exp(-i beta dz) / PMD waveplates (both polarisations of one
+//              frequency co-resident) -> N2-point DIT -> x conj twiddle -> store
+//   k_col_inv  load column tile -> N1-point DIT -> x exp(-alpha dz/2)/N ->
+//              wave-shuffle max of |ux|^2+|uy|^2 -> one atomicMax per workgroup
+//   k_ctrl     one lane per frame: nextstep + checkstep + last-step rule; the
+//              data-dependent step loop never round-trips to the host
+//
+// Twiddles of the in-LDS transforms are staged in LDS; frames of a batch carry
+// their own step state, so a batch of Monte-Carlo realisations advances in
+// lock-step launches while every frame keeps the reference's own step sequence.
+#include "../../include/polmux_hip.h"
+#include "plx_fft.h"
+
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+namespace {
+
+struct FrameCtl {
+    double zprop, dz;       // running distance, last nextstep() result      fiber.m:512-535
+    double cur;             // length of the step being executed (dz or last_step :538)
+    double leff, att;       // effective length of cur (:787-791), exp(-alpha/2*cur) (:531)
+    double dz_miss;         // checkstep state (:741-757)
+    double firstdz;
+    double dzb_first, dzb_last;
+    int ntot, nmem, ntrunk; // waveplate bookkeeping (:524-529)
+    int started, last, done, ncycle;
+    int pad_[3];
+};
+
+struct SsfmArgs {
+    cplx *ux, *uy;
+    const double *betat_p, *db1_p; // [nfc][N], bit-reversed/transposed order
+    const cplx *tpass;             // [N] inter-pass twiddles W_N^(n2*k1), same order
+    const cplx *tw1, *tw2;         // half tables W_N1^k, W_N2^k
+    const double *gam;             // [nfc] effective gamma (x8/9 when Manakov, :499-501)
+    const double *brf;             // [sets][nplates][9]: R11 R12 R21 R22 (re,im) db0
+    double *psum;                  // [F][N] row-sum of channel powers (scalar XPM, :795)
+    FrameCtl *ctl;
+    unsigned long long *umax;      // [F][nfc] bit pattern of max |u|^2 (>= 0)
+    int *ndone;
+    int p1, p2, nfc, dual, W, logW, R, logR;
+    int spm, xpm, manakov, pmd, nplates, brf_per_frame;
+    double alphalin, Lf, dzmax, dphimax, lcorr, invN;
+};
+
+__device__ __forceinline__ double wave_max(double v)
+{
+    for (int m = 32; m >= 1; m >>= 1) {
+        double o = __shfl_xor(v, m, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// block-wide max -> one atomicMax.  red: LDS scratch of >= 16 doubles.
+__device__ __forceinline__ void block_atomic_max(double v, double *red, unsigned long long *dst, int tid, int nthr)
+{
+    v = wave_max(v);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        double m = red[0];
+        for (int w = 1; w < (nthr + 63) / 64; w++) m = red[w] > m ? red[w] : m;
+        atomicMax(dst, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+// ---------------------------------------------------------------- initial max ---
+// Umax of nextstep (fiber.m:693-697) for the field as handed to fiber().
+__global__ __launch_bounds__(256) void k_umax(SsfmArgs a)
+{
+    PLX_DYN_LDS(lds);
+    double *red = (double *)lds;
+    const int fc = blockIdx.y;
+    const size_t N = (size_t)1 << (a.p1 + a.p2);
+    const cplx *x = a.ux + (size_t)fc * N;
+    const cplx *y = a.dual ? a.uy + (size_t)fc * N : nullptr;
+    double m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) {
+        cplx v = x[i];
+        double p = v.x * v.x + v.y * v.y;
+        if (y) {
+            cplx w = y[i];
+            p = p + w.x * w.x;
+            p = p + w.y * w.y;
+        }
+        m = p > m ? p : m;
+    }
+    block_atomic_max(m, red, a.umax + fc, threadIdx.x, blockDim.x);
+}
+
+// --------------------------------------------------------------- step control ---
+// nextstep (fiber.m:682-715), the loop head/tail of matrix_ssfm/scalar_ssfm
+// (:512-551, :585-636) and checkstep (:718-758), one lane per frame.
+__global__ void k_ctrl(SsfmArgs a, int nframes)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    FrameCtl c = a.ctl[f];
+    if (c.done) return;
+    if (c.started) {
+        if (a.dual) c.ntot = c.ntot + c.ntrunk - c.nmem; // :529
+        if (c.last) {
+            c.done = 1;
+            a.ctl[f] = c;
+            atomicAdd(a.ndone, 1);
+            return;
+        }
+    }
+    // nextstep
+    double Pmax = -INFINITY;
+    for (int k = 0; k < a.nfc; k++) {
+        double Umax = __longlong_as_double((long long)a.umax[f * a.nfc + k]);
+        double gp = a.gam[k] * Umax;
+        Pmax = gp > Pmax ? gp : Pmax;
+        a.umax[f * a.nfc + k] = 0ull;
+    }
+    double leffn = a.dphimax / Pmax;
+    double dl = a.alphalin * leffn;
+    double dz;
+    if (dl >= 1) {
+        dz = a.dzmax;
+    } else {
+        double step = (a.alphalin == 0) ? leffn : -1 / a.alphalin * log(1 - dl);
+        dz = step > a.dzmax ? a.dzmax : step;
+    }
+    if (!c.started) {
+        c.started = 1;
+        c.firstdz = dz;
+        c.zprop = dz;
+        c.ncycle = 1;
+    } else {
+        c.zprop = c.zprop + dz;
+        c.ncycle = c.ncycle + 1;
+    }
+    c.dz = dz;
+    double zc;
+    if (c.zprop < a.Lf) {
+        c.cur = dz; c.last = 0; zc = c.zprop;
+    } else {
+        c.cur = a.Lf - c.zprop + dz; c.last = 1; zc = a.Lf; // :538, :545
+    }
+    c.leff = (a.alphalin == 0) ? c.cur : (1 - exp(-a.alphalin * c.cur)) / a.alphalin;
+    c.att = exp(-(0.5 * a.alphalin) * c.cur);
+    if (a.dual) { // checkstep
+        const double lcorr = a.lcorr;
+        int nzc = (int)ceil(zc / lcorr);
+        if (c.dz_miss == 0) {
+            c.nmem = 0;
+            c.ntrunk = nzc - c.ntot;
+            double dzlast = c.cur - lcorr * (c.ntrunk - 1);
+            c.dzb_first = c.ntrunk > 1 ? lcorr : dzlast;
+            c.dzb_last = dzlast;
+            c.dz_miss = lcorr - dzlast;
+        } else {
+            c.nmem = 1;
+            c.ntrunk = nzc - c.ntot + 1;
+            if (c.ntrunk == 1) {
+                c.dzb_first = c.cur; c.dzb_last = c.cur;
+                c.dz_miss = c.dz_miss - c.cur;
+            } else {
+                double dzlast = c.cur - c.dz_miss - lcorr * (c.ntrunk - 2);
+                c.dzb_first = c.dz_miss; c.dzb_last = dzlast;
+                c.dz_miss = lcorr - dzlast;
+            }
+        }
+    }
+    a.ctl[f] = c;
+}
+
+// ------------------------------------------------- scalar XPM row sum (:795) ---
+__global__ __launch_bounds__(256) void k_rowsum(SsfmArgs a)
+{
+    const int f = blockIdx.y;
+    if (a.ctl[f].done) return;
+    const size_t N = (size_t)1 << (a.p1 + a.p2);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) {
+        double sum = 0;
+        for (int k = 0; k < a.nfc; k++) {
+            cplx v = a.ux[((size_t)f * a.nfc + k) * N + i];
+            sum += v.x * v.x + v.y * v.y;
+        }
+        a.psum[(size_t)f * N + i] = sum;
+    }
+}
+
+// ------------------------------------------------------------ pass 1: columns ---
+// Kerr step (matrix_nl_step :832-852 / nl_step :792-804) fused into the load of
+// the forward column transform.  Tile = N1 rows x 16 complex (dual: 8 columns of
+// ux | 8 of uy; scalar: 16 columns), i.e. 256 contiguous bytes of LDS per row.
+__global__ __launch_bounds__(256) void k_col_fwd(SsfmArgs a)
+{
+    PLX_DYN_LDS(lds);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
+    const FrameCtl *ctl = a.ctl + f;
+    if (ctl->done) return;
+    const int N1 = 1 << a.p1, N2 = 1 << a.p2;
+    cplx *s = (cplx *)lds;
+    cplx *tw = s + (size_t)N1 * 16;
+    lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, nthr);
+    const size_t base = (size_t)fc << (a.p1 + a.p2);
+    const int col0 = blockIdx.x * a.W;
+    const double leff = ctl->leff;
+    const double gamleff = a.gam[c] * leff;
+    const int nel = N1 << a.logW;
+    if (a.dual) {
+        for (int e = tid; e < nel; e += nthr) {
+            const int row = e >> a.logW, col = e & (a.W - 1);
+            const size_t g = base + (size_t)row * N2 + col0 + col;
+            cplx x = a.ux[g], y = a.uy[g];
+            if (a.spm) {
+                const double P = x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y; // :834-835
+                const cplx nl = cexpi(-gamleff * P);                              // :837
+                x = cmul(x, nl);
+                y = cmul(y, nl);
+                if (!a.manakov) { // CNLSE rotation :842-850
+                    const double s3 = 2 * (x.x * y.y - x.y * y.x);
+                    double sp, cp;
+                    sincos(gamleff * s3 / 3, &sp, &cp);
+                    const cplx xx = make_double2(cp * x.x + sp * y.x, cp * x.y + sp * y.y);
+                    const cplx yy = make_double2(cp * y.x - sp * x.x, cp * y.y - sp * x.y);
+                    x = xx; y = yy;
+                }
+            }
+            s[row * 16 + col] = x;
+            s[row * 16 + 8 + col] = y;
+        }
+    } else {
+        const bool active = a.spm || a.xpm; // :800-802
+        for (int e = tid; e < nel; e += nthr) {
+            const int row = e >> a.logW, col = e & (a.W - 1);
+            const size_t off = (size_t)row * N2 + col0 + col;
+            cplx x = a.ux[base + off];
+            if (active) {
+                double pw = x.x * x.x + x.y * x.y; // :792
+                if (a.xpm) {
+                    const double tot = a.psum[((size_t)f << (a.p1 + a.p2)) + off];
+                    pw = a.spm ? 2 * tot - pw : 2 * (tot - pw); // :795,797
+                }
+                x = cmul(x, cexpi(-a.gam[c] * pw * leff)); // :804
+            }
+            s[row * 16 + col] = x;
+        }
+    }
+    __syncthreads();
+    lds_fft_dif(s, a.p1, 16, 1, 4, tw, tid, nthr, true);
+    if (a.dual) {
+        for (int e = tid; e < nel; e += nthr) {
+            const int row = e >> a.logW, col = e & (a.W - 1);
+            const size_t g = base + (size_t)row * N2 + col0 + col;
+            a.ux[g] = s[row * 16 + col];
+            a.uy[g] = s[row * 16 + 8 + col];
+        }
+    } else {
+        for (int e = tid; e < nel; e += nthr) {
+            const int row = e >> a.logW, col = e & (a.W - 1);
+            a.ux[base + (size_t)row * N2 + col0 + col] = s[row * 16 + col];
+        }
+    }
+}
+
+// --------------------------------------------------------------- pass 2: rows ---
+// Second half of the forward transform, the linear operator of the step
+// (lin_step :771-773 / matrix_step :907-933) and the first half of the inverse
+// transform, all on one LDS-resident row set.
+__global__ __launch_bounds__(256) void k_row(SsfmArgs a)
+{
+    PLX_DYN_LDS(lds);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
+    const FrameCtl *ctl = a.ctl + f;
+    if (ctl->done) return;
+    const int N2 = 1 << a.p2, R = a.R;
+    cplx *s = (cplx *)lds;                       // [npol*R][N2]
+    cplx *tw = s + (size_t)(a.dual ? 2 : 1) * R * N2;
+    lds_load_twiddles(tw, a.tw2, N2 >> 1, tid, nthr);
+    const size_t N = (size_t)1 << (a.p1 + a.p2);
+    const size_t base = (size_t)fc * N;
+    const int j0 = blockIdx.x * R;
+    const int nel = R << a.p2;
+    for (int e = tid; e < nel; e += nthr) {
+        const int r = e >> a.p2, i = e & (N2 - 1);
+        const size_t fi = (size_t)(j0 + r) * N2 + i;
+        const cplx t = a.tpass[fi];
+        s[r * N2 + i] = cmul(a.ux[base + fi], t);
+        if (a.dual) s[(R + r) * N2 + i] = cmul(a.uy[base + fi], t);
+    }
+    __syncthreads();
+    lds_fft_dif(s, a.p2, 1, N2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr, false);
+    const double cur = ctl->cur;
+    const double *bt = a.betat_p + (size_t)c * N;
+    if (!a.dual) {
+        for (int e = tid; e < nel; e += nthr) { // Hf = fastexp(-betat*dz) :771
+            const int r = e >> a.p2, i = e & (N2 - 1);
+            const size_t fi = (size_t)(j0 + r) * N2 + i;
+            s[r * N2 + i] = cmul(s[r * N2 + i], cexpi(-(bt[fi] * cur)));
+        }
+    } else if (!a.pmd) {
+        // zero birefringence, one trunk (fiber.m:291-297): matR = I, deltabeta = 0
+        for (int e = tid; e < nel; e += nthr) {
+            const int r = e >> a.p2, i = e & (N2 - 1);
+            const size_t fi = (size_t)(j0 + r) * N2 + i;
+            const cplx h = cexpi(-(bt[fi] * cur));
+            s[r * N2 + i] = cmul(h, s[r * N2 + i]);
+            s[(R + r) * N2 + i] = cmul(h, s[(R + r) * N2 + i]);
+        }
+    } else {
+        const double *d1 = a.db1_p + (size_t)c * N;
+        const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * 9 : 0);
+        const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem; // plate of piece k: n0+k (1-based) :908
+        const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last, lcorr = a.lcorr;
+        for (int e = tid; e < nel; e += nthr) {
+            const int r = e >> a.p2, i = e & (N2 - 1);
+            const size_t fi = (size_t)(j0 + r) * N2 + i;
+            const double btf = bt[fi], d1f = d1[fi];
+            cplx x = s[r * N2 + i], y = s[(R + r) * N2 + i];
+            for (int k = 1; k <= ntrunk; k++) {
+                int plate = n0 + k - 1; // the reference indexes brf.theta(n) unchecked; stay in bounds
+                plate = plate < 0 ? 0 : (plate >= a.nplates ? a.nplates - 1 : plate);
+                const double *m = brf + (size_t)plate * 9;
+                const cplx R11 = make_double2(m[0], m[1]), R12 = make_double2(m[2], m[3]);
+                const cplx R21 = make_double2(m[4], m[5]), R22 = make_double2(m[6], m[7]);
+                const double dzk = (k == 1) ? dzb_first : (k == ntrunk ? dzb_last : lcorr);
+                cplx uux = cadd(cmulc(x, R11), cmulc(y, R21));                 // :920
+                cplx uuy = cadd(cmulc(x, R12), cmulc(y, R22));                 // :921
+                const double combeta = btf * dzk;                              // :924
+                const double deltabeta = 0.5 * (d1f + m[8]) * dzk / lcorr;     // :925
+                uux = cmul(cexpi(-(combeta + deltabeta)), uux);                // :927
+                uuy = cmul(cexpi(-(combeta - deltabeta)), uuy);                // :928
+                x = cadd(cmul(R11, uux), cmul(R12, uuy));                      // :931
+                y = cadd(cmul(R21, uux), cmul(R22, uuy));                      // :932
+            }
+            s[r * N2 + i] = x;
+            s[(R + r) * N2 + i] = y;
+        }
+    }
+    __syncthreads();
+    lds_fft_dit(s, a.p2, 1, N2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr, false);
+    for (int e = tid; e < nel; e += nthr) {
+        const int r = e >> a.p2, i = e & (N2 - 1);
+        const size_t fi = (size_t)(j0 + r) * N2 + i;
+        const cplx t = a.tpass[fi];
+        a.ux[base + fi] = cmulc(s[r * N2 + i], t);
+        if (a.dual) a.uy[base + fi] = cmulc(s[(R + r) * N2 + i], t);
+    }
+}
+
+// ------------------------------------------------------ pass 3: inverse columns ---
+// Completes ifft (1/N), applies the attenuation of the step (:531-532) and feeds
+// nextstep's global maximum (:694-696) -- no extra pass over the field.
+__global__ __launch_bounds__(256) void k_col_inv(SsfmArgs a)
+{
+    PLX_DYN_LDS(lds);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int fc = blockIdx.y, f = fc / a.nfc;
+    const FrameCtl *ctl = a.ctl + f;
+    if (ctl->done) return;
+    const int N1 = 1 << a.p1, N2 = 1 << a.p2;
+    cplx *s = (cplx *)lds;
+    cplx *tw = s + (size_t)N1 * 16;
+    double *red = (double *)(tw + (N1 >> 1));
+    lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, nthr);
+    const size_t base = (size_t)fc << (a.p1 + a.p2);
+    const int col0 = blockIdx.x * a.W;
+    const int nel = N1 << a.logW;
+    for (int e = tid; e < nel; e += nthr) {
+        const int row = e >> a.logW, col = e & (a.W - 1);
+        const size_t g = base + (size_t)row * N2 + col0 + col;
+        s[row * 16 + col] = a.ux[g];
+        if (a.dual) s[row * 16 + 8 + col] = a.uy[g];
+    }
+    __syncthreads();
+    lds_fft_dit(s, a.p1, 16, 1, 4, tw, tid, nthr, true);
+    const double sc = ctl->att * a.invN;
+    double m = 0;
+    for (int e = tid; e < nel; e += nthr) {
+        const int row = e >> a.logW, col = e & (a.W - 1);
+        const size_t g = base + (size_t)row * N2 + col0 + col;
+        cplx x = cscale(s[row * 16 + col], sc);
+        double p = x.x * x.x + x.y * x.y;
+        a.ux[g] = x;
+        if (a.dual) {
+            cplx y = cscale(s[row * 16 + 8 + col], sc);
+            p = p + y.x * y.x;
+            p = p + y.y * y.y;
+            a.uy[g] = y;
+        }
+        m = p > m ? p : m;
+    }
+    block_atomic_max(m, red, a.umax + fc, tid, nthr);
+}
+
+} // namespace
+
+// ================================================================= host side ===
+struct plx_ssfm {
+    plx_ssfm_desc d;
+    int p, p1, p2;
+    size_t N;
+    SsfmArgs a;
+    double *d_betat = nullptr, *d_db1 = nullptr, *d_gam = nullptr, *d_brf = nullptr, *d_psum = nullptr;
+    cplx *d_tpass = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
+    FrameCtl *d_ctl = nullptr;
+    unsigned long long *d_umax = nullptr;
+    int *d_ndone = nullptr;
+    int *h_ndone = nullptr; // pinned
+    std::vector<FrameCtl> h_ctl;
+    int brf_sets = 0;
+    size_t lds_col = 0, lds_row = 0;
+    int64_t row_launches = 0, sample_steps = 0;
+};
+
+static int ilog2(int64_t v)
+{
+    int l = 0;
+    while (((int64_t)1 << l) < v) l++;
+    return l;
+}
+
+static void free_plan(plx_ssfm *P)
+{
+    if (!P) return;
+    hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
+    hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
+    hipFree(P->d_ndone);
+    if (P->h_ndone) hipHostFree(P->h_ndone);
+    delete P;
+}
+
+static void half_table(std::vector<cplx> &t, int M)
+{
+    t.resize(M / 2 > 0 ? M / 2 : 1);
+    for (int k = 0; k < M / 2; k++) {
+        long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)M;
+        t[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+}
+
+#ifndef PLX_EMU
+template <class K> static hipError_t allow_lds(K kern, size_t bytes)
+{
+    return hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+#else
+template <class K> static hipError_t allow_lds(K, size_t) { return hipSuccess; }
+#endif
+
+extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
+{
+    if (!out || !desc) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: null argument");
+    *out = nullptr;
+    const int64_t N = desc->nfft;
+    const int p = ilog2(N);
+    if (N < 256 || ((int64_t)1 << p) != N || p > 20)
+        PLX_FAIL(PLX_ERR_UNSUPPORTED, "plx_ssfm_create: nfft must be a power of two in [256, 2^20]");
+    if (desc->nfc < 1 || desc->max_frames < 1) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: nfc and max_frames must be >= 1");
+    if (!desc->gam || !desc->betat) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: gam and betat are required");
+    if (desc->dual_pol && desc->fls[3] && desc->nfc > 1)
+        PLX_FAIL(PLX_ERR_REFERENCE, "The CNLSE with separate fields is not yet implemented"); // fiber.m:854
+    if (desc->dual_pol && desc->fls[3] && desc->nfc == 1) { /* xpm flag is forced to 0 for one field, :224 */ }
+    if (desc->nplates < 1) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: nplates must be >= 1");
+
+    plx_ssfm *P = new plx_ssfm();
+    P->d = *desc;
+    P->p = p;
+    P->p1 = (p + 1) / 2;
+    if (P->p1 > 9) P->p1 = 9; // column tile of 512 rows x 256 B = 128 KiB of LDS
+    P->p2 = p - P->p1;
+    P->N = (size_t)N;
+    const int N1 = 1 << P->p1, N2 = 1 << P->p2;
+    const int nfc = desc->nfc, F = desc->max_frames;
+    SsfmArgs &a = P->a;
+    std::memset(&a, 0, sizeof(a));
+    a.p1 = P->p1; a.p2 = P->p2; a.nfc = nfc; a.dual = desc->dual_pol ? 1 : 0;
+    a.W = a.dual ? 8 : 16; a.logW = a.dual ? 3 : 4;
+    // rows per workgroup in the row pass: keep >= 256 butterflies per radix-4 stage
+    {
+        int R = 1, npol = a.dual ? 2 : 1;
+        while (R * npol * (N2 / 4) < 256 && R * 2 <= N1) R *= 2;
+        a.R = R; a.logR = ilog2(R);
+    }
+    a.spm = desc->fls[2]; a.xpm = desc->fls[3]; a.manakov = desc->manakov ? 1 : 0; a.pmd = desc->fls[1] ? 1 : 0;
+    a.nplates = desc->nplates;
+    a.alphalin = desc->alphalin; a.Lf = desc->length; a.dzmax = desc->dzmaxt; a.dphimax = desc->dphimaxt;
+    a.lcorr = desc->length / desc->nplates; // fiber.m:507
+    a.invN = 1.0 / (double)N;
+
+    // ---- tables: spectral multipliers in the order the row pass sees them ----
+    std::vector<double> bt((size_t)nfc * N), d1;
+    std::vector<cplx> tp((size_t)N);
+    const bool have_db1 = desc->db1 != nullptr && a.dual;
+    if (have_db1) d1.resize((size_t)nfc * N);
+    for (int j = 0; j < N1; j++) {
+        const unsigned k1 = plx_bitrev((unsigned)j, P->p1);
+        for (int i = 0; i < N2; i++) {
+            const unsigned k2 = plx_bitrev((unsigned)i, P->p2);
+            const size_t k = (size_t)k1 + (size_t)N1 * k2, pos = (size_t)j * N2 + i;
+            for (int c = 0; c < nfc; c++) {
+                bt[(size_t)c * N + pos] = desc->betat[(size_t)c * N + k];
+                if (have_db1) d1[(size_t)c * N + pos] = desc->db1[(size_t)c * N + k];
+            }
+            const uint64_t e = ((uint64_t)i * k1) & (uint64_t)(N - 1); // n2*k1 mod N
+            long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)e / (long double)N;
+            tp[pos] = make_double2((double)cosl(ang), (double)sinl(ang));
+        }
+    }
+    std::vector<cplx> t1, t2;
+    half_table(t1, N1);
+    half_table(t2, N2);
+    std::vector<double> gam(nfc);
+    for (int c = 0; c < nfc; c++) gam[c] = (a.dual && a.manakov) ? desc->gam[c] * 8 / 9 : desc->gam[c]; // :499-501
+
+#define UP(dst, vec, T)                                                                             \
+    do {                                                                                            \
+        if (hipMalloc((void **)&(dst), (vec).size() * sizeof(T)) != hipSuccess ||                   \
+            hipMemcpy((dst), (vec).data(), (vec).size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { \
+            free_plan(P);                                                                           \
+            PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation/upload failed");              \
+        }                                                                                           \
+    } while (0)
+    UP(P->d_betat, bt, double);
+    if (have_db1) UP(P->d_db1, d1, double);
+    UP(P->d_tpass, tp, cplx);
+    UP(P->d_tw1, t1, cplx);
+    UP(P->d_tw2, t2, cplx);
+    UP(P->d_gam, gam, double);
+#undef UP
+    bool ok = hipMalloc((void **)&P->d_ctl, sizeof(FrameCtl) * F) == hipSuccess &&
+              hipMalloc((void **)&P->d_umax, sizeof(unsigned long long) * F * nfc) == hipSuccess &&
+              hipMalloc((void **)&P->d_ndone, 64) == hipSuccess &&
+              hipHostMalloc((void **)&P->h_ndone, 64, hipHostMallocDefault) == hipSuccess;
+    if (ok && !a.dual && a.xpm) ok = hipMalloc((void **)&P->d_psum, sizeof(double) * (size_t)F * N) == hipSuccess;
+    if (!ok) { free_plan(P); PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed"); }
+    a.betat_p = P->d_betat; a.db1_p = P->d_db1; a.tpass = P->d_tpass; a.tw1 = P->d_tw1; a.tw2 = P->d_tw2;
+    a.gam = P->d_gam; a.ctl = P->d_ctl; a.umax = P->d_umax; a.ndone = P->d_ndone; a.psum = P->d_psum;
+    P->h_ctl.resize(F);
+
+    P->lds_col = ((size_t)N1 * 16 + N1 / 2) * sizeof(cplx) + 16 * sizeof(double);
+    P->lds_row = ((size_t)(a.dual ? 2 : 1) * a.R * N2 + N2 / 2) * sizeof(cplx);
+    if (allow_lds(k_col_fwd, P->lds_col) != hipSuccess || allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
+        allow_lds(k_row, P->lds_row) != hipSuccess) {
+        free_plan(P);
+        PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
+    }
+    if (a.pmd && !a.dual) { free_plan(P); PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: PMD needs a dual-polarisation plan"); }
+    if (!a.pmd) { // fiber.m:291-297: birefringence off
+        double z = 0;
+        int rc = plx_ssfm_set_birefringence(P, &z, &z, &z, 1);
+        if (rc) { free_plan(P); return rc; }
+    }
+    *out = P;
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_destroy(plx_ssfm *P)
+{
+    free_plan(P);
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_set_birefringence(plx_ssfm *P, const double *db0, const double *theta,
+                                          const double *epsilon, int nsets)
+{
+    if (!P || !db0 || !theta || !epsilon) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_set_birefringence: null argument");
+    if (nsets != 1 && nsets > P->d.max_frames) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_set_birefringence: more sets than frames");
+    const int np = P->d.nplates;
+    std::vector<double> t((size_t)nsets * np * 9);
+    for (int sidx = 0; sidx < nsets; sidx++)
+        for (int n = 0; n < np; n++) {
+            const size_t i = (size_t)sidx * np + n;
+            // matR = matRth*matRepsilon, fiber.m:910-912
+            const double ct = cos(theta[i]), st = sin(theta[i]), ce = cos(epsilon[i]), se = sin(epsilon[i]);
+            double *m = &t[i * 9];
+            m[0] = ct * ce;  m[1] = -st * se; // R11
+            m[2] = -st * ce; m[3] = ct * se;  // R12
+            m[4] = st * ce;  m[5] = ct * se;  // R21
+            m[6] = ct * ce;  m[7] = st * se;  // R22
+            m[8] = db0[i];
+        }
+    if (P->d_brf) { hipFree(P->d_brf); P->d_brf = nullptr; }
+    PLX_HIP(hipMalloc((void **)&P->d_brf, t.size() * sizeof(double)));
+    PLX_HIP(hipMemcpy(P->d_brf, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    P->a.brf = P->d_brf;
+    P->a.brf_per_frame = nsets > 1 ? 1 : 0;
+    P->brf_sets = nsets;
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, int nframes, void *stream)
+{
+    if (!P || !d_ux) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: null argument");
+    if (nframes < 1 || nframes > P->d.max_frames) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: nframes out of range");
+    if (P->a.dual && !d_uy) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: dual-polarisation plan needs d_uy");
+    if (P->a.brf_per_frame && P->brf_sets < nframes)
+        PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: fewer birefringence sets than frames");
+    hipStream_t st = (hipStream_t)stream;
+    SsfmArgs a = P->a;
+    a.ux = (cplx *)d_ux;
+    a.uy = (cplx *)d_uy;
+    const int nfc = a.nfc, N1 = 1 << a.p1, N2 = 1 << a.p2;
+    const unsigned FC = (unsigned)nframes * nfc;
+    PLX_HIP(hipMemsetAsync(P->d_ctl, 0, sizeof(FrameCtl) * nframes, st));
+    PLX_HIP(hipMemsetAsync(P->d_umax, 0, sizeof(unsigned long long) * FC, st));
+    PLX_HIP(hipMemsetAsync(P->d_ndone, 0, 64, st));
+    {
+        unsigned gx = (unsigned)((P->N + 255) / 256);
+        if (gx > 64) gx = 64;
+        PLX_LAUNCH(k_umax, dim3(gx, FC), dim3(256), 16 * sizeof(double), st, a);
+    }
+    const dim3 gcol((unsigned)(N2 / a.W), FC), grow((unsigned)(N1 / a.R), FC), blk(256);
+    const dim3 gctl((unsigned)((nframes + 63) / 64)), bctl(64);
+    P->row_launches = 0;
+    // Data-dependent trip count (fiber.m:518): steps are enqueued in chunks; the
+    // completed-frame counter of chunk k is read back while chunk k+1 executes.
+    int chunk = 4, steps = 0;
+    const int kMaxSteps = 1 << 22;
+    hipEvent_t ev;
+    PLX_HIP(hipEventCreate(&ev));
+    bool pending = false;
+    for (;;) {
+        for (int sidx = 0; sidx < chunk; sidx++) {
+            PLX_LAUNCH(k_ctrl, gctl, bctl, 0, st, a, nframes);
+            if (!a.dual && a.xpm) {
+                unsigned gx = (unsigned)((P->N + 255) / 256);
+                if (gx > 256) gx = 256;
+                PLX_LAUNCH(k_rowsum, dim3(gx, (unsigned)nframes), blk, 0, st, a);
+            }
+            PLX_LAUNCH(k_col_fwd, gcol, blk, P->lds_col, st, a);
+            PLX_LAUNCH(k_row, grow, blk, P->lds_row, st, a);
+            PLX_LAUNCH(k_col_inv, gcol, blk, P->lds_col, st, a);
+            P->row_launches++;
+        }
+        steps += chunk;
+        if (pending) {
+            PLX_HIP(hipEventSynchronize(ev));
+            if (*P->h_ndone >= nframes) break;
+        }
+        PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, sizeof(int), hipMemcpyDeviceToHost, st));
+        PLX_HIP(hipEventRecord(ev, st));
+        pending = true;
+        if (chunk < 32) chunk *= 2;
+        if (steps > kMaxSteps) { hipEventDestroy(ev); PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate"); }
+    }
+    PLX_HIP(hipMemcpyAsync(P->h_ctl.data(), P->d_ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost, st));
+    PLX_HIP(hipStreamSynchronize(st));
+    hipEventDestroy(ev);
+    P->sample_steps = 0;
+    for (int f = 0; f < nframes; f++) {
+        if (!P->h_ctl[f].done) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: a frame did not reach the fibre end");
+        P->sample_steps += (int64_t)P->h_ctl[f].ncycle * (int64_t)P->N * nfc;
+    }
+    PLX_HIP(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_results(plx_ssfm *P, int nframes, double *firstdz, int32_t *ncycle)
+{
+    if (!P || nframes < 1 || nframes > P->d.max_frames) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_results: bad argument");
+    for (int f = 0; f < nframes; f++) {
+        if (firstdz) firstdz[f] = P->h_ctl[f].firstdz;
+        if (ncycle) ncycle[f] = P->h_ctl[f].ncycle;
+    }
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_stats(plx_ssfm *P, int64_t *row_pass_launches, int64_t *sample_steps)
+{
+    if (!P) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_stats: null plan");
+    if (row_pass_launches) *row_pass_launches = P->row_launches;
+    if (sample_steps) *sample_steps = P->sample_steps;
+    return PLX_OK;
+}
+
+// ---- gateway forms (one frame, split planes, host memory) --------------------------
+static int gateway_ssfm(double *uxr, double *uxi, double *uyr, double *uyi, const plx_ssfm_desc *desc,
+                        const double *db0, const double *theta, const double *epsilon, double *firstdz,
+                        int32_t *ncycle)
+{
+    if (!desc || !uxr) PLX_FAIL(PLX_ERR_ARG, "ssfm gateway: null argument");
+    plx_ssfm_desc d = *desc;
+    d.max_frames = 1;
+    const bool dual = d.dual_pol != 0;
+    if (dual && !uyr) PLX_FAIL(PLX_ERR_ARG, "matrix_ssfm gateway: missing y field");
+    if (!uxi || (dual && !uyi)) PLX_FAIL(PLX_ERR_ARG, "ssfm gateway: output imaginary planes are required");
+    plx_ssfm *P = nullptr;
+    int rc = plx_ssfm_create(&P, &d);
+    if (rc) return rc;
+    if (dual && d.fls[1]) {
+        rc = plx_ssfm_set_birefringence(P, db0, theta, epsilon, 1);
+        if (rc) { plx_ssfm_destroy(P); return rc; }
+    }
+    const size_t n = (size_t)d.nfft * d.nfc;
+    std::vector<double> hx(2 * n), hy(dual ? 2 * n : 0);
+    for (size_t i = 0; i < n; i++) {
+        hx[2 * i] = uxr[i]; hx[2 * i + 1] = uxi[i];
+        if (dual) { hy[2 * i] = uyr[i]; hy[2 * i + 1] = uyi[i]; }
+    }
+    double *dx = nullptr, *dy = nullptr;
+    auto cleanup = [&]() { hipFree(dx); hipFree(dy); plx_ssfm_destroy(P); };
+    if (hipMalloc((void **)&dx, 2 * n * sizeof(double)) != hipSuccess ||
+        (dual && hipMalloc((void **)&dy, 2 * n * sizeof(double)) != hipSuccess)) {
+        cleanup();
+        PLX_FAIL(PLX_ERR_HIP, "ssfm gateway: device allocation failed");
+    }
+    hipMemcpy(dx, hx.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice);
+    if (dual) hipMemcpy(dy, hy.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice);
+    rc = plx_ssfm_propagate_dev(P, dx, dy, 1, nullptr);
+    if (!rc) {
+        hipMemcpy(hx.data(), dx, 2 * n * sizeof(double), hipMemcpyDeviceToHost);
+        if (dual) hipMemcpy(hy.data(), dy, 2 * n * sizeof(double), hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < n; i++) {
+            uxr[i] = hx[2 * i]; uxi[i] = hx[2 * i + 1];
+            if (dual) { uyr[i] = hy[2 * i]; uyi[i] = hy[2 * i + 1]; }
+        }
+        plx_ssfm_results(P, 1, firstdz, ncycle);
+    }
+    cleanup();
+    return rc;
+}
+
+extern "C" int plx_matrix_ssfm(double *uxr, double *uxi, double *uyr, double *uyi, const plx_ssfm_desc *desc,
+                               const double *db0, const double *theta, const double *epsilon,
+                               double *firstdz, int32_t *ncycle)
+{
+    if (desc && !desc->dual_pol) PLX_FAIL(PLX_ERR_ARG, "plx_matrix_ssfm: descriptor is not dual-polarisation");
+    return gateway_ssfm(uxr, uxi, uyr, uyi, desc, db0, theta, epsilon, firstdz, ncycle);
+}
+
+extern "C" int plx_scalar_ssfm(double *ur, double *ui, const plx_ssfm_desc *desc, double *firstdz, int32_t *ncycle)
+{
+    if (desc && desc->dual_pol) PLX_FAIL(PLX_ERR_ARG, "plx_scalar_ssfm: descriptor is dual-polarisation");
+    return gateway_ssfm(ur, ui, nullptr, nullptr, desc, nullptr, nullptr, nullptr, firstdz, ncycle);
+}

@@ -1,0 +1,109 @@
+// hip_emu.cpp -- TEST INFRASTRUCTURE ONLY (see hip_emu.h).
+#include "hip_emu.h"
+#include <chrono>
+
+namespace emu {
+BlockCtx g_ctx;
+thread_local dim3 t_threadIdx, t_blockIdx;
+thread_local unsigned t_linear;
+
+namespace {
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_start, cv_done;
+    uint64_t gen = 0;
+    unsigned active = 0, remaining = 0;
+    const std::function<void()> *body = nullptr;
+    dim3 bidx;
+    bool stop = false;
+
+    void worker(unsigned id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(m);
+            cv_start.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            if (id >= active) continue;
+            lk.unlock();
+            const dim3 b = g_ctx.block;
+            t_linear = id;
+            t_threadIdx = dim3(id % b.x, (id / b.x) % b.y, id / (b.x * b.y));
+            t_blockIdx = bidx;
+            (*body)();
+            g_ctx.wave_bar[id / 64]->arrive_and_drop();
+            g_ctx.bar->arrive_and_drop();
+            lk.lock();
+            if (--remaining == 0) cv_done.notify_all();
+        }
+    }
+    void ensure(unsigned n)
+    {
+        while (th.size() < n) {
+            unsigned id = (unsigned)th.size();
+            th.emplace_back([this, id] { worker(id); });
+        }
+    }
+    void run_block(unsigned n, dim3 b, const std::function<void()> &f)
+    {
+        ensure(n);
+        std::unique_lock<std::mutex> lk(m);
+        active = n;
+        remaining = n;
+        body = &f;
+        bidx = b;
+        ++gen;
+        cv_start.notify_all();
+        cv_done.wait(lk, [&] { return remaining == 0; });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_start.notify_all();
+        for (auto &t : th) t.join();
+    }
+};
+Pool &pool()
+{
+    static Pool p;
+    return p;
+}
+} // namespace
+
+void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body)
+{
+    unsigned n = block.x * block.y * block.z;
+    if (n == 0 || n > 1024) { std::fprintf(stderr, "emu: bad block size %u\n", n); std::abort(); }
+    if (shmem > 160 * 1024) { std::fprintf(stderr, "emu: LDS request %zu > 160 KiB\n", shmem); std::abort(); }
+    static const bool trace = std::getenv("PLX_EMU_TRACE") != nullptr;
+    if (trace) std::fprintf(stderr, "emu launch grid=(%u,%u,%u) block=%u lds=%zu\n", grid.x, grid.y, grid.z, n, shmem);
+    g_ctx.grid = grid;
+    g_ctx.block = block;
+    g_ctx.nthreads = n;
+    g_ctx.xchg.assign(n, 0);
+    for (unsigned bz = 0; bz < grid.z; bz++)
+        for (unsigned by = 0; by < grid.y; by++)
+            for (unsigned bx = 0; bx < grid.x; bx++) {
+                // fresh, poisoned LDS per workgroup so uninitialised reads show up
+                g_ctx.lds.assign(shmem ? shmem : 16, (char)0x7f);
+                g_ctx.bar = std::make_unique<std::barrier<>>((std::ptrdiff_t)n);
+                g_ctx.wave_bar.clear();
+                for (unsigned w = 0; w < (n + 63) / 64; w++) {
+                    unsigned lanes = std::min(64u, n - w * 64);
+                    g_ctx.wave_bar.push_back(std::make_unique<std::barrier<>>((std::ptrdiff_t)lanes));
+                }
+                pool().run_block(n, dim3(bx, by, bz), body);
+            }
+}
+} // namespace emu
+
+double emu_now_ms()
+{
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
