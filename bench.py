@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py -- dual-pol Gsample/s through SSFM + Rx-DSP on MI355X.
+
+One "step" = one pass of the hot path (fiber 'g-s-' split-step Fourier propagation
+-> 2-sps pick -> CDE_OFDE overlap-save -> DspPdmCohQpsk with CMA + carrier recovery
+-> decisions / error count) over ONE BATCH of synthetic PDM-QPSK frames that is
+already resident in HBM when the timed region starts.  Workload at N=1: BASELINE
+config[1] (Run_my_PDM_QPSK-style: 28 Gbaud PDM-QPSK, 2^16-sample frame, one 80 km
+SSMF span + CMA demux), batched over --frames independent frames per GPU.
+
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL); frames are
+independent units, so ranks shard them with no data-path collective (weak scaling);
+the only exchange is the final all-reduce of the error counters.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+SSFM_BYTES_PER_SAMPLE_STEP = 272.0   # 4 sweeps x (32 R + 32 W) + 16 B of betat/db1, dual-pol
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
+    ap.add_argument("--nsymb", type=int, default=1024)
+    ap.add_argument("--nt", type=int, default=64)
+    ap.add_argument("--pavg", type=float, default=2.0)
+    ap.add_argument("--flag", default="g-s-")
+    ap.add_argument("--noise", type=float, default=0.05, help="receiver noise sigma per quadrature (full scale 1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=1)
+    return ap.parse_args()
+
+
+class HipEvents:
+    """HIP events on an explicit stream (torch.cuda.Event only sees torch's current stream)."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+
+    def create(self):
+        e = C.c_void_p()
+        assert self.hip.hipEventCreate(C.byref(e)) == 0
+        return e
+
+    def record(self, e, stream):
+        assert self.hip.hipEventRecord(e, C.c_void_p(stream)) == 0
+
+    def elapsed_ms(self, a, b):
+        assert self.hip.hipEventSynchronize(b) == 0
+        ms = C.c_float()
+        assert self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
+        return ms.value
+
+
+def cpu_baseline(cfg, hp, nframes):
+    """The reference algorithm restated on the CPU (oracle/, kind 'port'), one core, on a bounded
+    sample of the SAME workload: `nframes` frames of the batch."""
+    from oracle import plxo
+    import torch
+    gam, betat, db1 = hp._keep
+    t0 = time.perf_counter()
+    for _ in range(nframes):
+        rc, fd, nc, ox, oy = plxo.matrix_ssfm(hp.tx_host[0], hp.tx_host[1], betat, db1, min(cfg.dzmax, cfg.length),
+                                              cfg.dphimax, gam, hp.alphalin, cfg.length, 1, 0, hp.fls, [0.0], [0.0], [0.0])
+        half = cfg.nt // 2
+        rx = np.stack([ox[::half, 0], oy[::half, 0]], 1) * hp.rx_scale
+        ex, ey, _ = plxo.cde_ofde(rx[:, 0], rx[:, 1], 2 * cfg.symbolrate * 1e9, cfg.lam * 1e-9, cfg.length, cfg.disp * 1e-6,
+                                  cfg.slope * 1e-6, cfg.fft_length, cfg.cde_L)
+        op = plxo.dsp_params(power_mw=hp.power_mw, applypol=True, polmethod="cma", cma_mu=cfg.cma_mu, cma_taps=cfg.cma_taps,
+                             freqavg=cfg.freqavg, phasavg=cfg.phasavg, poworder=cfg.poworder)
+        sym = plxo.dsp_pdm_coh_qpsk(np.stack([ex, ey], 1), op)
+        plxo.samp2pat_coherent(np.angle(sym))
+    dt = time.perf_counter() - t0
+    return nframes * cfg.nfft / dt / 1e9, dt, nc
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from polmux_amd import _abi, pipeline
+    _abi.get().call("plx_set_device", local)
+
+    cfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag=a.flag)
+    F = a.frames
+    hp = pipeline.HotPath(cfg, max_frames=F)
+    n = cfg.nfft
+    # inputs for every step are staged in HBM before the timed region (fibre works in place)
+    total = a.steps + a.warmup
+    batches = [hp.make_batch(F) for _ in range(total)]
+    torch.cuda.synchronize()
+    ev = HipEvents()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    err_total = torch.zeros(2, dtype=torch.int64, device="cuda")
+    fib_ms, rx_ms, row_launches, sample_steps = [], [], 0, 0
+    for i in range(a.warmup):
+        ux, uy = batches[i]
+        hp.run(ux, uy, noise_sigma=a.noise, noise_seed=1000 * rank + i)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(a.warmup, total):
+        ux, uy = batches[i]
+        e0, e1, e2 = ev.create(), ev.create(), ev.create()
+        ev.record(e0, stream)
+        hp.fibre(ux, uy)
+        ev.record(e1, stream)
+        err = hp.receive(ux, uy, noise_sigma=a.noise, noise_seed=1000 * rank + i)
+        ev.record(e2, stream)
+        err_total += err.sum(0)
+        fib_ms.append((e0, e1)); rx_ms.append((e1, e2))
+        rl, ss = hp.ssfm_stats()
+        row_launches += rl; sample_steps += ss
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        dist.all_reduce(err_total, op=dist.ReduceOp.SUM)       # the one exchange step (RCCL over xGMI)
+    fib = sum(ev.elapsed_ms(x, y) for x, y in fib_ms)
+    rxm = sum(ev.elapsed_ms(x, y) for x, y in rx_ms)
+
+    if rank == 0:
+        samples = float(world) * a.steps * F * n
+        value = samples / dt / 1e9
+        # roofline of the dominant kernel group: the SSFM step (3 sweeps), HBM-bound.
+        # achieved = algorithmic bytes (272 B per dual-pol sample-step) / measured fibre time (HIP events)
+        achieved = SSFM_BYTES_PER_SAMPLE_STEP * sample_steps / (fib * 1e-3) / 1e9
+        out = {
+            "metric": "dual-pol Gsample/s through SSFM+Rx-DSP", "value": value, "unit": "Gsample/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Run_my_PDM_QPSK-style (BASELINE config[1]): 28 Gbaud PDM-QPSK, 2^%d-sample "
+                                   "dual-pol frame, 1x80 km SSMF span fiber('%s'), CDE_OFDE 256/128, CMA 7 taps + "
+                                   "V&V carrier recovery" % (int(np.log2(n)), a.flag),
+                       "frames_per_gpu_per_step": F, "nsymb": a.nsymb, "nt": a.nt, "pavg_mw": a.pavg,
+                       "ssfm_steps_per_frame": sample_steps / (a.steps * F * n), "rx_noise_sigma": a.noise,
+                       "fibre_ms_per_step": fib / a.steps, "rxdsp_ms_per_step": rxm / a.steps,
+                       "bit_errors_xy": err_total.cpu().tolist()},
+            "roofline": {"bound": "hbm", "kernel": "SSFM step (k_col_fwd + k_row + k_col_inv)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "sample_steps_per_s": sample_steps / (fib * 1e-3),
+                         "launches": row_launches},
+        }
+        if not a.no_cpu_baseline:
+            v, cdt, nc = cpu_baseline(cfg, hp, a.cpu_frames)
+            out["cpu_baseline"] = {"value": v, "unit": "Gsample/s", "cores": 1, "kind": "port",
+                                   "sample": "%d frame(s) of the same batch through oracle/ (fibre %d steps + CDE + CMA + CPE), "
+                                             "%.1f s" % (a.cpu_frames, nc, cdt)}
+        print(json.dumps(out))
+    hp.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

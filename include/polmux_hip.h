@@ -169,16 +169,19 @@ int64_t plx_dsp_out_len(const plx_dsp *plan);
 /* samp2pat 'coherent' decisions (samp2pat.m:61-66) + error count against the
  * transmitted pattern (ber_estimate.m:119 err = sum(sum(pat ~= pat_hat))):
  * d_sym [frame][ncol][L] complex; d_pat uint8 [ncol*2][L] (shared by frames, may be
- * NULL); d_pat_hat (optional) uint8 [frame][ncol*2][L]; d_err int64 [frame].       */
+ * NULL); d_pat_hat (optional) uint8 [frame][ncol*2][L]; d_err int64 [frame][ncol]
+ * (errors of each column's two bit streams, so a caller can resolve the pi/2
+ * ambiguity of each polarisation separately; their sum is the reference's err).    */
 int plx_decide_count_dev(const double *d_sym, int64_t L, int32_t ncol, int nframes, const uint8_t *d_pat,
                          uint8_t *d_pat_hat, int64_t *d_err, void *stream);
 
 /* ------------------------------------------------------------ small helpers --- */
 /* strided pick + scale used between fibre and CDE when the full front end
  * (receiver_cohmix + decimate) is not in the chain:
- * out[f][c][i] = scale * in[f][c][offset + i*stride]                                */
+ * out[s*out_pitch + i] = scale * in[s*n_in + offset + i*stride], s < nsig
+ * (out_pitch 0 = n_out; a larger pitch interleaves the two polarisations of a frame) */
 int plx_pick_dev(const double *d_in, double *d_out, int64_t n_in, int64_t n_out, int64_t offset,
-                 int64_t stride, double scale, int nsig, void *stream);
+                 int64_t stride, double scale, int nsig, int64_t out_pitch, void *stream);
 
 #ifdef __cplusplus
 }

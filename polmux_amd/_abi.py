@@ -71,7 +71,7 @@ SIGNATURES = {
     "plx_dsp_run_dev": [_vp, _vp, _vp, C.c_int, _vp],
     "plx_dsp_out_len": [_vp],
     "plx_decide_count_dev": [_vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _vp],
-    "plx_pick_dev": [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, C.c_int, _vp],
+    "plx_pick_dev": [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, C.c_int, _i64, _vp],
 }
 _RESTYPES = {"plx_dsp_out_len": _i64}
 
@@ -87,6 +87,11 @@ class Binding:
                               "`python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); there is no CPU fallback" % path)
         self.path = path
+        if os.path.basename(path) == "libpolmux_hip.so":
+            # torch owns the HBM buffers and the streams handed to the library: load its HIP
+            # runtime FIRST so both sides share one runtime (torch bundles its own libamdhip64;
+            # loading ours first would bind torch to a second, different copy).
+            import torch  # noqa: F401
         self.lib = C.CDLL(path)
         self.lib.plx_last_error.restype = C.c_char_p
         for name, args in SIGNATURES.items():

@@ -33,11 +33,12 @@ __global__ __launch_bounds__(256) void k_fastexp(const double *__restrict__ x, c
 }
 
 __global__ __launch_bounds__(256) void k_pick(const cplx *__restrict__ in, cplx *__restrict__ out, int64_t n_in,
-                                              int64_t n_out, int64_t offset, int64_t stride, double scale)
+                                              int64_t n_out, int64_t offset, int64_t stride, double scale,
+                                              int64_t out_pitch)
 {
     const int sig = blockIdx.y;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * blockDim.x)
-        out[(size_t)sig * n_out + i] = cscale(in[(size_t)sig * n_in + offset + i * stride], scale);
+        out[(size_t)sig * out_pitch + i] = cscale(in[(size_t)sig * n_in + offset + i * stride], scale);
 }
 } // namespace
 
@@ -82,13 +83,15 @@ extern "C" int plx_fastexp(const double *x, double *yr, double *yi, size_t count
 }
 
 extern "C" int plx_pick_dev(const double *d_in, double *d_out, int64_t n_in, int64_t n_out, int64_t offset,
-                            int64_t stride, double scale, int nsig, void *stream)
+                            int64_t stride, double scale, int nsig, int64_t out_pitch, void *stream)
 {
+    if (out_pitch == 0) out_pitch = n_out;
+    if (out_pitch < n_out) PLX_FAIL(PLX_ERR_ARG, "plx_pick_dev: out_pitch smaller than n_out");
     if (!d_in || !d_out) PLX_FAIL(PLX_ERR_ARG, "plx_pick_dev: null argument");
     if (n_out < 1 || nsig < 1 || stride < 1 || offset < 0 || offset + (n_out - 1) * stride >= n_in)
         PLX_FAIL(PLX_ERR_ARG, "plx_pick_dev: selection out of range");
     PLX_LAUNCH(k_pick, dim3(grid_for((size_t)n_out), (unsigned)nsig), dim3(256), 0, stream, (const cplx *)d_in,
-               (cplx *)d_out, n_in, n_out, offset, stride, scale);
+               (cplx *)d_out, n_in, n_out, offset, stride, scale, out_pitch);
     PLX_HIP(hipGetLastError());
     return PLX_OK;
 }

@@ -1,0 +1,1054 @@
+// plx_rx.hip -- receiver side of the hot path on gfx950:
+//   CDE_OFDE.m overlap-save CD equaliser, the CMA / EASI 2x2 butterfly of
+//   cmaadaptivefilter.c / easiadaptivefilter.c with its driver loops
+//   (DspPdmCohQpsk.m:142-244), the DspPdmCohQpsk.m body (decimate, NLRotation,
+//   normalise, carrier recovery :12-79, vitvit :97-123) and samp2pat decisions.
+//
+// MI355X mapping:
+//   * overlap-save: one workgroup = 8 blocks of one signal; the 256-point block
+//     transform, the filter taps H (bit-reversed, pre-scaled by 1/N) and the twiddles
+//     all live in LDS; each input sample is read twice (50 % overlap), each output
+//     written once.
+//   * CMA: a strictly serial recurrence in the sample index, so parallelism comes
+//     from (frames) x (taps): a group of 8/16/32 lanes owns one frame, lane = tap
+//     index, each lane keeps its four complex taps in registers; the four dot
+//     products are reduced across the group with wave shuffles, the Godard error is
+//     formed redundantly by every lane, and the tap update is lane-local.  The pass
+//     loop and its 5e-5 convergence test run on the device.
+//   * carrier recovery: one workgroup per (frame, polarisation); the circular boxcar
+//     of vitvit is evaluated as the direct circular moving sum it is (the reference
+//     goes through fft/ifft of length L; same linear operator), cumsum/unwrap are
+//     block scans.
+#include "../../include/polmux_hip.h"
+#include "plx_fft.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+// ===================================================================== CDE ======
+struct CdeArgs {
+    const cplx *x;
+    cplx *y;
+    const cplx *Hp;  // [N] H at bit-reversed bins, fftshift undone, times 1/N
+    const cplx *tw;  // half table W_N^k
+    int64_t nx;
+    int logN, L, B2, G, logG, nblocks, h_in_lds;
+};
+
+// OverlapBothTrans, CDE_OFDE.m:88-124
+__global__ __launch_bounds__(256) void k_cde(CdeArgs a)
+{
+    PLX_DYN_LDS(lds);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int N = 1 << a.logN;
+    cplx *s = (cplx *)lds;            // [G][N]
+    cplx *tw = s + (size_t)a.G * N;   // [N/2]
+    cplx *Hl = tw + (N >> 1);         // [N] when staged
+    lds_load_twiddles(tw, a.tw, N >> 1, tid, nthr);
+    if (a.h_in_lds)
+        for (int k = tid; k < N; k += nthr) Hl[k] = a.Hp[k];
+    const cplx *H = a.h_in_lds ? Hl : a.Hp;
+    const size_t sig = blockIdx.y;
+    const cplx *x = a.x + sig * (size_t)a.nx;
+    cplx *y = a.y + sig * (size_t)a.nx;
+    const int b0 = blockIdx.x * a.G;
+    const int nel = a.G << a.logN;
+    for (int e = tid; e < nel; e += nthr) {
+        const int g = e >> a.logN, n = e & (N - 1);
+        const int64_t src = (int64_t)(b0 + g) * a.L - a.B2 + n; // zero extension :92-102
+        cplx v = make_double2(0.0, 0.0);
+        if (b0 + g < a.nblocks && src >= 0 && src < a.nx) v = x[src];
+        s[e] = v;
+    }
+    __syncthreads();
+    lds_fft_dif(s, a.logN, 1, N, a.logG, tw, tid, nthr, false);
+    for (int e = tid; e < nel; e += nthr) s[e] = cmul(s[e], H[e & (N - 1)]); // Yc = Xc.*H :110
+    __syncthreads();
+    lds_fft_dit(s, a.logN, 1, N, a.logG, tw, tid, nthr, false);
+    const int nout = a.G * a.L;
+    for (int e = tid; e < nout; e += nthr) {
+        const int g = e / a.L, j = e - g * a.L;
+        const int64_t dst = (int64_t)(b0 + g) * a.L + j;
+        if (b0 + g < a.nblocks && dst < a.nx) y[dst] = s[(g << a.logN) + a.B2 + j]; // :115,119
+    }
+}
+
+// ============================================================ CMA / EASI ======
+struct DemuxArgs {
+    const cplx *x;   // [frame][2][L]
+    cplx *y;         // [frame][2][L]
+    const cplx *M;   // [frame][4] or [4] (m_stride 0)
+    cplx *h;         // optional [frame][2][2*taps]: h1(:,1) h1(:,2) | h2(:,1) h2(:,2)
+    int *passes;     // optional
+    int64_t L;
+    int nframes, taps, halftaps, G, logG, m_stride, max_passes, single_pass, dontskip, skipk;
+    double mu, R1, R2;
+};
+
+template <class T> __device__ __forceinline__ T group_sum(T v, int G)
+{
+    for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double group_max(double v, int G)
+{
+    for (int m = 1; m < G; m <<= 1) {
+        double o = __shfl_xor(v, m, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// cmafilter (cmaadaptivefilter.c:57-91) inside the pass loop of cmapolardemux
+// (DspPdmCohQpsk.m:161-191).  Group of G lanes per frame, lane t owns tap t.
+__global__ __launch_bounds__(256) void k_cma(DemuxArgs a)
+{
+    const int lane_in_grp = threadIdx.x & (a.G - 1);
+    const int grp = (blockIdx.x * blockDim.x + threadIdx.x) >> a.logG;
+    const bool frame_ok = grp < a.nframes;
+    const int f = frame_ok ? grp : a.nframes - 1; // idle groups shadow the last frame, never store
+    const int t = lane_in_grp;
+    const bool tap_ok = t < a.taps;
+    const int64_t L = a.L;
+    const cplx *x1 = a.x + (size_t)f * 2 * L, *x2 = x1 + L;
+    cplx *y1 = a.y + (size_t)f * 2 * L, *y2 = y1 + L;
+    // taps: h11 = h1(t,1), h12 = h1(t,2), h21 = h2(t,1), h22 = h2(t,2)
+    cplx h11 = make_double2(0, 0), h12 = h11, h21 = h11, h22 = h11;
+    if (a.single_pass) {
+        if (tap_ok) { // taps handed in by the caller: [2][2*taps]
+            const cplx *hh = a.h + (size_t)f * 4 * a.taps;
+            h11 = hh[t]; h12 = hh[a.taps + t]; h21 = hh[2 * a.taps + t]; h22 = hh[3 * a.taps + t];
+        }
+    } else if (t == a.halftaps) { // hzero(halftaps+1,:,:) = M  :160
+        const cplx *M = a.M + (size_t)f * a.m_stride;
+        h11 = M[0]; h12 = M[1]; h21 = M[2]; h22 = M[3];
+    }
+    const int64_t nout = a.single_pass ? L - a.taps + 1 : L; // gateway: dimY = Mdim-Ntap+1
+    int c = 1, npass = 0;
+    // Groups of one wave may need different pass counts; the wave keeps looping until its
+    // slowest group is done and finished groups run predicated (no stores, no updates).
+    bool active = c < a.max_passes; // while ~convergence && (c < repetitions)  :176
+    while (__any(active)) {
+        const cplx o11 = h11, o12 = h12, o21 = h21, o22 = h22;
+        for (int64_t i = 0; i < nout; i++) {
+            int64_t idx = a.single_pass ? i + t : i + t - a.halftaps; // cyclic extension :161-165
+            if (!a.single_pass) { if (idx < 0) idx += L; else if (idx >= L) idx -= L; }
+            cplx xa = make_double2(0, 0), xb = xa;
+            if (tap_ok) { xa = x1[idx]; xb = x2[idx]; }
+            // y_r = sum_t x1[i+t] h_r1[t] + x2[i+t] h_r2[t]   (cmaadaptivefilter.c:71-81)
+            cplx p1 = cadd(cmul(xa, h11), cmul(xb, h12));
+            cplx p2 = cadd(cmul(xa, h21), cmul(xb, h22));
+            const double y1r = group_sum(p1.x, a.G), y1i = group_sum(p1.y, a.G);
+            const double y2r = group_sum(p2.x, a.G), y2i = group_sum(p2.y, a.G);
+            if (active && frame_ok && t == 0) { y1[i] = make_double2(y1r, y1i); y2[i] = make_double2(y2r, y2i); }
+            if (active && (a.dontskip || ((int)(i & 1) == a.skipk))) { // :85
+                // updatecoeff :41-54: h += k*y*conj(x), k = mu*(R-|y|^2)
+                const double k1 = a.mu * (a.R1 - y1r * y1r - y1i * y1i);
+                const double k2 = a.mu * (a.R2 - y2r * y2r - y2i * y2i);
+                h11.x += k1 * (y1r * xa.x + y1i * xa.y); h11.y += k1 * (y1i * xa.x - y1r * xa.y);
+                h12.x += k1 * (y1r * xb.x + y1i * xb.y); h12.y += k1 * (y1i * xb.x - y1r * xb.y);
+                h21.x += k2 * (y2r * xa.x + y2i * xa.y); h21.y += k2 * (y2i * xa.x - y2r * xa.y);
+                h22.x += k2 * (y2r * xb.x + y2i * xb.y); h22.y += k2 * (y2i * xb.x - y2r * xb.y);
+            }
+        }
+        // max(max(abs([h1_old-h1 h2_old-h2]))) < 5e-5  :187
+        double d = hypot(o11.x - h11.x, o11.y - h11.y);
+        double e = hypot(o12.x - h12.x, o12.y - h12.y);
+        d = e > d ? e : d;
+        e = hypot(o21.x - h21.x, o21.y - h21.y);
+        d = e > d ? e : d;
+        e = hypot(o22.x - h22.x, o22.y - h22.y);
+        d = e > d ? e : d;
+        d = group_max(d, a.G);
+        if (active) {
+            npass++;
+            c++;
+            if (a.single_pass || d < 5e-5 || !(c < a.max_passes)) active = false;
+        }
+    }
+    if (frame_ok && tap_ok && a.h) {
+        cplx *hh = a.h + (size_t)f * 4 * a.taps;
+        hh[t] = h11; hh[a.taps + t] = h12; hh[2 * a.taps + t] = h21; hh[3 * a.taps + t] = h22;
+    }
+    if (frame_ok && t == 0 && a.passes) a.passes[f] = npass;
+}
+
+// ---- DPP lane exchange inside a 16-lane row (no LDS crossbar on the critical path) ----
+// xor-1 / xor-2 are quad permutes; 7 and 15 are the row_half_mirror / row_mirror pairings
+// (lane i <-> 7-i, i <-> 15-i), valid butterfly partners once the lower levels are reduced.
+#ifdef PLX_EMU
+template <int X> __device__ __forceinline__ double lane_xchg(double v) { return __shfl_xor(v, X, 64); }
+#else
+template <int X> __device__ __forceinline__ double lane_xchg(double v)
+{
+    constexpr int ctrl = X == 1 ? 0xB1 : X == 2 ? 0x4E : X == 7 ? 0x141 : 0x140;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+#endif
+__device__ __forceinline__ double sum8(double v)
+{
+    v += lane_xchg<1>(v);
+    v += lane_xchg<2>(v);
+    v += lane_xchg<7>(v);
+    return v;
+}
+__device__ __forceinline__ double max16(double v)
+{
+    double o = lane_xchg<1>(v); v = o > v ? o : v;
+    o = lane_xchg<2>(v); v = o > v ? o : v;
+    o = lane_xchg<7>(v); v = o > v ? o : v;
+    o = lane_xchg<15>(v); v = o > v ? o : v;
+    return v;
+}
+
+// Fast path of the cmapolardemux driver for taps <= 8 (the reference's 7): 16 lanes per frame,
+// lane = (output row r, tap t); each lane keeps h_r(t,1), h_r(t,2) in registers, the dot
+// products are DPP-reduced over the 8 tap lanes, the input samples of the next chunk are
+// prefetched while the current chunk runs (the recurrence itself is latency-bound).
+#define CMA_U 8
+__global__ __launch_bounds__(64) void k_cma16(DemuxArgs a)
+{
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l16 = threadIdx.x & 15, r = l16 >> 3, t = l16 & 7;
+    const int grp = gtid >> 4;
+    const bool frame_ok = grp < a.nframes;
+    const int f = frame_ok ? grp : a.nframes - 1;
+    const bool tap_ok = t < a.taps;
+    const int64_t L = a.L;
+    const cplx *x1 = a.x + (size_t)f * 2 * L, *x2 = x1 + L;
+    cplx *yo = a.y + (size_t)f * 2 * L + (size_t)r * L;
+    cplx ha = make_double2(0, 0), hb = ha; // h_r(t,1), h_r(t,2)
+    if (t == a.halftaps) {
+        const cplx *M = a.M + (size_t)f * a.m_stride;
+        ha = M[2 * r]; hb = M[2 * r + 1];
+    }
+    const double Rr = r ? a.R2 : a.R1, mu = a.mu;
+    const int64_t off = (int64_t)t - a.halftaps;
+    int c = 1, npass = 0;
+    bool active = c < a.max_passes;
+    const int64_t nchunks = L / CMA_U, tail0 = nchunks * CMA_U;
+    while (__any(active)) {
+        const cplx oa = ha, ob = hb;
+        cplx ca[CMA_U], cb[CMA_U], na[CMA_U], nb[CMA_U];
+#pragma unroll
+        for (int u = 0; u < CMA_U; u++) {
+            int64_t idx = u + off;
+            if (idx < 0) idx += L; else if (idx >= L) idx -= L;
+            ca[u] = tap_ok ? x1[idx] : make_double2(0, 0);
+            cb[u] = tap_ok ? x2[idx] : make_double2(0, 0);
+        }
+        for (int64_t ch = 0; ch < nchunks; ch++) {
+            const int64_t i0 = ch * CMA_U;
+            if (ch + 1 < nchunks) {
+#pragma unroll
+                for (int u = 0; u < CMA_U; u++) {
+                    int64_t idx = i0 + CMA_U + u + off;
+                    if (idx < 0) idx += L; else if (idx >= L) idx -= L;
+                    na[u] = tap_ok ? x1[idx] : make_double2(0, 0);
+                    nb[u] = tap_ok ? x2[idx] : make_double2(0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CMA_U; u++) {
+                const cplx xa = ca[u], xb = cb[u];
+                const double pr = (xa.x * ha.x - xa.y * ha.y) + (xb.x * hb.x - xb.y * hb.y);
+                const double pi = (xa.x * ha.y + xa.y * ha.x) + (xb.x * hb.y + xb.y * hb.x);
+                const double yr = sum8(pr), yi = sum8(pi);
+                if (active && frame_ok && t == 0) yo[i0 + u] = make_double2(yr, yi);
+                if (active) {
+                    const double k = mu * (Rr - yr * yr - yi * yi);
+                    const double kr = k * yr, ki = k * yi;
+                    ha.x += kr * xa.x + ki * xa.y; ha.y += ki * xa.x - kr * xa.y;
+                    hb.x += kr * xb.x + ki * xb.y; hb.y += ki * xb.x - kr * xb.y;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CMA_U; u++) { ca[u] = na[u]; cb[u] = nb[u]; }
+        }
+        for (int64_t i = tail0; i < L; i++) { // L not a multiple of the chunk
+            int64_t idx = i + off;
+            if (idx < 0) idx += L; else if (idx >= L) idx -= L;
+            const cplx xa = tap_ok ? x1[idx] : make_double2(0, 0), xb = tap_ok ? x2[idx] : make_double2(0, 0);
+            const double pr = (xa.x * ha.x - xa.y * ha.y) + (xb.x * hb.x - xb.y * hb.y);
+            const double pi = (xa.x * ha.y + xa.y * ha.x) + (xb.x * hb.y + xb.y * hb.x);
+            const double yr = sum8(pr), yi = sum8(pi);
+            if (active && frame_ok && t == 0) yo[i] = make_double2(yr, yi);
+            if (active) {
+                const double k = mu * (Rr - yr * yr - yi * yi);
+                const double kr = k * yr, ki = k * yi;
+                ha.x += kr * xa.x + ki * xa.y; ha.y += ki * xa.x - kr * xa.y;
+                hb.x += kr * xb.x + ki * xb.y; hb.y += ki * xb.x - kr * xb.y;
+            }
+        }
+        double d = hypot(oa.x - ha.x, oa.y - ha.y);
+        const double e = hypot(ob.x - hb.x, ob.y - hb.y);
+        d = max16(e > d ? e : d);
+        if (active) {
+            npass++;
+            c++;
+            if (d < 5e-5 || !(c < a.max_passes)) active = false;
+        }
+    }
+    if (frame_ok && tap_ok && a.h) { // [h1(:,1) h1(:,2) | h2(:,1) h2(:,2)]
+        cplx *hh = a.h + (size_t)f * 4 * a.taps + (size_t)r * 2 * a.taps;
+        hh[t] = ha; hh[a.taps + t] = hb;
+    }
+    if (frame_ok && l16 == 0 && a.passes) a.passes[f] = npass;
+}
+
+// easifilter (easiadaptivefilter.c:52-93) inside easipolardemux (DspPdmCohQpsk.m:195-244).
+// taps == 1 in the driver (:197); the gateway form allows any odd/even taps: the update only
+// ever touches the real parts of tap 0 (:83-90), the output uses all taps.  One lane per frame.
+__global__ __launch_bounds__(64) void k_easi(DemuxArgs a)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.nframes) return;
+    const int64_t L = a.L;
+    const int taps = a.taps;
+    const cplx *x1 = a.x + (size_t)f * 2 * L, *x2 = x1 + L;
+    cplx *y1 = a.y + (size_t)f * 2 * L, *y2 = y1 + L;
+    cplx *hh = a.h + (size_t)f * 4 * taps; // working taps live in global memory (tap 0 in registers)
+    if (!a.single_pass) {
+        const cplx *M = a.M + (size_t)f * a.m_stride;
+        hh[0] = M[0]; hh[1] = M[1]; hh[2] = M[2]; hh[3] = M[3];
+    }
+    // the only mutable state: real parts of h1(1,1) h1(1,2)... note the reference indexes
+    // h1r[0], h1r[1]: with taps==1 these are h1(1,1), h1(1,2); with taps>1 they are h1(1,1), h1(2,1).
+    const int64_t nout = a.single_pass ? L - taps + 1 : L;
+    int c = 1, npass = 0;
+    bool conv = false;
+    const double mu = a.mu;
+    while (!conv && c < a.max_passes) {
+        const double o0 = hh[0].x, o1 = hh[1].x, o2 = hh[2 * taps].x, o3 = hh[2 * taps + 1].x;
+        double a0 = o0, a1 = o1, b0 = o2, b1 = o3; // h1r[0], h1r[1], h2r[0], h2r[1]
+        for (int64_t i = 0; i < nout; i++) {
+            double y1r = 0, y1i = 0, y2r = 0, y2i = 0;
+            for (int p = 0; p < 2; p++) {
+                const cplx *xp = p ? x2 : x1;
+                double s1r = 0, s1i = 0, s2r = 0, s2i = 0;
+                for (int t = 0; t < taps; t++) {
+                    const cplx xv = xp[i + t];
+                    cplx g1 = hh[p * taps + t], g2 = hh[2 * taps + p * taps + t];
+                    const int flat = p * taps + t; // position inside h1r / h2r
+                    if (flat == 0) { g1.x = a0; g2.x = b0; }
+                    if (flat == 1) { g1.x = a1; g2.x = b1; }
+                    s1r += xv.x * g1.x - xv.y * g1.y; s1i += xv.y * g1.x + xv.x * g1.y;
+                    s2r += xv.x * g2.x - xv.y * g2.y; s2i += xv.y * g2.x + xv.x * g2.y;
+                }
+                y1r += s1r; y1i += s1i; y2r += s2r; y2i += s2i;
+            }
+            y1[i] = make_double2(y1r, y1i);
+            y2[i] = make_double2(y2r, y2i);
+            if (a.dontskip || ((int)(i & 1) == a.skipk)) {
+                const double A = y1r, B = y2r; // only the real parts enter :81
+                const double den1 = 1 + mu * (A * A + B * B);
+                const double den2 = 1 + mu * (A * fabs(A) + B * fabs(B));
+                const double E0 = (A * A - 1) / den1;
+                const double E1 = (A * B) / den1 + (A * B * (A * A - B * B)) / den2;
+                const double E2 = (A * B) / den1 + (A * B * (B * B - A * A)) / den2;
+                const double E3 = (B * B - 1) / den1;
+                const double n11 = (1 - mu * E0) * a0 + (-mu * E1) * b0;
+                const double n12 = (1 - mu * E0) * a1 + (-mu * E1) * b1;
+                const double n21 = (-mu * E2) * a0 + (1 - mu * E3) * b0;
+                const double n22 = (-mu * E2) * a1 + (1 - mu * E3) * b1;
+                a0 = n11; a1 = n12; b0 = n21; b1 = n22;
+            }
+        }
+        hh[0].x = a0; hh[1].x = a1; hh[2 * taps].x = b0; hh[2 * taps + 1].x = b1;
+        npass++;
+        if (a.single_pass) break;
+        double d = fabs(o0 - a0), e = fabs(o1 - a1);
+        d = e > d ? e : d; e = fabs(o2 - b0); d = e > d ? e : d; e = fabs(o3 - b1); d = e > d ? e : d;
+        if (d < 5e-5) conv = true;
+        c++;
+    }
+    if (a.passes) a.passes[f] = npass;
+}
+
+// ================================================== DspPdmCohQpsk front part ======
+struct PreArgs {
+    const cplx *in; // [frame][ncol][Lin]
+    cplx *out;      // [frame][ncol][L]
+    int64_t Lin, L;
+    int ncol, stride, applynlr;
+    double nlralpha, inv_peak;
+};
+
+// :12-23: 1:2:end, NLRotation (:87-94), /peak.  One workgroup per frame.
+__global__ __launch_bounds__(256) void k_dsp_pre(PreArgs a)
+{
+    PLX_DYN_LDS(lds);
+    double *red = (double *)lds;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const size_t f = blockIdx.x;
+    const cplx *in = a.in + f * a.ncol * (size_t)a.Lin;
+    cplx *out = a.out + f * a.ncol * (size_t)a.L;
+    double mean = 0;
+    if (a.applynlr) {
+        double acc = 0;
+        for (int64_t i = tid; i < a.L; i += nthr) {
+            double q = 0;
+            for (int c = 0; c < a.ncol; c++) {
+                const cplx v = in[(size_t)c * a.Lin + i * a.stride];
+                const double m = hypot(v.x, v.y);
+                q += m * m;
+            }
+            acc += q;
+        }
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        if ((tid & 63) == 0) red[tid >> 6] = acc;
+        __syncthreads();
+        for (int w = 0; w < (nthr + 63) / 64; w++) mean += red[w];
+        mean /= (double)a.L;
+    }
+    for (int64_t i = tid; i < a.L; i += nthr) {
+        double q = 0;
+        if (a.applynlr)
+            for (int c = 0; c < a.ncol; c++) {
+                const cplx v = in[(size_t)c * a.Lin + i * a.stride];
+                const double m = hypot(v.x, v.y);
+                q += m * m;
+            }
+        for (int c = 0; c < a.ncol; c++) {
+            cplx v = in[(size_t)c * a.Lin + i * a.stride];
+            if (a.applynlr) {
+                const double ph = atan2(v.y, v.x) + a.nlralpha * (q - mean);
+                const double am = hypot(v.x, v.y);
+                double sp, cp;
+                sincos(ph, &sp, &cp);
+                v = make_double2(am * cp, am * sp);
+            }
+            out[(size_t)c * a.L + i] = make_double2(v.x * a.inv_peak, v.y * a.inv_peak);
+        }
+    }
+}
+
+// rotpolar (:126-139) from the Kikuchi ratio r = mean(x1./x2): either applies y = x*M
+// ('singlepol', :29-31) or only writes M.' as the initial centre taps (:151-153).
+__global__ __launch_bounds__(256) void k_rotpolar(const cplx *x, cplx *y, cplx *Mout, int64_t L, int apply)
+{
+    PLX_DYN_LDS(lds);
+    double *red = (double *)lds;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const size_t f = blockIdx.x;
+    const cplx *x1 = x + f * 2 * (size_t)L, *x2 = x1 + L;
+    double sr = 0, si = 0;
+    for (int64_t i = tid; i < L; i += nthr) {
+        const cplx a = x1[i], b = x2[i];
+        const double den = b.x * b.x + b.y * b.y;
+        sr += (a.x * b.x + a.y * b.y) / den;
+        si += (a.y * b.x - a.x * b.y) / den;
+    }
+    for (int m = 32; m >= 1; m >>= 1) { sr += __shfl_xor(sr, m, 64); si += __shfl_xor(si, m, 64); }
+    if ((tid & 63) == 0) { red[2 * (tid >> 6)] = sr; red[2 * (tid >> 6) + 1] = si; }
+    __syncthreads();
+    double rr = 0, ri = 0;
+    for (int w = 0; w < (nthr + 63) / 64; w++) { rr += red[2 * w]; ri += red[2 * w + 1]; }
+    rr /= (double)L; ri /= (double)L;
+    double m, delta, alpha;
+    const double ar = hypot(rr, ri);
+    if (ar < 0.5) {
+        m = ar; delta = atan2(ri, rr); alpha = m * m / (m * m + 1);
+    } else {
+        const double d2 = rr * rr + ri * ri; // 1/r
+        const double ir = rr / d2, ii = -ri / d2;
+        m = hypot(ir, ii); delta = -atan2(ii, ir); alpha = 1 / (m * m + 1);
+    }
+    double sd, cd;
+    sincos(-delta, &sd, &cd);
+    const cplx M11 = make_double2(sqrt(alpha) * cd, sqrt(alpha) * sd);
+    const cplx M12 = make_double2(-sqrt(1 - alpha) * cd, -sqrt(1 - alpha) * sd);
+    const cplx M21 = make_double2(sqrt(1 - alpha), 0), M22 = make_double2(sqrt(alpha), 0);
+    if (apply) {
+        cplx *y1 = y + f * 2 * (size_t)L, *y2 = y1 + L;
+        for (int64_t i = tid; i < L; i += nthr) { // y = x*M
+            const cplx a = x1[i], b = x2[i];
+            y1[i] = cadd(cmul(a, M11), cmul(b, M21));
+            y2[i] = cadd(cmul(a, M12), cmul(b, M22));
+        }
+    } else if (tid == 0) { // M = rotpolar(1,r).'
+        cplx *Mo = Mout + f * 4;
+        Mo[0] = M11; Mo[1] = M21; Mo[2] = M12; Mo[3] = M22;
+    }
+}
+
+// ============================================================ carrier recovery ======
+struct CpeArgs {
+    const cplx *s;   // [frame][ncol][L] normalised, demultiplexed samples
+    cplx *out;       // [frame][ncol][L]
+    cplx *wsc;       // global scratch [frame*ncol][2][L] (used when LDS is too small)
+    double *wsr;     // global scratch [frame*ncol][L]
+    int64_t L;
+    int use_lds, modorder, freqavg, phasavg, poworder;
+};
+
+__device__ __forceinline__ cplx cpow_int(cplx v, int P)
+{
+    cplx r = v;
+    for (int i = 1; i < P; i++) r = cmul(r, v);
+    return r;
+}
+
+// circular causal boxcar of 2k+1 taps (vitvit :106-117): dst[n] = mean_{m<N} src[(n-m) mod L]
+__device__ __forceinline__ void boxcar(const cplx *src, cplx *dst, int64_t L, int k, int tid, int nthr)
+{
+    const int64_t N = 2 * (int64_t)k + 1;
+    const double invN = 1.0 / (double)N;
+    for (int64_t n = tid; n < L; n += nthr) {
+        double ar = 0, ai = 0;
+        int64_t j = n;
+        for (int64_t m = 0; m < N; m++) {
+            const cplx v = src[j];
+            ar += v.x; ai += v.y;
+            j = (j == 0) ? L - 1 : j - 1;
+        }
+        dst[n] = make_double2(ar * invN, ai * invN);
+    }
+}
+
+// inclusive scan of w[0..L) in place (cumsum); red: >= nthr+1 doubles of LDS
+__device__ __forceinline__ void block_cumsum(double *w, int64_t L, double *red, int tid, int nthr)
+{
+    const int64_t per = (L + nthr - 1) / nthr, lo = (int64_t)tid * per, hi = (lo + per < L) ? lo + per : L;
+    double acc = 0;
+    for (int64_t i = lo; i < hi; i++) { acc += w[i]; w[i] = acc; }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double run = 0;
+        for (int t = 0; t < nthr; t++) { const double v = red[t]; red[t] = run; run += v; }
+    }
+    __syncthreads();
+    const double off = red[tid];
+    for (int64_t i = lo; i < hi; i++) w[i] += off;
+    __syncthreads();
+}
+
+// :44-79 for one column.  One workgroup per (frame, column).
+__global__ __launch_bounds__(256) void k_cpe(CpeArgs a)
+{
+    PLX_DYN_LDS(lds);
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int64_t L = a.L;
+    const size_t col = blockIdx.x;
+    const cplx *s = a.s + col * (size_t)L;
+    cplx *out = a.out + col * (size_t)L;
+    double *red = (double *)lds; // [nthr+16]
+    cplx *bufA, *bufB;
+    double *w, *th;
+    if (a.use_lds) {
+        bufA = (cplx *)(red + nthr + 16);
+        bufB = bufA + L;
+        w = (double *)(bufB + L);
+        th = w + L;
+    } else {
+        bufA = a.wsc + col * 2 * (size_t)L;
+        bufB = bufA + L;
+        w = a.wsr + col * 2 * (size_t)L;
+        th = w + L;
+    }
+    const int Mo = 1 << a.modorder;
+    const double off = a.modorder > 1 ? 0.78539816339744830962 : 0.0; // +pi/4 :62-66
+    if (a.freqavg) {
+        // omega = cumsum(vitvit(s.*conj(fastshift(s,1)), M, M, freqavg, false))  :49-50
+        for (int64_t n = tid; n < L; n += nthr) {
+            const cplx d = cmulc(s[n], s[n == 0 ? L - 1 : n - 1]);
+            bufA[n] = cpow_int(d, Mo); // P == M: s.^P
+        }
+        __syncthreads();
+        boxcar(bufA, bufB, L, a.freqavg, tid, nthr);
+        __syncthreads();
+        for (int64_t n = tid; n < L; n += nthr) w[n] = atan2(bufB[n].y, bufB[n].x) / Mo;
+        __syncthreads();
+        block_cumsum(w, L, red, tid, nthr);
+        // circularity fix :52-55
+        const double w1 = w[0], wend = w[L - 1];
+        const double closest = w1 + round((wend - w1) / 2 / 3.14159265358979323846) * 2 * 3.14159265358979323846;
+        const double ratio = closest / wend;
+        __syncthreads();
+        for (int64_t n = tid; n < L; n += nthr) w[n] = ((w[n] - w1) * ratio) + w1;
+        __syncthreads();
+    } else {
+        for (int64_t n = tid; n < L; n += nthr) w[n] = 0;
+        __syncthreads();
+    }
+    // theta = vitvit(sigdemod, P, M, phasavg, true)  :57-61
+    for (int64_t n = tid; n < L; n += nthr) {
+        const cplx sd = a.freqavg ? cmul(s[n], cexpi(-w[n])) : s[n];
+        if (a.poworder == Mo) {
+            bufA[n] = cpow_int(sd, Mo);
+        } else {
+            const cplx sm = cpow_int(sd, Mo);
+            const double am = pow(hypot(sd.x, sd.y), (double)a.poworder);
+            const double ang = atan2(sm.y, sm.x);
+            double sp, cp;
+            sincos(ang, &sp, &cp);
+            bufA[n] = make_double2(am * cp, am * sp);
+        }
+    }
+    __syncthreads();
+    const cplx *bs = bufA;
+    if (a.phasavg > 0) {
+        boxcar(bufA, bufB, L, a.phasavg, tid, nthr);
+        __syncthreads();
+        bs = bufB;
+    }
+    for (int64_t n = tid; n < L; n += nthr) th[n] = atan2(bs[n].y, bs[n].x);
+    __syncthreads();
+    // unwrap (tolerance pi): correction of sample n depends on th[n]-th[n-1] only -> scan
+    double *corr = (double *)bufA; // bufA is free again
+    const double PI = 3.14159265358979323846;
+    for (int64_t n = tid; n < L; n += nthr) {
+        double cv = 0;
+        if (n > 0) {
+            const double dp = th[n] - th[n - 1];
+            double dps = fmod(dp + PI, 2 * PI);
+            if (dps < 0) dps += 2 * PI;
+            dps -= PI;
+            if (dps == -PI && dp > 0) dps = PI;
+            cv = (fabs(dp) < PI) ? 0.0 : dps - dp;
+        }
+        corr[n] = cv;
+    }
+    __syncthreads();
+    block_cumsum(corr, L, red, tid, nthr);
+    for (int64_t n = tid; n < L; n += nthr) {
+        const double theta = (th[n] + corr[n]) / Mo;
+        out[n] = cmul(s[n], cexpi(-w[n] - theta + off)); // :67,79
+    }
+}
+
+// ====================================================== decisions + error count ======
+// samp2pat 'coherent' (samp2pat.m:61-66) and err = sum(sum(pat ~= pat_hat)) (ber_estimate.m:119),
+// kept per column so that a caller can resolve the pi/2 ambiguity of each polarisation.
+__global__ __launch_bounds__(256) void k_decide(const cplx *sym, int64_t L, int ncol, const uint8_t *pat,
+                                                uint8_t *pat_hat, unsigned long long *err)
+{
+    PLX_DYN_LDS(lds);
+    unsigned long long *red = (unsigned long long *)lds;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const size_t fc = blockIdx.x, f = fc / ncol;
+    const int c = (int)(fc - f * ncol);
+    unsigned long long cnt = 0;
+    for (int64_t i = tid; i < L; i += nthr) {
+        const cplx v = sym[fc * (size_t)L + i];
+        const double ph = atan2(v.y, v.x);
+        const uint8_t first = fabs(ph) <= 1.57079632679489661923 ? 1 : 0;
+        const uint8_t second = ph > 0 ? 1 : 0;
+        if (pat_hat) {
+            pat_hat[(f * 2 * ncol + 2 * c) * (size_t)L + i] = first;
+            pat_hat[(f * 2 * ncol + 2 * c + 1) * (size_t)L + i] = second;
+        }
+        if (pat) {
+            cnt += (pat[(size_t)(2 * c) * L + i] != first);
+            cnt += (pat[(size_t)(2 * c + 1) * L + i] != second);
+        }
+    }
+    for (int m = 32; m >= 1; m >>= 1) cnt += __shfl_xor(cnt, m, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0 && err) {
+        unsigned long long tot = 0;
+        for (int w = 0; w < (nthr + 63) / 64; w++) tot += red[w];
+        err[fc] = tot;
+    }
+}
+
+int ilog2i(int64_t v)
+{
+    int l = 0;
+    while (((int64_t)1 << l) < v) l++;
+    return l;
+}
+
+#ifndef PLX_EMU
+template <class K> hipError_t allow_lds(K kern, size_t bytes)
+{
+    return hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+#else
+template <class K> hipError_t allow_lds(K, size_t) { return hipSuccess; }
+#endif
+
+} // namespace
+
+// =================================================================== CDE host ===
+struct plx_cde {
+    int64_t N, L;
+    int logN, G, h_in_lds;
+    cplx *d_H = nullptr, *d_tw = nullptr;
+    size_t lds = 0;
+};
+
+static const char *kCdeMsg[] = {"", "Error: x must be one dimensional complex vector", "Error: H must be even length",
+                                "Error: L must be > 0", "Error: L must be shorter than filter length",
+                                "Error: Signal must be longer or equal filter"};
+
+extern "C" int plx_cde_create(plx_cde **out, int64_t fft_len, int64_t L, const double *H)
+{
+    if (!out || !H) PLX_FAIL(PLX_ERR_ARG, "plx_cde_create: null argument");
+    *out = nullptr;
+    if (fft_len % 2 != 0) PLX_FAIL(PLX_ERR_ARG, kCdeMsg[2]);     // CDE_OFDE.m:73-74
+    if (L <= 0) PLX_FAIL(PLX_ERR_ARG, kCdeMsg[3]);               // :77-78
+    if (L > fft_len) PLX_FAIL(PLX_ERR_ARG, kCdeMsg[4]);          // :79-80
+    const int logN = ilog2i(fft_len);
+    if (((int64_t)1 << logN) != fft_len || fft_len < 4 || fft_len > 4096)
+        PLX_FAIL(PLX_ERR_UNSUPPORTED, "plx_cde_create: FFT length must be a power of two in [4, 4096]");
+    if ((fft_len - L) % 2 != 0) PLX_FAIL(PLX_ERR_UNSUPPORTED, "plx_cde_create: overlap N-L must be even");
+    plx_cde *P = new plx_cde();
+    P->N = fft_len; P->L = L; P->logN = logN;
+    int G = 1;
+    while (G < 8 && (int64_t)G * 2 * fft_len <= 2048) G *= 2;
+    P->G = G;
+    P->h_in_lds = fft_len <= 1024 ? 1 : 0;
+    // H is given on the fftshift-ordered grid: unshifted bin k takes H[(k+N/2) mod N]
+    // (CDE_OFDE.m:108-112); LDS position i holds bin bitrev(i); fold in ifft's 1/N.
+    std::vector<cplx> Hp((size_t)fft_len), tw((size_t)(fft_len / 2));
+    for (int64_t i = 0; i < fft_len; i++) {
+        const int64_t k = (int64_t)plx_bitrev((unsigned)i, logN);
+        const int64_t src = (k + fft_len / 2) % fft_len;
+        Hp[i] = make_double2(H[2 * src] / (double)fft_len, H[2 * src + 1] / (double)fft_len);
+    }
+    for (int64_t k = 0; k < fft_len / 2; k++) {
+        long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)fft_len;
+        tw[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    if (hipMalloc((void **)&P->d_H, Hp.size() * sizeof(cplx)) != hipSuccess ||
+        hipMalloc((void **)&P->d_tw, tw.size() * sizeof(cplx)) != hipSuccess ||
+        hipMemcpy(P->d_H, Hp.data(), Hp.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(P->d_tw, tw.data(), tw.size() * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) {
+        plx_cde_destroy(P);
+        PLX_FAIL(PLX_ERR_HIP, "plx_cde_create: device allocation/upload failed");
+    }
+    P->lds = ((size_t)G * fft_len + fft_len / 2 + (P->h_in_lds ? fft_len : 0)) * sizeof(cplx);
+    if (allow_lds(k_cde, P->lds) != hipSuccess) { plx_cde_destroy(P); PLX_FAIL(PLX_ERR_HIP, "plx_cde_create: cannot reserve LDS"); }
+    *out = P;
+    return PLX_OK;
+}
+
+extern "C" int plx_cde_destroy(plx_cde *P)
+{
+    if (P) { hipFree(P->d_H); hipFree(P->d_tw); delete P; }
+    return PLX_OK;
+}
+
+extern "C" int plx_cde_apply_dev(plx_cde *P, const double *d_x, double *d_y, int64_t nx, int nsig, void *stream)
+{
+    if (!P || !d_x || !d_y) PLX_FAIL(PLX_ERR_ARG, "plx_cde_apply_dev: null argument");
+    if (nx < P->N) PLX_FAIL(PLX_ERR_ARG, kCdeMsg[5]); // CDE_OFDE.m:83-84
+    if (nsig < 1) PLX_FAIL(PLX_ERR_ARG, "plx_cde_apply_dev: nsig must be >= 1");
+    CdeArgs a;
+    a.x = (const cplx *)d_x; a.y = (cplx *)d_y; a.Hp = P->d_H; a.tw = P->d_tw; a.nx = nx;
+    a.logN = P->logN; a.L = (int)P->L; a.B2 = (int)((P->N - P->L) / 2); a.G = P->G; a.logG = ilog2i(P->G);
+    a.nblocks = (int)((nx + P->L - 1) / P->L); a.h_in_lds = P->h_in_lds;
+    const unsigned gx = (unsigned)((a.nblocks + a.G - 1) / a.G);
+    PLX_LAUNCH(k_cde, dim3(gx, (unsigned)nsig), dim3(256), P->lds, stream, a);
+    PLX_HIP(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_cde_ofde(const double *xr, const double *xi, const double *yr, const double *yi, int64_t nx,
+                            double fs, double lambda_ref, double span, double D, double S, int64_t fft_len,
+                            int64_t L, double *oxr, double *oxi, double *oyr, double *oyi)
+{
+    if (!xr || !yr || !oxr || !oxi || !oyr || !oyi) PLX_FAIL(PLX_ERR_ARG, "plx_cde_ofde: null argument");
+    if (fft_len > nx) fft_len = nx; // CDE_OFDE.m:24-27
+    // transfer function, CDE_OFDE.m:29-38 (host, double)
+    const double c = 299792458.0, fc = c / lambda_ref, df = 1.0 / ((double)fft_len / fs);
+    std::vector<double> H(2 * (size_t)fft_len);
+    for (int64_t i = 0; i < fft_len; i++) {
+        const double fg = df * (double)(i - fft_len / 2);
+        const double hd = -(D * span * M_PI * c / (fc * fc) * (fg * fg));
+        const double hs = S * span * M_PI * (c * c) / 3 / (fc * fc * fc * fc) * (fg * fg * fg);
+        H[2 * i] = cos(hd + hs);
+        H[2 * i + 1] = sin(hd + hs);
+    }
+    if (nx < fft_len) PLX_FAIL(PLX_ERR_ARG, kCdeMsg[5]);
+    plx_cde *P = nullptr;
+    int rc = plx_cde_create(&P, fft_len, L, H.data());
+    if (rc) return rc;
+    std::vector<double> h(4 * (size_t)nx);
+    for (int64_t i = 0; i < nx; i++) {
+        h[2 * i] = xr[i]; h[2 * i + 1] = xi ? xi[i] : 0.0;
+        h[2 * (nx + i)] = yr[i]; h[2 * (nx + i) + 1] = yi ? yi[i] : 0.0;
+    }
+    double *dx = nullptr, *dy = nullptr;
+    const size_t bytes = h.size() * sizeof(double);
+    if (hipMalloc((void **)&dx, bytes) != hipSuccess || hipMalloc((void **)&dy, bytes) != hipSuccess) {
+        hipFree(dx); hipFree(dy); plx_cde_destroy(P);
+        PLX_FAIL(PLX_ERR_HIP, "plx_cde_ofde: device allocation failed");
+    }
+    hipMemcpy(dx, h.data(), bytes, hipMemcpyHostToDevice);
+    rc = plx_cde_apply_dev(P, dx, dy, nx, 2, nullptr);
+    if (!rc && hipMemcpy(h.data(), dy, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+        plx_set_error("plx_cde_ofde: download failed");
+        rc = PLX_ERR_HIP;
+    }
+    hipFree(dx); hipFree(dy); plx_cde_destroy(P);
+    if (rc) return rc;
+    for (int64_t i = 0; i < nx; i++) {
+        oxr[i] = h[2 * i]; oxi[i] = h[2 * i + 1];
+        oyr[i] = h[2 * (nx + i)]; oyi[i] = h[2 * (nx + i) + 1];
+    }
+    return PLX_OK;
+}
+
+// ================================================================ pol-demux host ===
+static int launch_demux(int method, DemuxArgs &a, void *stream)
+{
+    if (method == PLX_DEMUX_CMA && !a.single_pass && a.taps <= 8 && a.dontskip && a.L >= 16) {
+        const unsigned gx = (unsigned)((a.nframes + 3) / 4); // 4 frames per wave, one wave per workgroup
+        PLX_LAUNCH(k_cma16, dim3(gx), dim3(64), 0, stream, a);
+    } else if (method == PLX_DEMUX_CMA) {
+        int G = 8;
+        while (G < a.taps) G *= 2;
+        if (G > 64) PLX_FAIL(PLX_ERR_UNSUPPORTED, "pol-demux: at most 64 taps are supported");
+        a.G = G; a.logG = ilog2i(G);
+        const int frames_per_block = 256 / G;
+        const unsigned gx = (unsigned)((a.nframes + frames_per_block - 1) / frames_per_block);
+        PLX_LAUNCH(k_cma, dim3(gx), dim3(256), 0, stream, a);
+    } else {
+        const unsigned gx = (unsigned)((a.nframes + 63) / 64);
+        PLX_LAUNCH(k_easi, dim3(gx), dim3(64), 0, stream, a);
+    }
+    PLX_HIP(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_poldemux_dev(int method, const double *d_x, double *d_y, int64_t L, int nframes, int32_t taps,
+                                double mu, const double *R, const double *d_M, double *d_h, int32_t *d_passes,
+                                void *stream)
+{
+    if (!d_x || !d_y || !d_M) PLX_FAIL(PLX_ERR_ARG, "plx_poldemux_dev: null argument");
+    if (method != PLX_DEMUX_CMA && method != PLX_DEMUX_EASI) PLX_FAIL(PLX_ERR_ARG, "plx_poldemux_dev: unknown method");
+    if (L < 1 || nframes < 1 || taps < 1 || !(mu > 0)) PLX_FAIL(PLX_ERR_ARG, "plx_poldemux_dev: bad size");
+    DemuxArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = (const cplx *)d_x; a.y = (cplx *)d_y; a.M = (const cplx *)d_M; a.h = (cplx *)d_h; a.passes = d_passes;
+    a.L = L; a.nframes = nframes; a.m_stride = 4; a.mu = mu; a.dontskip = 1; // drivers pass sps = 1 (:179,:231)
+    double *tmp_h = nullptr;
+    if (method == PLX_DEMUX_CMA) {
+        if (!R) PLX_FAIL(PLX_ERR_ARG, "plx_poldemux_dev: CMA needs R");
+        if (taps % 2 == 0) PLX_FAIL(PLX_ERR_ARG, "Ntaps should be an ODD INTEGER."); // cmaadaptivefilter.c:118-119
+        if (taps / 2 >= L) PLX_FAIL(PLX_ERR_ARG, "plx_poldemux_dev: more taps than samples");
+        a.taps = taps; a.halftaps = taps / 2; a.R1 = R[0]; a.R2 = R[1];
+        a.max_passes = (int)(50.0 * ceil(1.0 / ((double)L * mu))); // :175
+    } else {
+        a.taps = 1; a.halftaps = 0; // easipolardemux fixes taps = 1 (:197)
+        a.max_passes = (int)(20.0 * ceil(1.0 / ((double)L * mu))); // :227
+        if (!a.h) { // the EASI kernel keeps its taps in global memory
+            PLX_HIP(hipMalloc((void **)&tmp_h, sizeof(cplx) * 4 * (size_t)nframes));
+            a.h = (cplx *)tmp_h;
+        }
+    }
+    int rc = launch_demux(method, a, stream);
+    if (tmp_h) { hipStreamSynchronize((hipStream_t)stream); hipFree(tmp_h); }
+    return rc;
+}
+
+// gateway forms: one call of the MEX function on host arrays -----------------------
+static int gateway_filter(int method, const double *xr, const double *xi, int32_t Mdim, double *h1r, double *h1i,
+                          double *h2r, double *h2i, double Ntap, double mu, const double *R, double sps, double *yr,
+                          double *yi)
+{
+    if (!xr || !h1r || !h2r || !yr || !yi) PLX_FAIL(PLX_ERR_ARG, "adaptive filter gateway: null argument");
+    const int taps = (int)Ntap;
+    if (method == PLX_DEMUX_CMA && taps % 2 == 0) PLX_FAIL(PLX_ERR_ARG, "Ntaps should be an ODD INTEGER.");
+    if ((int)sps != 1 && (int)sps != 2) PLX_FAIL(PLX_ERR_ARG, "Samples x symbol should be either 1 or 2.");
+    if (taps < 1 || Mdim < taps) PLX_FAIL(PLX_ERR_ARG, "adaptive filter gateway: input shorter than the filter");
+    if (method == PLX_DEMUX_CMA && taps > 64) PLX_FAIL(PLX_ERR_UNSUPPORTED, "pol-demux: at most 64 taps are supported");
+    const int dimY = Mdim - taps + 1;
+    std::vector<double> hx(4 * (size_t)Mdim), hh(8 * (size_t)taps), hy(4 * (size_t)Mdim, 0.0);
+    for (int p = 0; p < 2; p++)
+        for (int i = 0; i < Mdim; i++) {
+            hx[2 * ((size_t)p * Mdim + i)] = xr[(size_t)p * Mdim + i];
+            hx[2 * ((size_t)p * Mdim + i) + 1] = xi ? xi[(size_t)p * Mdim + i] : 0.0;
+        }
+    for (int j = 0; j < 2 * taps; j++) {
+        hh[2 * j] = h1r[j]; hh[2 * j + 1] = h1i ? h1i[j] : 0.0;
+        hh[2 * (2 * taps + j)] = h2r[j]; hh[2 * (2 * taps + j) + 1] = h2i ? h2i[j] : 0.0;
+    }
+    double *dx = nullptr, *dy = nullptr, *dh = nullptr;
+    auto cleanup = [&]() { hipFree(dx); hipFree(dy); hipFree(dh); };
+    if (hipMalloc((void **)&dx, hx.size() * 8) != hipSuccess || hipMalloc((void **)&dy, hy.size() * 8) != hipSuccess ||
+        hipMalloc((void **)&dh, hh.size() * 8) != hipSuccess) {
+        cleanup();
+        PLX_FAIL(PLX_ERR_HIP, "adaptive filter gateway: device allocation failed");
+    }
+    hipMemcpy(dx, hx.data(), hx.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(dh, hh.data(), hh.size() * 8, hipMemcpyHostToDevice);
+    hipMemset(dy, 0, hy.size() * 8);
+    DemuxArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = (const cplx *)dx; a.y = (cplx *)dy; a.h = (cplx *)dh; a.L = Mdim; a.nframes = 1; a.taps = taps;
+    a.halftaps = 0; a.mu = mu; a.single_pass = 1; a.max_passes = 2;
+    a.dontskip = ((int)sps == 1) ? 1 : 0;
+    a.skipk = ((taps - 1) / 2) % 2; // cmaadaptivefilter.c:64
+    if (R) { a.R1 = R[0]; a.R2 = R[1]; }
+    int rc = launch_demux(method, a, nullptr);
+    if (!rc) {
+        hipMemcpy(hy.data(), dy, hy.size() * 8, hipMemcpyDeviceToHost);
+        hipMemcpy(hh.data(), dh, hh.size() * 8, hipMemcpyDeviceToHost);
+        // y is [dimY x 2]; the kernel wrote column p at offset p*Mdim
+        for (int p = 0; p < 2; p++)
+            for (int i = 0; i < dimY; i++) {
+                yr[(size_t)p * dimY + i] = hy[2 * ((size_t)p * Mdim + i)];
+                yi[(size_t)p * dimY + i] = hy[2 * ((size_t)p * Mdim + i) + 1];
+            }
+        // in-place tap update, as the reference MEX does through prhs[1..2] (:87-88)
+        for (int j = 0; j < 2 * taps; j++) {
+            h1r[j] = hh[2 * j]; if (h1i) h1i[j] = hh[2 * j + 1];
+            h2r[j] = hh[2 * (2 * taps + j)]; if (h2i) h2i[j] = hh[2 * (2 * taps + j) + 1];
+        }
+    }
+    cleanup();
+    return rc;
+}
+
+extern "C" int plx_cmaadaptivefilter(const double *xr, const double *xi, int32_t Mdim, double *h1r, double *h1i,
+                                     double *h2r, double *h2i, double Ntap, double mu, const double *R, double sps,
+                                     double *yr, double *yi)
+{
+    if (!R) PLX_FAIL(PLX_ERR_ARG, "plx_cmaadaptivefilter: R is required");
+    return gateway_filter(PLX_DEMUX_CMA, xr, xi, Mdim, h1r, h1i, h2r, h2i, Ntap, mu, R, sps, yr, yi);
+}
+
+extern "C" int plx_easiadaptivefilter(const double *xr, const double *xi, int32_t Mdim, double *h1r, double *h1i,
+                                      double *h2r, double *h2i, double Ntap, double mu, double sps, double *yr,
+                                      double *yi)
+{
+    return gateway_filter(PLX_DEMUX_EASI, xr, xi, Mdim, h1r, h1i, h2r, h2i, Ntap, mu, nullptr, sps, yr, yi);
+}
+
+// ===================================================================== DSP host ===
+struct plx_dsp {
+    plx_dsp_params p;
+    int64_t Lin, L;
+    int ncol, max_frames;
+    cplx *d_a = nullptr, *d_b = nullptr, *d_M = nullptr, *d_h = nullptr, *d_wsc = nullptr;
+    double *d_wsr = nullptr;
+    int use_lds = 0;
+    size_t lds_cpe = 0;
+};
+
+extern "C" int plx_dsp_destroy(plx_dsp *P)
+{
+    if (P) {
+        hipFree(P->d_a); hipFree(P->d_b); hipFree(P->d_M); hipFree(P->d_h); hipFree(P->d_wsc); hipFree(P->d_wsr);
+        delete P;
+    }
+    return PLX_OK;
+}
+
+extern "C" int plx_dsp_create(plx_dsp **out, int64_t Lin, int32_t ncol, int32_t max_frames, const plx_dsp_params *p)
+{
+    if (!out || !p) PLX_FAIL(PLX_ERR_ARG, "plx_dsp_create: null argument");
+    *out = nullptr;
+    if (Lin < 2 || (ncol != 1 && ncol != 2) || max_frames < 1) PLX_FAIL(PLX_ERR_ARG, "plx_dsp_create: bad size");
+    if (p->applypol && ncol == 2 && (p->polmethod < 0 || p->polmethod > 3))
+        PLX_FAIL(PLX_ERR_ARG, "Unknown Polar Rotation method."); // DspPdmCohQpsk.m:40
+    if (p->modorder < 1 || p->modorder > 4 || p->poworder < 1 || p->freqavg < 0 || p->phasavg < 0)
+        PLX_FAIL(PLX_ERR_ARG, "plx_dsp_create: bad carrier-recovery parameters");
+    plx_dsp *P = new plx_dsp();
+    P->p = *p; P->Lin = Lin; P->ncol = ncol; P->max_frames = max_frames;
+    P->L = p->workatbaudrate ? Lin : (Lin + 1) / 2;
+    const size_t n = (size_t)max_frames * ncol * P->L;
+    const size_t lds = (256 + 16) * sizeof(double) + (size_t)P->L * (2 * sizeof(cplx) + 2 * sizeof(double));
+    P->use_lds = lds <= 64 * 1024 ? 1 : 0;
+    P->lds_cpe = P->use_lds ? lds : (256 + 16) * sizeof(double);
+    bool ok = hipMalloc((void **)&P->d_a, n * sizeof(cplx)) == hipSuccess &&
+              hipMalloc((void **)&P->d_b, n * sizeof(cplx)) == hipSuccess &&
+              hipMalloc((void **)&P->d_M, (size_t)max_frames * 4 * sizeof(cplx)) == hipSuccess &&
+              hipMalloc((void **)&P->d_h, (size_t)max_frames * 4 * 64 * sizeof(cplx)) == hipSuccess;
+    if (ok && !P->use_lds)
+        ok = hipMalloc((void **)&P->d_wsc, 2 * n * sizeof(cplx)) == hipSuccess &&
+             hipMalloc((void **)&P->d_wsr, 2 * n * sizeof(double)) == hipSuccess;
+    if (!ok) { plx_dsp_destroy(P); PLX_FAIL(PLX_ERR_HIP, "plx_dsp_create: device allocation failed"); }
+    if (allow_lds(k_cpe, P->lds_cpe) != hipSuccess) { plx_dsp_destroy(P); PLX_FAIL(PLX_ERR_HIP, "plx_dsp_create: cannot reserve LDS"); }
+    *out = P;
+    return PLX_OK;
+}
+
+extern "C" int64_t plx_dsp_out_len(const plx_dsp *P) { return P ? P->L : -1; }
+
+static int demux_stage(plx_dsp *P, int method, cplx *src, cplx *dst, int nframes, void *stream)
+{
+    const plx_dsp_params &p = P->p;
+    const int txpol = method == PLX_DEMUX_CMA ? p.cma_txpolars : p.easi_txpolars;
+    const double phi = method == PLX_DEMUX_CMA ? p.cma_phizero : p.easi_phizero;
+    if (txpol == 2) { // M = [cos sin; -sin cos]  :155-156
+        std::vector<cplx> M((size_t)nframes * 4);
+        for (int f = 0; f < nframes; f++) {
+            M[4 * f] = make_double2(cos(phi), 0); M[4 * f + 1] = make_double2(sin(phi), 0);
+            M[4 * f + 2] = make_double2(-sin(phi), 0); M[4 * f + 3] = make_double2(cos(phi), 0);
+        }
+        PLX_HIP(hipMemcpyAsync(P->d_M, M.data(), M.size() * sizeof(cplx), hipMemcpyHostToDevice, (hipStream_t)stream));
+        PLX_HIP(hipStreamSynchronize((hipStream_t)stream)); // M is a stack temporary
+    } else {
+        PLX_LAUNCH(k_rotpolar, dim3((unsigned)nframes), dim3(256), 16 * sizeof(double), stream, (const cplx *)src,
+                   (cplx *)nullptr, P->d_M, P->L, 0);
+    }
+    return plx_poldemux_dev(method, (const double *)src, (double *)dst, P->L, nframes,
+                            method == PLX_DEMUX_CMA ? p.cma_taps : 1, method == PLX_DEMUX_CMA ? p.cma_mu : p.easi_mu,
+                            p.cma_R, (const double *)P->d_M, (double *)P->d_h, nullptr, stream);
+}
+
+extern "C" int plx_dsp_run_dev(plx_dsp *P, const double *d_in, double *d_out, int nframes, void *stream)
+{
+    if (!P || !d_in || !d_out) PLX_FAIL(PLX_ERR_ARG, "plx_dsp_run_dev: null argument");
+    if (nframes < 1 || nframes > P->max_frames) PLX_FAIL(PLX_ERR_ARG, "plx_dsp_run_dev: nframes out of range");
+    const plx_dsp_params &p = P->p;
+    PreArgs pa;
+    pa.in = (const cplx *)d_in; pa.out = P->d_a; pa.Lin = P->Lin; pa.L = P->L; pa.ncol = P->ncol;
+    pa.stride = p.workatbaudrate ? 1 : 2; pa.applynlr = p.applynlr; pa.nlralpha = p.nlralpha;
+    pa.inv_peak = 1.0 / (4 * sqrt(p.power_mw)); // :22-23 (multiplication by the reciprocal)
+    PLX_LAUNCH(k_dsp_pre, dim3((unsigned)nframes), dim3(256), 16 * sizeof(double), stream, pa);
+    cplx *cur = P->d_a, *oth = P->d_b;
+    if (p.applypol && P->ncol == 2) { // :26-42
+        int rc = PLX_OK;
+        switch (p.polmethod) {
+        case 0:
+            PLX_LAUNCH(k_rotpolar, dim3((unsigned)nframes), dim3(256), 16 * sizeof(double), stream, (const cplx *)cur,
+                       oth, (cplx *)nullptr, P->L, 1);
+            std::swap(cur, oth);
+            break;
+        case 1:
+            rc = demux_stage(P, PLX_DEMUX_CMA, cur, oth, nframes, stream);
+            std::swap(cur, oth);
+            break;
+        case 2:
+            rc = demux_stage(P, PLX_DEMUX_EASI, cur, oth, nframes, stream);
+            std::swap(cur, oth);
+            break;
+        case 3:
+            rc = demux_stage(P, PLX_DEMUX_EASI, cur, oth, nframes, stream);
+            if (!rc) rc = demux_stage(P, PLX_DEMUX_CMA, oth, cur, nframes, stream);
+            break;
+        default:
+            PLX_FAIL(PLX_ERR_ARG, "Unknown Polar Rotation method.");
+        }
+        if (rc) return rc;
+    }
+    CpeArgs ca;
+    ca.s = cur; ca.out = (cplx *)d_out; ca.wsc = P->d_wsc; ca.wsr = P->d_wsr; ca.L = P->L; ca.use_lds = P->use_lds;
+    ca.modorder = p.modorder; ca.freqavg = p.freqavg; ca.phasavg = p.phasavg; ca.poworder = p.poworder;
+    PLX_LAUNCH(k_cpe, dim3((unsigned)(nframes * P->ncol)), dim3(256), P->lds_cpe, stream, ca);
+    PLX_HIP(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_decide_count_dev(const double *d_sym, int64_t L, int32_t ncol, int nframes, const uint8_t *d_pat,
+                                    uint8_t *d_pat_hat, int64_t *d_err, void *stream)
+{
+    if (!d_sym || L < 1 || ncol < 1 || nframes < 1) PLX_FAIL(PLX_ERR_ARG, "plx_decide_count_dev: bad argument");
+    PLX_LAUNCH(k_decide, dim3((unsigned)(nframes * ncol)), dim3(256), 16 * sizeof(unsigned long long), stream,
+               (const cplx *)d_sym, L, (int)ncol, d_pat, d_pat_hat, (unsigned long long *)d_err);
+    PLX_HIP(hipGetLastError());
+    return PLX_OK;
+}

@@ -1,0 +1,184 @@
+"""Batched, device-resident hot path: fibre -> (pick to 2 sps) -> CDE_OFDE ->
+DspPdmCohQpsk (CMA + carrier recovery) -> decisions/error count.
+
+This is what bench.py times and what the Monte-Carlo runner shards.  It is the
+chain of Run_my_PDM_QPSK.m:122-193 minus the analogue front end
+(receiver_cohmix + decimate, SURVEY 8f-1, "next"): the harness takes the
+symbol-centre and mid-symbol samples of the propagated field directly.  Every
+stage is a call into libpolmux_hip through the resident tier of the C ABI;
+torch only owns the HBM buffers and the stream.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _abi, synth
+from .fiber import fiber_tables, parse_flag
+from .gstate import GSTATE
+from .rx import cde_transfer, dsp_params_struct
+
+
+class HotPathConfig:
+    """Run_my_PDM_QPSK-style parameters (BASELINE config C1 by default)."""
+
+    def __init__(self, nsymb=1024, nt=64, symbolrate=28.0, pavg_mw=2.0, lam=1550.0, flag="g-s-",
+                 length=8e4, alphadB=0.2, aeff=80.0, n2=2.7e-20, disp=17.0, slope=0.0, dphimax=5e-3, dzmax=2e4,
+                 dgd=0.1, nplates=100, manakov="no", nspans=1, fft_length=256, cde_L=128, applypol=True,
+                 polmethod="cma", cma_taps=7, cma_mu=1 / 6000, freqavg=500, phasavg=3, poworder=2):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+    @property
+    def nfft(self):
+        return self.nsymb * self.nt
+
+
+class HotPath:
+    def __init__(self, cfg, max_frames):
+        import torch
+        self.torch = torch
+        self.cfg = cfg
+        self.F = int(max_frames)
+        self.lib = _abi.get()
+        self.dev = torch.device("cuda", torch.cuda.current_device())
+        n = cfg.nfft
+        # --- host side of fiber(): flag, conversions, tables (fiber.m:157-362) ---
+        GSTATE.NSYMB, GSTATE.NT, GSTATE.NCH = cfg.nsymb, cfg.nt, 1
+        GSTATE.SYMBOLRATE = cfg.symbolrate
+        GSTATE.FN = synth.fn_grid(cfg.nsymb, cfg.nt)
+        GSTATE.LAMBDA = np.array([cfg.lam])
+        x = {"length": cfg.length, "alphadB": cfg.alphadB, "aeff": cfg.aeff, "n2": cfg.n2, "lambda": cfg.lam,
+             "disp": cfg.disp, "slope": cfg.slope, "dphimax": cfg.dphimax, "dzmax": min(cfg.dzmax, cfg.length)}
+        self.fls, dphimaxt, dzmaxt = parse_flag(cfg.flag, 1, x)
+        self.pmd = self.fls[1] == 1
+        nplates = cfg.nplates if self.pmd else 1
+        dgdrms = math.sqrt(3 * math.pi / 8) * cfg.dgd / math.sqrt(nplates) if self.pmd else 0.0   # fiber.m:277
+        t = fiber_tables(x, self.fls, 1, dgdrms)
+        self.alphalin = t["alphalin"]
+        d = _abi.SsfmDesc()
+        d.nfft, d.nfc, d.dual_pol, d.max_frames = n, 1, 1, self.F
+        for i in range(4):
+            d.fls[i] = self.fls[i]
+        d.dzmaxt, d.dphimaxt, d.alphalin, d.length = dzmaxt, dphimaxt, t["alphalin"], cfg.length
+        d.nplates, d.manakov = nplates, int(str(cfg.manakov).lower() == "yes")
+        self._keep = (np.ascontiguousarray(t["gam"]), t["betat"], t["db1"])
+        d.gam, d.betat, d.db1 = (a.ctypes.data for a in self._keep)
+        self.ssfm = C.c_void_p()
+        self.lib.call("plx_ssfm_create", C.byref(self.ssfm), C.byref(d))
+        self.nplates = nplates
+        # --- Tx (host, once): Run_my_PDM_QPSK.m:101-117 ---
+        ux, uy, bits, power = synth.pdm_qpsk_field(cfg.nsymb, cfg.nt, cfg.pavg_mw)
+        self.tx_host = (ux, uy)
+        self.bits = bits
+        self.power_mw = power
+        GSTATE.POWER = np.array([power])
+        self.tx = torch.from_numpy(np.stack([ux, uy])).to(self.dev)          # [2, n]
+        self.pat = torch.from_numpy(np.ascontiguousarray(bits.T.astype(np.uint8))).to(self.dev)   # [4, nsymb]
+        # --- Rx plans ---
+        self.Lrx = 2 * cfg.nsymb
+        fs = 2 * cfg.symbolrate * 1e9                                         # Run_my_PDM_QPSK.m:66,149
+        N = min(cfg.fft_length, self.Lrx)
+        H = cde_transfer(N, fs, cfg.lam * 1e-9, cfg.length * cfg.nspans, cfg.disp * 1e-6, cfg.slope * 1e-6)
+        Hi = np.ascontiguousarray(H).view(np.float64)
+        self.cde = C.c_void_p()
+        self.lib.call("plx_cde_create", C.byref(self.cde), N, cfg.cde_L, Hi.ctypes.data)
+        dsp = dict(workatbaudrate=False, applynlr=False, applypol=cfg.applypol, polmethod=cfg.polmethod,
+                   cmaparams=dict(R=[1, 1], mu=cfg.cma_mu, taps=cfg.cma_taps, txpolars=2, phizero=0),
+                   easiparams=dict(mu=cfg.cma_mu, txpolars=2, phizero=0), modorder=2, freqavg=cfg.freqavg,
+                   phasavg=cfg.phasavg, poworder=cfg.poworder)
+        self.dsp_p = dsp_params_struct(dsp, power)
+        self.dsp = C.c_void_p()
+        self.lib.call("plx_dsp_create", C.byref(self.dsp), self.Lrx, 2, self.F, C.byref(self.dsp_p))
+        # receive scale: undo the span loss and bring symbols to the 4*sqrt(P) full scale that
+        # DspPdmCohQpsk divides by (DspPdmCohQpsk.m:22-23, "2* -> see receiver_cohmix")
+        self.rx_scale = 4.0 * math.sqrt(power) / math.sqrt(power / 2.0) * math.exp(0.5 * self.alphalin * cfg.length * cfg.nspans)
+        c128 = torch.complex128
+        self.rx = torch.empty((self.F, 2, self.Lrx), dtype=c128, device=self.dev)
+        self.eq = torch.empty_like(self.rx)
+        self.sym = torch.empty((self.F, 2, cfg.nsymb), dtype=c128, device=self.dev)
+        self.err = torch.zeros((self.F, 2), dtype=torch.int64, device=self.dev)
+
+    def close(self):
+        for name, h in (("plx_ssfm_destroy", self.ssfm), ("plx_cde_destroy", self.cde), ("plx_dsp_destroy", self.dsp)):
+            if h:
+                self.lib.call(name, h)
+        self.ssfm = self.cde = self.dsp = None
+
+    # ------------------------------------------------------------------ inputs ---
+    def make_batch(self, nframes, launch_scale=None):
+        """Synthetic inputs: the Tx waveform replicated over frames -> (ux, uy), each [F, n] complex128,
+        with an optional per-frame launch-power scaling (power sweep)."""
+        torch = self.torch
+        ux = self.tx[0].unsqueeze(0).repeat(nframes, 1).contiguous()
+        uy = self.tx[1].unsqueeze(0).repeat(nframes, 1).contiguous()
+        if launch_scale is not None:
+            k = torch.as_tensor(np.sqrt(np.asarray(launch_scale, dtype=float)), device=self.dev).reshape(-1, 1)
+            ux, uy = ux * k, uy * k
+        return ux, uy
+
+    def set_random_pmd(self, seeds):
+        """brf draws of fiber.m:274-276, one independent set per frame, keyed by realisation seed."""
+        np_ = self.nplates
+        db0 = np.empty((len(seeds), np_)); th = np.empty_like(db0); ep = np.empty_like(db0)
+        for k, sd in enumerate(seeds):
+            r = np.random.default_rng([20260101, int(sd), 1])
+            db0[k] = r.random(np_) * 2 * math.pi - math.pi
+            th[k] = r.random(np_) * math.pi - 0.5 * math.pi
+            ep[k] = 0.5 * np.arcsin(r.random(np_) * 2 - 1)
+        self.lib.call("plx_ssfm_set_birefringence", self.ssfm, db0.ctypes.data, th.ctypes.data, ep.ctypes.data, len(seeds))
+        return db0, th, ep
+
+    # ------------------------------------------------------------------- stages ---
+    def stream(self):
+        return self.torch.cuda.current_stream().cuda_stream
+
+    def fibre(self, ux, uy):
+        """ux, uy: [F, n] complex128 device tensors ([frame][channel=1][nfft]), propagated in place."""
+        for _ in range(self.cfg.nspans):
+            self.lib.call("plx_ssfm_propagate_dev", self.ssfm, ux.data_ptr(), uy.data_ptr(), ux.shape[0], self.stream())
+
+    def receive(self, ux, uy, noise_sigma=0.0, noise_seed=None):
+        """2-sps pick (symbol centre + mid-symbol), CDE, DSP, decisions.  Returns err [F,2] (device)."""
+        F = ux.shape[0]
+        cfg = self.cfg
+        half = cfg.nt // 2
+        st = self.stream()
+        rx = self.rx[:F]
+        for pol, src in enumerate((ux, uy)):   # rx[f][pol][i] = scale * u_pol[f][i*half]
+            self.lib.call("plx_pick_dev", src.data_ptr(), rx.data_ptr() + pol * self.Lrx * 16, cfg.nfft, self.Lrx, 0,
+                          half, self.rx_scale, F, 2 * self.Lrx, st)
+        if noise_sigma:
+            g = self.torch.Generator(device=self.dev)
+            g.manual_seed(int(noise_seed or 0))
+            nz = self.torch.randn((F, 2, self.Lrx, 2), generator=g, device=self.dev, dtype=self.torch.float64)
+            rx += noise_sigma * self.torch.view_as_complex(nz)
+        self.lib.call("plx_cde_apply_dev", self.cde, rx.data_ptr(), self.eq.data_ptr(), self.Lrx, 2 * F, st)
+        self.lib.call("plx_dsp_run_dev", self.dsp, self.eq.data_ptr(), self.sym.data_ptr(), F, st)
+        self.lib.call("plx_decide_count_dev", self.sym.data_ptr(), cfg.nsymb, 2, F, self.pat.data_ptr(), None,
+                      self.err.data_ptr(), st)
+        return self.err[:F]
+
+    def errors_min_over_rotations(self, F):
+        """Resolve the pi/2 ambiguity of the blind phase estimate per polarisation (host-side
+        convenience for BER sanity; the reference's scripts use differential decoding instead)."""
+        torch = self.torch
+        best = None
+        base = self.sym[:F].clone()
+        for k in range(4):
+            self.sym[:F] = base * (1j ** k)
+            self.lib.call("plx_decide_count_dev", self.sym.data_ptr(), self.cfg.nsymb, 2, F, self.pat.data_ptr(), None,
+                          self.err.data_ptr(), self.stream())
+            e = self.err[:F].clone()
+            best = e if best is None else torch.minimum(best, e)
+        self.sym[:F] = base
+        return best
+
+    def run(self, ux, uy, noise_sigma=0.0, noise_seed=None):
+        self.fibre(ux, uy)
+        return self.receive(ux, uy, noise_sigma, noise_seed)
+
+    def ssfm_stats(self):
+        rows, steps = C.c_int64(), C.c_int64()
+        self.lib.call("plx_ssfm_stats", self.ssfm, C.byref(rows), C.byref(steps))
+        return rows.value, steps.value

@@ -1,0 +1,23 @@
+"""Build/load the emulated (CPU, test-only) copy of the kernels -- see tests/emu/hip_emu.h.
+polmux_amd never loads this library; it exists so the kernel sources can be exercised
+(and sanitised) without a GPU."""
+import glob
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "tests", "emu", "_build", "libpolmux_emu.so")
+
+
+def build():
+    srcs = glob.glob(os.path.join(ROOT, "polmux_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "tests", "emu", "hip_emu.*")) \
+        + [os.path.join(ROOT, "include", "polmux_hip.h")]
+    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
+        return LIB
+    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build.sh")], stdout=subprocess.DEVNULL)
+    return LIB
+
+
+def binding():
+    from polmux_amd import _abi
+    return _abi.Binding(build())

@@ -94,6 +94,12 @@ template <class T> static inline T __shfl_down(T v, int d, int = 64)
 }
 template <class T> static inline T __shfl(T v, int src, int = 64) { return emu_shfl_src(v, src); }
 static inline int __builtin_amdgcn_readfirstlane(int v) { return v; }
+static inline int __any(int pred)
+{
+    int v = pred ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m, 64);
+    return v;
+}
 
 static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v)
 {

@@ -1,0 +1,292 @@
+"""Run the *kernel sources* (polmux_amd/csrc/*.hip) under the host emulator of
+tests/emu and compare with the CPU oracle.  This is a CPU-side sanity net for
+indexing and synchronisation (it is also what the ASan/UBSan build runs); the
+parity tests proper are the -m gpu tests, which call the hipcc-built library."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from polmux_amd import synth
+from polmux_amd._abi import DspParams, SsfmDesc
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from tests import _emu
+    return _emu.binding()
+
+
+def _vp(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def _il(z):
+    """complex array -> interleaved float64 copy (C order over the given array's memory order)"""
+    z = np.ascontiguousarray(z, dtype=np.complex128)
+    return z.view(np.float64).copy()
+
+
+def _qpsk_field(n, nt, pavg, seeds=(2, 3)):
+    ux, uy, bits, pw = synth.pdm_qpsk_field(n // nt, nt, pavg, *seeds)
+    return ux, uy, bits, pw
+
+
+def _desc(n, nfc, dual, fls, L, alpha, gam, dzmax, dphimax, betat, db1, nplates=1, manakov=0, frames=1):
+    d = SsfmDesc()
+    d.nfft, d.nfc, d.dual_pol, d.max_frames = n, nfc, dual, frames
+    for i in range(4):
+        d.fls[i] = fls[i]
+    d.dzmaxt, d.dphimaxt, d.alphalin, d.length, d.nplates, d.manakov = dzmax, dphimax, alpha, L, nplates, manakov
+    d._keep = (np.ascontiguousarray(gam, dtype=float), np.asfortranarray(betat), np.asfortranarray(db1))
+    d.gam, d.betat, d.db1 = d._keep[0].ctypes.data, d._keep[1].ctypes.data, d._keep[2].ctypes.data
+    return d
+
+
+def _tables(n, nt, fls, nplates, nfc=1):
+    omega = 2 * np.pi * 28 * synth.fn_grid(n // nt, nt)
+    betat = np.stack([0.5 * omega ** 2 * -2.17e-8 * fls[0] + 6.8e-9 * k * omega for k in range(nfc)], 1)
+    db1 = np.stack([np.sqrt(3 * np.pi / 8) * 0.1 / np.sqrt(nplates) / 28 * omega * fls[1] for _ in range(nfc)], 1)
+    return betat, db1
+
+
+def test_emu_matrix_ssfm_batch_with_pmd(emu, oracle):
+    """two frames with their own PMD realisation and launch power advance in lock-step launches"""
+    n, nt, nplates, L = 1024, 16, 6, 4e4
+    fls = [1, 1, 1, 0]
+    betat, db1 = _tables(n, nt, fls, nplates)
+    r = np.random.default_rng(3)
+    brf = [(r.random(nplates) * 2 * np.pi - np.pi, r.random(nplates) * np.pi - np.pi / 2, 0.5 * np.arcsin(r.random(nplates) * 2 - 1))
+           for _ in range(2)]
+    fields = [_qpsk_field(n, nt, p)[:2] for p in (6.0, 12.0)]
+    d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 1e4, 2e-2, betat, db1, nplates=nplates, frames=2)
+    plan = C.c_void_p()
+    emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+    db0 = np.concatenate([b[0] for b in brf]); th = np.concatenate([b[1] for b in brf]); ep = np.concatenate([b[2] for b in brf])
+    emu.call("plx_ssfm_set_birefringence", plan, _vp(db0), _vp(th), _vp(ep), 2)
+    ux = _il(np.stack([f[0] for f in fields])); uy = _il(np.stack([f[1] for f in fields]))
+    emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 2, None)
+    first = np.zeros(2); ncyc = np.zeros(2, np.int32)
+    emu.call("plx_ssfm_results", plan, 2, _vp(first), _vp(ncyc))
+    rows, steps = C.c_int64(), C.c_int64()
+    emu.call("plx_ssfm_stats", plan, C.byref(rows), C.byref(steps))
+    emu.call("plx_ssfm_destroy", plan)
+    gx = ux.view(np.complex128).reshape(2, n); gy = uy.view(np.complex128).reshape(2, n)
+    for f in range(2):
+        rc, ofd, onc, ox, oy = oracle.matrix_ssfm(fields[f][0], fields[f][1], betat, db1, 1e4, 2e-2, [1.3e-6], 4.6e-5, L,
+                                                  nplates, 0, fls, *brf[f])
+        assert rc == 0 and ncyc[f] == onc and first[f] == pytest.approx(ofd, rel=1e-13)
+        assert np.abs(gx[f] - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
+        assert np.abs(gy[f] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
+    assert ncyc[0] != ncyc[1]          # the frames really did take different step sequences
+    assert steps.value == int(ncyc.sum()) * n and rows.value >= ncyc.max()
+
+
+def test_emu_scalar_xpm_gateway(emu, oracle):
+    n, nt, nfc = 512, 8, 2
+    fls = [1, 0, 1, 1]
+    betat, db1 = _tables(n, nt, fls, 1, nfc)
+    u = np.asfortranarray(np.stack([_qpsk_field(n, nt, 6.0, (2 + k, 5 + k))[0] for k in range(nfc)], 1))
+    gam = [1.2e-6, 1.3e-6]
+    d = _desc(n, nfc, 0, fls, 3e4, 4.6e-5, gam, 1e4, 2e-2, betat, db1)
+    ur, ui = np.asfortranarray(u.real.copy()), np.asfortranarray(u.imag.copy())
+    fd, nc = C.c_double(), C.c_int32()
+    emu.call("plx_scalar_ssfm", _vp(ur), _vp(ui), C.byref(d), C.byref(fd), C.byref(nc))
+    ofd, onc, ou = oracle.scalar_ssfm(u, betat, 1e4, 2e-2, gam, 4.6e-5, 3e4, fls)
+    assert nc.value == onc
+    assert np.abs((ur + 1j * ui) - ou).max() < 1e-11 * np.abs(ou).max()
+
+
+def test_emu_reference_error_paths(emu):
+    betat = np.zeros((256, 2))
+    d = _desc(256, 2, 1, [1, 0, 1, 1], 1e3, 0.0, [1e-6, 1e-6], 1e3, 5e-3, betat, betat)
+    plan = C.c_void_p()
+    from polmux_amd._abi import PolmuxError
+    with pytest.raises(PolmuxError, match="CNLSE with separate fields"):          # fiber.m:854
+        emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+    d = _desc(300, 1, 1, [1, 0, 0, 0], 1e3, 0.0, [1e-6], 1e3, 5e-3, np.zeros((300, 1)), np.zeros((300, 1)))
+    with pytest.raises(PolmuxError, match="power of two"):
+        emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+
+
+def test_emu_fastexp(emu):
+    x = np.linspace(-50, 50, 1001)
+    yr, yi = np.zeros_like(x), np.zeros_like(x)
+    emu.call("plx_fastexp", _vp(x), _vp(yr), _vp(yi), x.size)
+    np.testing.assert_allclose(yr + 1j * yi, np.exp(1j * x), atol=1e-15)
+
+
+@pytest.mark.parametrize("nx,N,L", [(2048, 256, 128), (700, 64, 32), (16, 16, 8), (1000, 128, 100)])
+def test_emu_cde(emu, oracle, nx, N, L):
+    r = np.random.default_rng(nx)
+    x = r.standard_normal((2, nx)) + 1j * r.standard_normal((2, nx))
+    H = oracle.cde_transfer(N, 56e9, 1.55e-6, 8e4, 17e-6, 0.0)
+    plan = C.c_void_p()
+    Hi = _il(H)
+    emu.call("plx_cde_create", C.byref(plan), N, L, _vp(Hi))
+    xi, yo = _il(x), np.zeros(4 * nx)
+    emu.call("plx_cde_apply_dev", plan, _vp(xi), _vp(yo), nx, 2, None)
+    emu.call("plx_cde_destroy", plan)
+    y = yo.view(np.complex128).reshape(2, nx)
+    for k in range(2):
+        ref, rc = oracle.overlap_both_trans(x[k], H, L)
+        assert rc == 0
+        np.testing.assert_allclose(y[k], ref, rtol=0, atol=1e-12)
+
+
+def test_emu_cde_gateway_and_checks(emu, oracle):
+    from polmux_amd._abi import PolmuxError
+    r = np.random.default_rng(5)
+    nx = 600
+    x = r.standard_normal(nx) + 1j * r.standard_normal(nx)
+    y = r.standard_normal(nx) + 1j * r.standard_normal(nx)
+    outs = [np.zeros(nx) for _ in range(4)]
+    args = [np.ascontiguousarray(v) for v in (x.real, x.imag, y.real, y.imag)]
+    emu.call("plx_cde_ofde", *[_vp(a) for a in args], nx, 56e9, 1.55e-6, 8e4, 17e-6, 0.0, 256, 128, *[_vp(o) for o in outs])
+    ox, oy, rc = oracle.cde_ofde(x, y, 56e9, 1.55e-6, 8e4, 17e-6, 0.0, 256, 128)
+    np.testing.assert_allclose(outs[0] + 1j * outs[1], ox, atol=1e-12)
+    np.testing.assert_allclose(outs[2] + 1j * outs[3], oy, atol=1e-12)
+    with pytest.raises(PolmuxError, match="L must be > 0"):                       # CDE_OFDE.m:77-78
+        emu.call("plx_cde_ofde", *[_vp(a) for a in args], nx, 56e9, 1.55e-6, 8e4, 17e-6, 0.0, 256, 0, *[_vp(o) for o in outs])
+    with pytest.raises(PolmuxError, match="shorter than filter"):                 # :79-80
+        emu.call("plx_cde_ofde", *[_vp(a) for a in args], nx, 56e9, 1.55e-6, 8e4, 17e-6, 0.0, 256, 300, *[_vp(o) for o in outs])
+
+
+def _mixed_qpsk(L, seed, noise=0.05):
+    r = np.random.default_rng(seed)
+    a = np.exp(1j * (np.pi / 4 + np.pi / 2 * r.integers(0, 4, (L, 2))))
+    th = 0.4
+    J = np.array([[np.cos(th), np.sin(th) * np.exp(0.3j)], [-np.sin(th) * np.exp(-0.3j), np.cos(th)]])
+    return a @ J + noise * (r.standard_normal((L, 2)) + 1j * r.standard_normal((L, 2)))
+
+
+@pytest.mark.parametrize("taps,sps", [(1, 1), (3, 2), (7, 1), (7, 2), (15, 1)])
+def test_emu_cmaadaptivefilter_gateway(emu, oracle, taps, sps):
+    x = np.asfortranarray(_mixed_qpsk(200, taps))
+    r = np.random.default_rng(taps)
+    h1 = np.asfortranarray(0.3 * (r.standard_normal((taps, 2)) + 1j * r.standard_normal((taps, 2))))
+    h2 = np.asfortranarray(0.3 * (r.standard_normal((taps, 2)) + 1j * r.standard_normal((taps, 2))))
+    xr, xi = np.asfortranarray(x.real.copy()), np.asfortranarray(x.imag.copy())
+    hs = [np.asfortranarray(v.copy()) for v in (h1.real, h1.imag, h2.real, h2.imag)]
+    dimY = 200 - taps + 1
+    yr, yi = np.zeros((dimY, 2), order="F"), np.zeros((dimY, 2), order="F")
+    R = np.array([1.0, 1.2])
+    emu.call("plx_cmaadaptivefilter", _vp(xr), _vp(xi), 200, *[_vp(h) for h in hs], float(taps), 1e-3, _vp(R), float(sps),
+             _vp(yr), _vp(yi))
+    y, g1, g2 = oracle.cmaadaptivefilter(x, h1, h2, taps, 1e-3, R, sps)
+    np.testing.assert_allclose(yr + 1j * yi, y, atol=1e-13)
+    np.testing.assert_allclose(hs[0] + 1j * hs[1], g1, atol=1e-13)       # taps updated IN PLACE (MEX contract)
+    np.testing.assert_allclose(hs[2] + 1j * hs[3], g2, atol=1e-13)
+
+
+def test_emu_filter_gateway_errors(emu):
+    from polmux_amd._abi import PolmuxError
+    z = np.zeros((16, 2), order="F"); h = np.zeros((4, 2), order="F"); y = np.zeros((16, 2), order="F"); R = np.ones(2)
+    with pytest.raises(PolmuxError, match="Ntaps should be an ODD INTEGER."):
+        emu.call("plx_cmaadaptivefilter", _vp(z), _vp(z), 16, _vp(h), _vp(h), _vp(h), _vp(h), 4.0, 1e-3, _vp(R), 1.0, _vp(y), _vp(y))
+    with pytest.raises(PolmuxError, match="Samples x symbol should be either 1 or 2."):
+        emu.call("plx_cmaadaptivefilter", _vp(z), _vp(z), 16, _vp(h), _vp(h), _vp(h), _vp(h), 3.0, 1e-3, _vp(R), 3.0, _vp(y), _vp(y))
+    with pytest.raises(PolmuxError, match="Samples x symbol should be either 1 or 2."):
+        emu.call("plx_easiadaptivefilter", _vp(z), _vp(z), 16, _vp(h), _vp(h), _vp(h), _vp(h), 1.0, 1e-3, 0.0, _vp(y), _vp(y))
+
+
+@pytest.mark.parametrize("taps", [1, 3])
+def test_emu_easiadaptivefilter_gateway(emu, oracle, taps):
+    x = np.asfortranarray(_mixed_qpsk(150, 9))
+    r = np.random.default_rng(2)
+    h1 = np.asfortranarray(0.5 * (r.standard_normal((taps, 2)) + 1j * r.standard_normal((taps, 2))))
+    h2 = np.asfortranarray(0.5 * (r.standard_normal((taps, 2)) + 1j * r.standard_normal((taps, 2))))
+    xr, xi = np.asfortranarray(x.real.copy()), np.asfortranarray(x.imag.copy())
+    hs = [np.asfortranarray(v.copy()) for v in (h1.real, h1.imag, h2.real, h2.imag)]
+    dimY = 150 - taps + 1
+    yr, yi = np.zeros((dimY, 2), order="F"), np.zeros((dimY, 2), order="F")
+    emu.call("plx_easiadaptivefilter", _vp(xr), _vp(xi), 150, *[_vp(h) for h in hs], float(taps), 1e-2, 1.0, _vp(yr), _vp(yi))
+    y, g1, g2 = oracle.easiadaptivefilter(x, h1, h2, taps, 1e-2, 1)
+    np.testing.assert_allclose(yr + 1j * yi, y, atol=1e-12)
+    np.testing.assert_allclose(hs[0] + 1j * hs[1], g1, atol=1e-12)
+    np.testing.assert_allclose(hs[2] + 1j * hs[3], g2, atol=1e-12)
+
+
+def test_emu_poldemux_batch(emu, oracle):
+    """three frames, different convergence behaviour inside one wave"""
+    L, taps, mu = 128, 7, 1 / 300
+    xs = [_mixed_qpsk(L, 20, noise=0.0), _mixed_qpsk(L, 21, noise=0.15), _mixed_qpsk(L, 22, noise=0.02)]
+    xin = _il(np.stack([x.T for x in xs]))                     # [frame][2][L]
+    y = np.zeros_like(xin)
+    M = _il(np.tile(np.eye(2, dtype=complex).reshape(1, 4), (3, 1)))
+    h = np.zeros(3 * 4 * taps * 2); passes = np.zeros(3, np.int32)
+    R = np.array([1.0, 1.0])
+    emu.call("plx_poldemux_dev", 1, _vp(xin), _vp(y), L, 3, taps, mu, _vp(R), _vp(M), _vp(h), _vp(passes), None)
+    yy = y.view(np.complex128).reshape(3, 2, L)
+    hh = h.view(np.complex128).reshape(3, 2, 2, taps)
+    for f in range(3):
+        oy, h1, h2, n = oracle.cmapolardemux(xs[f], np.eye(2), taps, mu, R)
+        assert passes[f] == n
+        np.testing.assert_allclose(yy[f].T, oy, atol=1e-11)
+        np.testing.assert_allclose(hh[f, 0].T, h1, atol=1e-11)
+        np.testing.assert_allclose(hh[f, 1].T, h2, atol=1e-11)
+    assert len(set(passes.tolist())) > 1
+    # EASI driver
+    y2 = np.zeros_like(xin); p2 = np.zeros(3, np.int32)
+    emu.call("plx_poldemux_dev", 2, _vp(xin), _vp(y2), L, 3, 1, mu, None, _vp(M), None, _vp(p2), None)
+    for f in range(3):
+        oy, h1, h2, n = oracle.easipolardemux(xs[f], np.eye(2), mu)
+        assert p2[f] == n
+        np.testing.assert_allclose(y2.view(np.complex128).reshape(3, 2, L)[f].T, oy, atol=1e-11)
+
+
+def _dsp_params(**kw):
+    p = DspParams()
+    d = dict(workatbaudrate=0, applynlr=0, nlralpha=0.0, power_mw=2.0, applypol=0, polmethod=1, cma_mu=1 / 300,
+             cma_taps=7, cma_txpolars=2, cma_phizero=0.0, easi_mu=1 / 300, easi_txpolars=2, easi_phizero=0.0,
+             modorder=2, freqavg=20, phasavg=3, poworder=2)
+    d.update(kw)
+    for k, v in d.items():
+        setattr(p, k, v)
+    p.cma_R[0], p.cma_R[1] = 1.0, 1.0
+    return p
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(applypol=1, polmethod=1), dict(applypol=1, polmethod=3, freqavg=0),
+                                dict(applypol=1, polmethod=0, applynlr=1, nlralpha=0.05),
+                                dict(applypol=1, polmethod=2, easi_txpolars=1, workatbaudrate=1, poworder=4, freqavg=70)])
+def test_emu_dsp_chain(emu, oracle, kw):
+    L = 64
+    p = _dsp_params(**kw)
+    Lin = L if p.workatbaudrate else 2 * L
+    frames = 2
+    r = np.random.default_rng(7)
+    ins = []
+    for f in range(frames):
+        s = _mixed_qpsk(L, 30 + f, noise=0.03) * np.exp(1j * (2 * np.pi * 2 / L * np.arange(L) + 0.3))[:, None]
+        x = np.zeros((Lin, 2), complex)
+        x[:: (1 if p.workatbaudrate else 2)] = s * 4 * np.sqrt(2.0)
+        if not p.workatbaudrate:
+            x[1::2] = r.standard_normal((L, 2))
+        ins.append(x)
+    din = _il(np.stack([x.T for x in ins]))
+    plan = C.c_void_p()
+    emu.call("plx_dsp_create", C.byref(plan), Lin, 2, frames, C.byref(p))
+    Lout = emu.lib.plx_dsp_out_len(plan)
+    assert Lout == L
+    dout = np.zeros(frames * 2 * L * 2)
+    emu.call("plx_dsp_run_dev", plan, _vp(din), _vp(dout), frames, None)
+    emu.call("plx_dsp_destroy", plan)
+    out = dout.view(np.complex128).reshape(frames, 2, L)
+    names = {0: "singlepol", 1: "cma", 2: "easi", 3: "combo"}
+    op = oracle.dsp_params(power_mw=2.0, workatbaudrate=bool(p.workatbaudrate), applynlr=bool(p.applynlr), nlralpha=p.nlralpha,
+                           applypol=bool(p.applypol), polmethod=names[p.polmethod], cma_mu=p.cma_mu, cma_taps=p.cma_taps,
+                           cma_txpolars=p.cma_txpolars, easi_mu=p.easi_mu, easi_txpolars=p.easi_txpolars,
+                           modorder=p.modorder, freqavg=p.freqavg, phasavg=p.phasavg, poworder=p.poworder)
+    for f in range(frames):
+        ref = oracle.dsp_pdm_coh_qpsk(ins[f], op)
+        np.testing.assert_allclose(out[f].T, ref, atol=2e-10)
+    # decisions + error count
+    pat = oracle.samp2pat_coherent(np.angle(out[0].T))
+    dp = np.ascontiguousarray(pat.T.copy())
+    dp[0, :5] ^= 1
+    err = np.zeros((frames, 2), np.int64); hat = np.zeros((frames, 4, L), np.uint8)
+    emu.call("plx_decide_count_dev", _vp(dout), L, 2, frames, _vp(dp), _vp(hat), _vp(err), None)
+    np.testing.assert_array_equal(hat[0], pat.T)
+    assert err[0].tolist() == [5, 0]
+    assert err[1].sum() == int(np.sum(oracle.samp2pat_coherent(np.angle(out[1].T)).T != dp))
