@@ -38,6 +38,17 @@ __device__ __forceinline__ cplx cexpi(double a)
     return make_double2(c, s);
 }
 
+// Keep a batch of global loads issued back-to-back: an empty asm that "uses" the loaded value
+// stops the compiler from sinking each load next to its (conditional) consumer, where it would
+// be followed by s_waitcnt vmcnt(0) and serialise the batch.
+#ifdef PLX_EMU
+__device__ __forceinline__ void pin(cplx &) {}
+__device__ __forceinline__ void pin(double &) {}
+#else
+__device__ __forceinline__ void pin(cplx &v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
+__device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
+#endif
+
 // ---- error plumbing (host) ------------------------------------------------------
 void plx_set_error(const std::string &msg);
 #define PLX_HIP(call)                                                                          \

@@ -115,6 +115,171 @@ __device__ __forceinline__ void lds_fft_dit(cplx *s, int logM, int IS, int TS, i
     }
 }
 
+// ---------------------------------------------------------------------------------
+// Row transforms (point-fastest layout).  A plain in-place radix-4 pass has 64-byte lane
+// strides in its last two stages (4-way LDS bank conflicts, measured 51 % of the LDS cycles of
+// the SSFM row pass), so rows use a padded layout -- one 16-byte slot after every 16 points,
+// physical(i) = i + (i >> 4) -- and finish (DIF) / start (DIT) with a 16-point transform held
+// entirely in registers: lane u reads the 16 contiguous points of block u (lane stride 17
+// slots => conflict-free), does two radix-4 layers in registers and writes them back.  The
+// remaining stages (sub-block length >= 16) keep the radix-4 scheme on 16-aligned runs.
+__device__ __forceinline__ int row_phys(int i) { return i + (i >> 4); }
+__device__ __forceinline__ int row_pitch(int M) { return M + (M >> 4); }
+
+#define PLX_C8 0.92387953251128673848  /* cos(pi/8) */
+#define PLX_S8 0.38268343236508978178  /* sin(pi/8) */
+#define PLX_R2 0.70710678118654752440  /* sqrt(1/2) */
+
+// in-register 16-point DIF, natural in -> bit-reversed out (same placement rule as lds_fft_dif)
+__device__ __forceinline__ void r16_dif(cplx *x)
+{
+    const cplx w1 = make_double2(PLX_C8, -PLX_S8), w2 = make_double2(PLX_R2, -PLX_R2), w3 = make_double2(PLX_S8, -PLX_C8);
+    const cplx w6 = make_double2(-PLX_R2, -PLX_R2), w9 = make_double2(-PLX_C8, PLX_S8);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { // layer m = 16, q = 4
+        const cplx a0 = x[j], a1 = x[j + 4], a2 = x[j + 8], a3 = x[j + 12];
+        const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
+        cplx y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+        if (j == 1) { y1 = cmul(y1, w1); y2 = cmul(y2, w2); y3 = cmul(y3, w3); }
+        if (j == 2) { y1 = cmul(y1, w2); y2 = cmulni(y2); y3 = cmul(y3, w6); }
+        if (j == 3) { y1 = cmul(y1, w3); y2 = cmul(y2, w6); y3 = cmul(y3, w9); }
+        x[j] = cadd(t0, t2); x[j + 4] = y2; x[j + 8] = y1; x[j + 12] = y3;
+    }
+#pragma unroll
+    for (int b = 0; b < 16; b += 4) { // layer m = 4, q = 1
+        const cplx a0 = x[b], a1 = x[b + 1], a2 = x[b + 2], a3 = x[b + 3];
+        const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
+        x[b] = cadd(t0, t2); x[b + 1] = csub(t0, t2); x[b + 2] = cadd(t1, t3); x[b + 3] = csub(t1, t3);
+    }
+}
+
+// in-register 16-point unscaled inverse DIT, bit-reversed in -> natural out
+__device__ __forceinline__ void r16_dit(cplx *x)
+{
+    const cplx w1 = make_double2(PLX_C8, -PLX_S8), w2 = make_double2(PLX_R2, -PLX_R2), w3 = make_double2(PLX_S8, -PLX_C8);
+    const cplx w6 = make_double2(-PLX_R2, -PLX_R2), w9 = make_double2(-PLX_C8, PLX_S8);
+#pragma unroll
+    for (int b = 0; b < 16; b += 4) { // layer m = 4
+        const cplx c0 = x[b], c2 = x[b + 1], c1 = x[b + 2], c3 = x[b + 3];
+        const cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
+        x[b] = cadd(s0, s2); x[b + 1] = cadd(s1, s3); x[b + 2] = csub(s0, s2); x[b + 3] = csub(s1, s3);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) { // layer m = 16
+        cplx c0 = x[j], c2 = x[j + 4], c1 = x[j + 8], c3 = x[j + 12];
+        if (j == 1) { c1 = cmulc(c1, w1); c2 = cmulc(c2, w2); c3 = cmulc(c3, w3); }
+        if (j == 2) { c1 = cmulc(c1, w2); c2 = cmuli(c2); c3 = cmulc(c3, w6); }
+        if (j == 3) { c1 = cmulc(c1, w3); c2 = cmulc(c2, w6); c3 = cmulc(c3, w9); }
+        const cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
+        x[j] = cadd(s0, s2); x[j + 4] = cadd(s1, s3); x[j + 8] = csub(s0, s2); x[j + 12] = csub(s1, s3);
+    }
+}
+
+// T = 1<<logT padded rows of M = 1<<logM (M >= 16) points each, row t at s + t*row_pitch(M).
+__device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
+{
+    const int M = 1 << logM, halfM = M >> 1, T = 1 << logT, TSp = row_pitch(M);
+    int lm = logM;
+    if (logM & 1) { // radix-2 head (halfM >= 16)
+        const int total = T * halfM, hp = row_phys(halfM);
+        for (int b = tid; b < total; b += nthr) {
+            const int j = b & (halfM - 1), t = b >> (logM - 1);
+            cplx *p = s + t * TSp + row_phys(j);
+            const cplx a = p[0], c = p[hp];
+            p[0] = cadd(a, c);
+            p[hp] = cmul(csub(a, c), tw[j]);
+        }
+        __syncthreads();
+        lm--;
+    }
+    for (; lm >= 6; lm -= 2) { // radix-4 stages with q >= 16
+        const int lq = lm - 2, q = 1 << lq, sh = logM - lm, qs = row_phys(q);
+        const int total = T << (logM - 2);
+        for (int b = tid; b < total; b += nthr) {
+            const int bi = b & ((M >> 2) - 1), t = b >> (logM - 2);
+            const int j = bi & (q - 1);
+            const int base = ((bi >> lq) << lm) + j;
+            cplx *p = s + t * TSp + row_phys(base);
+            cplx a0 = p[0], a1 = p[qs], a2 = p[2 * qs], a3 = p[3 * qs];
+            cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
+            const int k = j << sh;
+            cplx y0 = cadd(t0, t2), y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+            if (k) {
+                y1 = cmul(y1, tw[k]);
+                y2 = cmul(y2, tw[2 * k]);
+                y3 = cmul(y3, tw3(tw, 3 * k, halfM));
+            }
+            p[0] = y0; p[qs] = y2; p[2 * qs] = y1; p[3 * qs] = y3;
+        }
+        __syncthreads();
+    }
+    { // 16-point tail in registers
+        const int total = T << (logM - 4);
+        for (int u = tid; u < total; u += nthr) {
+            const int blk = u & ((M >> 4) - 1), t = u >> (logM - 4);
+            cplx *p = s + t * TSp + blk * 17;
+            cplx x[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = p[k];
+            r16_dif(x);
+#pragma unroll
+            for (int k = 0; k < 16; k++) p[k] = x[k];
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
+{
+    const int M = 1 << logM, halfM = M >> 1, T = 1 << logT, TSp = row_pitch(M);
+    {
+        const int total = T << (logM - 4);
+        for (int u = tid; u < total; u += nthr) {
+            const int blk = u & ((M >> 4) - 1), t = u >> (logM - 4);
+            cplx *p = s + t * TSp + blk * 17;
+            cplx x[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = p[k];
+            r16_dit(x);
+#pragma unroll
+            for (int k = 0; k < 16; k++) p[k] = x[k];
+        }
+        __syncthreads();
+    }
+    const int lmax = (logM & 1) ? logM - 1 : logM;
+    for (int lm = 6; lm <= lmax; lm += 2) {
+        const int lq = lm - 2, q = 1 << lq, sh = logM - lm, qs = row_phys(q);
+        const int total = T << (logM - 2);
+        for (int b = tid; b < total; b += nthr) {
+            const int bi = b & ((M >> 2) - 1), t = b >> (logM - 2);
+            const int j = bi & (q - 1);
+            const int base = ((bi >> lq) << lm) + j;
+            cplx *p = s + t * TSp + row_phys(base);
+            cplx c0 = p[0], c2 = p[qs], c1 = p[2 * qs], c3 = p[3 * qs];
+            const int k = j << sh;
+            if (k) {
+                c1 = cmulc(c1, tw[k]);
+                c2 = cmulc(c2, tw[2 * k]);
+                c3 = cmulc(c3, tw3(tw, 3 * k, halfM));
+            }
+            cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
+            p[0] = cadd(s0, s2); p[qs] = cadd(s1, s3); p[2 * qs] = csub(s0, s2); p[3 * qs] = csub(s1, s3);
+        }
+        __syncthreads();
+    }
+    if (logM & 1) {
+        const int total = T * halfM, hp = row_phys(halfM);
+        for (int b = tid; b < total; b += nthr) {
+            const int j = b & (halfM - 1), t = b >> (logM - 1);
+            cplx *p = s + t * TSp + row_phys(j);
+            const cplx a = p[0], c = cmulc(p[hp], tw[j]);
+            p[0] = cadd(a, c);
+            p[hp] = csub(a, c);
+        }
+        __syncthreads();
+    }
+}
+
 // stage the half table W_M^k (k < M/2) from global memory into LDS
 __device__ __forceinline__ void lds_load_twiddles(cplx *dst, const cplx *__restrict__ src, int halfM, int tid, int nthr)
 {

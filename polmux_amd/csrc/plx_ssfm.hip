@@ -26,6 +26,7 @@
 #include "plx_fft.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -55,7 +56,7 @@ struct SsfmArgs {
     FrameCtl *ctl;
     unsigned long long *umax;      // [F][nfc] bit pattern of max |u|^2 (>= 0)
     int *ndone;
-    int p1, p2, nfc, dual, W, logW, R, logR;
+    int p1, p2, nfc, dual, W, logW, T, logT, R, logR; // column tile: N1 rows x T complex (T = W*npol)
     int spm, xpm, manakov, pmd, nplates, brf_per_frame;
     double alphalin, Lf, dzmax, dphimax, lcorr, invN;
 };
@@ -67,6 +68,29 @@ __device__ __forceinline__ double wave_max(double v)
         v = o > v ? o : v;
     }
     return v;
+}
+
+// exp(i a) for the Kerr step.  The step controller bounds |a| by dphimax (fiber.m:699), a few
+// mrad, so the Taylor branch (|a| < 2^-4, truncation < 1e-25, ~1 ulp) is the one that runs;
+// larger arguments ('--s-' exact single step, fiber.m:172-174) take the full-range sincos.
+__device__ __forceinline__ void sincos_small(double a, double *s, double *c)
+{
+    if (fabs(a) < 0.0625) {
+        const double z = a * a;
+        double ps = fma(z, -1.0 / 39916800.0, 1.0 / 362880.0);
+        ps = fma(z, ps, -1.0 / 5040.0);
+        ps = fma(z, ps, 1.0 / 120.0);
+        ps = fma(z, ps, -1.0 / 6.0);
+        *s = fma(a * z, ps, a);
+        double pc = fma(z, 1.0 / 479001600.0, -1.0 / 3628800.0);
+        pc = fma(z, pc, 1.0 / 40320.0);
+        pc = fma(z, pc, -1.0 / 720.0);
+        pc = fma(z, pc, 1.0 / 24.0);
+        pc = fma(z, pc, -0.5);
+        *c = fma(z, pc, 1.0);
+    } else {
+        sincos(a, s, c);
+    }
 }
 
 // block-wide max -> one atomicMax.  red: LDS scratch of >= 16 doubles.
@@ -203,8 +227,12 @@ __global__ __launch_bounds__(256) void k_rowsum(SsfmArgs a)
 
 // ------------------------------------------------------------ pass 1: columns ---
 // Kerr step (matrix_nl_step :832-852 / nl_step :792-804) fused into the load of
-// the forward column transform.  Tile = N1 rows x 16 complex (dual: 8 columns of
-// ux | 8 of uy; scalar: 16 columns), i.e. 256 contiguous bytes of LDS per row.
+// the forward column transform.  Tile = N1 rows x T complex (dual: W columns of ux |
+// W of uy; scalar: W columns): T*16 B contiguous bytes of LDS per row, so the T
+// interleaved transforms are read conflict-free.  Global loads are issued in
+// batches of COL_CH per thread before any arithmetic, to keep >= 64 KiB in flight
+// per CU.
+#define COL_CH 4
 __global__ __launch_bounds__(256) void k_col_fwd(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
@@ -212,126 +240,162 @@ __global__ __launch_bounds__(256) void k_col_fwd(SsfmArgs a)
     const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
     const FrameCtl *ctl = a.ctl + f;
     if (ctl->done) return;
-    const int N1 = 1 << a.p1, N2 = 1 << a.p2;
+    const int N1 = 1 << a.p1, N2 = 1 << a.p2, T = a.T, W = a.W;
     cplx *s = (cplx *)lds;
-    cplx *tw = s + (size_t)N1 * 16;
+    cplx *tw = s + ((size_t)N1 << a.logT);
     lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, nthr);
     const size_t base = (size_t)fc << (a.p1 + a.p2);
-    const int col0 = blockIdx.x * a.W;
+    const int col0 = blockIdx.x * W;
     const double leff = ctl->leff;
-    const double gamleff = a.gam[c] * leff;
+    const double gam = a.gam[c], gamleff = gam * leff;
     const int nel = N1 << a.logW;
     if (a.dual) {
-        for (int e = tid; e < nel; e += nthr) {
-            const int row = e >> a.logW, col = e & (a.W - 1);
-            const size_t g = base + (size_t)row * N2 + col0 + col;
-            cplx x = a.ux[g], y = a.uy[g];
-            if (a.spm) {
-                const double P = x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y; // :834-835
-                const cplx nl = cexpi(-gamleff * P);                              // :837
-                x = cmul(x, nl);
-                y = cmul(y, nl);
-                if (!a.manakov) { // CNLSE rotation :842-850
-                    const double s3 = 2 * (x.x * y.y - x.y * y.x);
-                    double sp, cp;
-                    sincos(gamleff * s3 / 3, &sp, &cp);
-                    const cplx xx = make_double2(cp * x.x + sp * y.x, cp * x.y + sp * y.y);
-                    const cplx yy = make_double2(cp * y.x - sp * x.x, cp * y.y - sp * x.y);
-                    x = xx; y = yy;
-                }
+        for (int e0 = tid; e0 < nel; e0 += nthr * COL_CH) {
+            cplx xv[COL_CH], yv[COL_CH];
+#pragma unroll
+            for (int k = 0; k < COL_CH; k++) {
+                const int e = min(e0 + k * nthr, nel - 1);
+                const size_t g = base + (size_t)(e >> a.logW) * N2 + col0 + (e & (W - 1));
+                xv[k] = a.ux[g]; yv[k] = a.uy[g];
             }
-            s[row * 16 + col] = x;
-            s[row * 16 + 8 + col] = y;
+#pragma unroll
+            for (int k = 0; k < COL_CH; k++) { pin(xv[k]); pin(yv[k]); }
+#pragma unroll
+            for (int k = 0; k < COL_CH; k++) {
+                const int e = e0 + k * nthr;
+                if (e >= nel) continue;
+                cplx x = xv[k], y = yv[k];
+                if (a.spm) {
+                    const double P = x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y; // :834-835
+                    double sn, cs;
+                    sincos_small(-gamleff * P, &sn, &cs);                             // :837
+                    const cplx nl = make_double2(cs, sn);
+                    x = cmul(x, nl);
+                    y = cmul(y, nl);
+                    if (!a.manakov) { // CNLSE rotation :842-850
+                        const double s3 = 2 * (x.x * y.y - x.y * y.x);
+                        double sp, cp;
+                        sincos_small(gamleff * s3 / 3, &sp, &cp);
+                        const cplx xx = make_double2(cp * x.x + sp * y.x, cp * x.y + sp * y.y);
+                        const cplx yy = make_double2(cp * y.x - sp * x.x, cp * y.y - sp * x.y);
+                        x = xx; y = yy;
+                    }
+                }
+                const int row = e >> a.logW, col = e & (W - 1);
+                s[(row << a.logT) + col] = x;
+                s[(row << a.logT) + W + col] = y;
+            }
         }
     } else {
         const bool active = a.spm || a.xpm; // :800-802
-        for (int e = tid; e < nel; e += nthr) {
-            const int row = e >> a.logW, col = e & (a.W - 1);
-            const size_t off = (size_t)row * N2 + col0 + col;
-            cplx x = a.ux[base + off];
-            if (active) {
-                double pw = x.x * x.x + x.y * x.y; // :792
-                if (a.xpm) {
-                    const double tot = a.psum[((size_t)f << (a.p1 + a.p2)) + off];
-                    pw = a.spm ? 2 * tot - pw : 2 * (tot - pw); // :795,797
-                }
-                x = cmul(x, cexpi(-a.gam[c] * pw * leff)); // :804
+        for (int e0 = tid; e0 < nel; e0 += nthr * COL_CH) {
+            cplx xv[COL_CH];
+            double pv[COL_CH];
+#pragma unroll
+            for (int k = 0; k < COL_CH; k++) {
+                const int e = min(e0 + k * nthr, nel - 1);
+                const size_t off = (size_t)(e >> a.logW) * N2 + col0 + (e & (W - 1));
+                xv[k] = a.ux[base + off];
+                pv[k] = a.xpm ? a.psum[((size_t)f << (a.p1 + a.p2)) + off] : 0.0;
             }
-            s[row * 16 + col] = x;
+#pragma unroll
+            for (int k = 0; k < COL_CH; k++) { pin(xv[k]); pin(pv[k]); }
+#pragma unroll
+            for (int k = 0; k < COL_CH; k++) {
+                const int e = e0 + k * nthr;
+                if (e >= nel) continue;
+                cplx x = xv[k];
+                if (active) {
+                    double pw = x.x * x.x + x.y * x.y; // :792
+                    if (a.xpm) pw = a.spm ? 2 * pv[k] - pw : 2 * (pv[k] - pw); // :795,797
+                    double sn, cs;
+                    sincos_small(-gam * pw * leff, &sn, &cs); // :804
+                    x = cmul(x, make_double2(cs, sn));
+                }
+                s[((e >> a.logW) << a.logT) + (e & (W - 1))] = x;
+            }
         }
     }
     __syncthreads();
-    lds_fft_dif(s, a.p1, 16, 1, 4, tw, tid, nthr, true);
-    if (a.dual) {
-        for (int e = tid; e < nel; e += nthr) {
-            const int row = e >> a.logW, col = e & (a.W - 1);
-            const size_t g = base + (size_t)row * N2 + col0 + col;
-            a.ux[g] = s[row * 16 + col];
-            a.uy[g] = s[row * 16 + 8 + col];
-        }
-    } else {
-        for (int e = tid; e < nel; e += nthr) {
-            const int row = e >> a.logW, col = e & (a.W - 1);
-            a.ux[base + (size_t)row * N2 + col0 + col] = s[row * 16 + col];
-        }
+    lds_fft_dif(s, a.p1, T, 1, a.logT, tw, tid, nthr, true);
+    for (int e = tid; e < nel; e += nthr) {
+        const int row = e >> a.logW, col = e & (W - 1);
+        const size_t g = base + (size_t)row * N2 + col0 + col;
+        a.ux[g] = s[(row << a.logT) + col];
+        if (a.dual) a.uy[g] = s[(row << a.logT) + W + col];
     }
 }
 
 // --------------------------------------------------------------- pass 2: rows ---
 // Second half of the forward transform, the linear operator of the step
 // (lin_step :771-773 / matrix_step :907-933) and the first half of the inverse
-// transform, all on one LDS-resident row set.
-__global__ __launch_bounds__(256) void k_row(SsfmArgs a)
+// transform, all on one LDS-resident row set (padded layout, see plx_fft.h).
+#define ROW_THREADS 128
+#define ROW_CH 4
+__global__ __launch_bounds__(ROW_THREADS) void k_row(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
     const FrameCtl *ctl = a.ctl + f;
     if (ctl->done) return;
-    const int N2 = 1 << a.p2, R = a.R;
-    cplx *s = (cplx *)lds;                       // [npol*R][N2]
-    cplx *tw = s + (size_t)(a.dual ? 2 : 1) * R * N2;
+    const int N2 = 1 << a.p2, R = a.R, TSp = row_pitch(N2);
+    cplx *s = (cplx *)lds;                       // [npol*R][TSp]
+    cplx *tw = s + (size_t)(a.dual ? 2 : 1) * R * TSp;
     lds_load_twiddles(tw, a.tw2, N2 >> 1, tid, nthr);
     const size_t N = (size_t)1 << (a.p1 + a.p2);
     const size_t base = (size_t)fc * N;
     const int j0 = blockIdx.x * R;
     const int nel = R << a.p2;
-    for (int e = tid; e < nel; e += nthr) {
-        const int r = e >> a.p2, i = e & (N2 - 1);
-        const size_t fi = (size_t)(j0 + r) * N2 + i;
-        const cplx t = a.tpass[fi];
-        s[r * N2 + i] = cmul(a.ux[base + fi], t);
-        if (a.dual) s[(R + r) * N2 + i] = cmul(a.uy[base + fi], t);
+    const cplx *uyp = a.dual ? a.uy : a.ux;
+    const size_t rowbase = (size_t)j0 * N2;      // the R rows of this workgroup are contiguous
+    for (int e0 = tid; e0 < nel; e0 += nthr * ROW_CH) {
+        cplx tv[ROW_CH], xv[ROW_CH], yv[ROW_CH];
+#pragma unroll
+        for (int k = 0; k < ROW_CH; k++) {
+            const int e = min(e0 + k * nthr, nel - 1);
+            tv[k] = a.tpass[rowbase + e];
+            xv[k] = a.ux[base + rowbase + e];
+            yv[k] = uyp[base + rowbase + e];
+        }
+#pragma unroll
+        for (int k = 0; k < ROW_CH; k++) { pin(tv[k]); pin(xv[k]); pin(yv[k]); }
+#pragma unroll
+        for (int k = 0; k < ROW_CH; k++) {
+            const int e = e0 + k * nthr;
+            if (e < nel) {
+                const int r = e >> a.p2, i = e & (N2 - 1);
+                s[r * TSp + row_phys(i)] = cmul(xv[k], tv[k]);
+                if (a.dual) s[(R + r) * TSp + row_phys(i)] = cmul(yv[k], tv[k]);
+            }
+        }
     }
     __syncthreads();
-    lds_fft_dif(s, a.p2, 1, N2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr, false);
+    row_fft_dif(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     const double cur = ctl->cur;
-    const double *bt = a.betat_p + (size_t)c * N;
+    const double *bt = a.betat_p + (size_t)c * N + rowbase;
     if (!a.dual) {
         for (int e = tid; e < nel; e += nthr) { // Hf = fastexp(-betat*dz) :771
-            const int r = e >> a.p2, i = e & (N2 - 1);
-            const size_t fi = (size_t)(j0 + r) * N2 + i;
-            s[r * N2 + i] = cmul(s[r * N2 + i], cexpi(-(bt[fi] * cur)));
+            const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+            s[o] = cmul(s[o], cexpi(-(bt[e] * cur)));
         }
     } else if (!a.pmd) {
         // zero birefringence, one trunk (fiber.m:291-297): matR = I, deltabeta = 0
         for (int e = tid; e < nel; e += nthr) {
-            const int r = e >> a.p2, i = e & (N2 - 1);
-            const size_t fi = (size_t)(j0 + r) * N2 + i;
-            const cplx h = cexpi(-(bt[fi] * cur));
-            s[r * N2 + i] = cmul(h, s[r * N2 + i]);
-            s[(R + r) * N2 + i] = cmul(h, s[(R + r) * N2 + i]);
+            const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+            const cplx h = cexpi(-(bt[e] * cur));
+            s[o] = cmul(h, s[o]);
+            s[o + R * TSp] = cmul(h, s[o + R * TSp]);
         }
     } else {
-        const double *d1 = a.db1_p + (size_t)c * N;
+        const double *d1 = a.db1_p + (size_t)c * N + rowbase;
         const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * 9 : 0);
         const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem; // plate of piece k: n0+k (1-based) :908
         const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last, lcorr = a.lcorr;
         for (int e = tid; e < nel; e += nthr) {
-            const int r = e >> a.p2, i = e & (N2 - 1);
-            const size_t fi = (size_t)(j0 + r) * N2 + i;
-            const double btf = bt[fi], d1f = d1[fi];
-            cplx x = s[r * N2 + i], y = s[(R + r) * N2 + i];
+            const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+            const double btf = bt[e], d1f = d1[e];
+            cplx x = s[o], y = s[o + R * TSp];
             for (int k = 1; k <= ntrunk; k++) {
                 int plate = n0 + k - 1; // the reference indexes brf.theta(n) unchecked; stay in bounds
                 plate = plate < 0 ? 0 : (plate >= a.nplates ? a.nplates - 1 : plate);
@@ -348,18 +412,17 @@ __global__ __launch_bounds__(256) void k_row(SsfmArgs a)
                 x = cadd(cmul(R11, uux), cmul(R12, uuy));                      // :931
                 y = cadd(cmul(R21, uux), cmul(R22, uuy));                      // :932
             }
-            s[r * N2 + i] = x;
-            s[(R + r) * N2 + i] = y;
+            s[o] = x;
+            s[o + R * TSp] = y;
         }
     }
     __syncthreads();
-    lds_fft_dit(s, a.p2, 1, N2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr, false);
+    row_fft_dit(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     for (int e = tid; e < nel; e += nthr) {
-        const int r = e >> a.p2, i = e & (N2 - 1);
-        const size_t fi = (size_t)(j0 + r) * N2 + i;
-        const cplx t = a.tpass[fi];
-        a.ux[base + fi] = cmulc(s[r * N2 + i], t);
-        if (a.dual) a.uy[base + fi] = cmulc(s[(R + r) * N2 + i], t);
+        const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+        const cplx t = a.tpass[rowbase + e];
+        a.ux[base + rowbase + e] = cmulc(s[o], t);
+        if (a.dual) a.uy[base + rowbase + e] = cmulc(s[o + R * TSp], t);
     }
 }
 
@@ -373,32 +436,48 @@ __global__ __launch_bounds__(256) void k_col_inv(SsfmArgs a)
     const int fc = blockIdx.y, f = fc / a.nfc;
     const FrameCtl *ctl = a.ctl + f;
     if (ctl->done) return;
-    const int N1 = 1 << a.p1, N2 = 1 << a.p2;
+    const int N1 = 1 << a.p1, N2 = 1 << a.p2, T = a.T, W = a.W;
     cplx *s = (cplx *)lds;
-    cplx *tw = s + (size_t)N1 * 16;
+    cplx *tw = s + ((size_t)N1 << a.logT);
     double *red = (double *)(tw + (N1 >> 1));
     lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, nthr);
     const size_t base = (size_t)fc << (a.p1 + a.p2);
-    const int col0 = blockIdx.x * a.W;
+    const int col0 = blockIdx.x * W;
     const int nel = N1 << a.logW;
-    for (int e = tid; e < nel; e += nthr) {
-        const int row = e >> a.logW, col = e & (a.W - 1);
-        const size_t g = base + (size_t)row * N2 + col0 + col;
-        s[row * 16 + col] = a.ux[g];
-        if (a.dual) s[row * 16 + 8 + col] = a.uy[g];
+    const cplx *uyp = a.dual ? a.uy : a.ux; // scalar plans read ux twice (second copy unused)
+    for (int e0 = tid; e0 < nel; e0 += nthr * COL_CH) {
+        cplx xv[COL_CH], yv[COL_CH];
+#pragma unroll
+        for (int k = 0; k < COL_CH; k++) {
+            const int e = min(e0 + k * nthr, nel - 1); // clamped duplicate loads keep the batch branch-free
+            const size_t g = base + (size_t)(e >> a.logW) * N2 + col0 + (e & (W - 1));
+            xv[k] = a.ux[g];
+            yv[k] = uyp[g];
+        }
+#pragma unroll
+        for (int k = 0; k < COL_CH; k++) { pin(xv[k]); pin(yv[k]); }
+#pragma unroll
+        for (int k = 0; k < COL_CH; k++) {
+            const int e = e0 + k * nthr;
+            if (e < nel) {
+                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
+                s[o] = xv[k];
+                if (a.dual) s[o + W] = yv[k];
+            }
+        }
     }
     __syncthreads();
-    lds_fft_dit(s, a.p1, 16, 1, 4, tw, tid, nthr, true);
+    lds_fft_dit(s, a.p1, T, 1, a.logT, tw, tid, nthr, true);
     const double sc = ctl->att * a.invN;
     double m = 0;
     for (int e = tid; e < nel; e += nthr) {
-        const int row = e >> a.logW, col = e & (a.W - 1);
+        const int row = e >> a.logW, col = e & (W - 1);
         const size_t g = base + (size_t)row * N2 + col0 + col;
-        cplx x = cscale(s[row * 16 + col], sc);
+        cplx x = cscale(s[(row << a.logT) + col], sc);
         double p = x.x * x.x + x.y * x.y;
         a.ux[g] = x;
         if (a.dual) {
-            cplx y = cscale(s[row * 16 + 8 + col], sc);
+            cplx y = cscale(s[(row << a.logT) + W + col], sc);
             p = p + y.x * y.x;
             p = p + y.y * y.y;
             a.uy[g] = y;
@@ -481,20 +560,40 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     plx_ssfm *P = new plx_ssfm();
     P->d = *desc;
     P->p = p;
-    P->p1 = (p + 1) / 2;
-    if (P->p1 > 9) P->p1 = 9; // column tile of 512 rows x 256 B = 128 KiB of LDS
+    // Four-step split N = N1 x N2.  The column tile is N1 rows x T complex (T = W columns per
+    // polarisation x npol) and is kept at <= 64 KiB so two workgroups share a CU; a wider, shorter
+    // tile means longer contiguous row segments in HBM (W*16 B per polarisation).  The row pass
+    // holds npol x N2 complex (+ twiddles) in LDS, which bounds N2 at 2048 for dual-pol frames.
+    {
+        const int npol = desc->dual_pol ? 2 : 1;
+        int logW = desc->dual_pol ? 3 : 4;                   // 8 (dual) / 16 (scalar) columns per tile (measured best)
+        int p1 = 12 - (logW + (npol == 2 ? 1 : 0));          // N1 * T = 4096 complex = 64 KiB
+        const int p2max = 11;
+        if (p - p1 > p2max) p1 = p - p2max;                  // large frames: taller tiles instead
+        if (p1 > p - 4) p1 = p - 4;                          // keep N2 >= 16
+        if (p1 < 2) p1 = 2;
+        while ((((size_t)1 << p1) << (logW + (npol == 2 ? 1 : 0))) * sizeof(cplx) > 128 * 1024 && logW > 3) logW--;
+        if (const char *e = getenv("PLX_SSFM_P1")) { int v = atoi(e); if (v >= 2 && v <= p - 4) p1 = v; }
+        if (const char *e = getenv("PLX_SSFM_LOGW")) { int v = atoi(e); if (v >= 2 && v <= 6) logW = v; }
+        while (((int64_t)1 << (p - p1)) < ((int64_t)1 << logW)) logW--;  // tile not wider than a row
+        P->p1 = p1;
+        P->a.logW = logW;
+    }
     P->p2 = p - P->p1;
     P->N = (size_t)N;
     const int N1 = 1 << P->p1, N2 = 1 << P->p2;
     const int nfc = desc->nfc, F = desc->max_frames;
     SsfmArgs &a = P->a;
+    const int keep_logW = P->a.logW;
     std::memset(&a, 0, sizeof(a));
     a.p1 = P->p1; a.p2 = P->p2; a.nfc = nfc; a.dual = desc->dual_pol ? 1 : 0;
-    a.W = a.dual ? 8 : 16; a.logW = a.dual ? 3 : 4;
-    // rows per workgroup in the row pass: keep >= 256 butterflies per radix-4 stage
+    a.logW = keep_logW; a.W = 1 << a.logW;
+    a.logT = a.logW + (a.dual ? 1 : 0); a.T = 1 << a.logT;
+    // rows per workgroup in the row pass: >= one 16-point register block per thread
     {
         int R = 1, npol = a.dual ? 2 : 1;
-        while (R * npol * (N2 / 4) < 256 && R * 2 <= N1) R *= 2;
+        while (R * npol * (N2 / 16) < ROW_THREADS / 2 && R * 2 <= N1) R *= 2;   // measured: 2 rows x 2 pols at N2 = 256
+        if (const char *e = getenv("PLX_SSFM_ROWS")) { int v = atoi(e); if (v >= 1 && v <= N1 && (v & (v - 1)) == 0) R = v; }
         a.R = R; a.logR = ilog2(R);
     }
     a.spm = desc->fls[2]; a.xpm = desc->fls[3]; a.manakov = desc->manakov ? 1 : 0; a.pmd = desc->fls[1] ? 1 : 0;
@@ -553,8 +652,8 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     a.gam = P->d_gam; a.ctl = P->d_ctl; a.umax = P->d_umax; a.ndone = P->d_ndone; a.psum = P->d_psum;
     P->h_ctl.resize(F);
 
-    P->lds_col = ((size_t)N1 * 16 + N1 / 2) * sizeof(cplx) + 16 * sizeof(double);
-    P->lds_row = ((size_t)(a.dual ? 2 : 1) * a.R * N2 + N2 / 2) * sizeof(cplx);
+    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 16 * sizeof(double);
+    P->lds_row = ((size_t)(a.dual ? 2 : 1) * a.R * (N2 + N2 / 16) + N2 / 2) * sizeof(cplx);
     if (allow_lds(k_col_fwd, P->lds_col) != hipSuccess || allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
         allow_lds(k_row, P->lds_row) != hipSuccess) {
         free_plan(P);
@@ -625,7 +724,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
         if (gx > 64) gx = 64;
         PLX_LAUNCH(k_umax, dim3(gx, FC), dim3(256), 16 * sizeof(double), st, a);
     }
-    const dim3 gcol((unsigned)(N2 / a.W), FC), grow((unsigned)(N1 / a.R), FC), blk(256);
+    const dim3 gcol((unsigned)(N2 / a.W), FC), grow((unsigned)(N1 / a.R), FC), blk(256), brow(ROW_THREADS);
     const dim3 gctl((unsigned)((nframes + 63) / 64)), bctl(64);
     P->row_launches = 0;
     // Data-dependent trip count (fiber.m:518): steps are enqueued in chunks; the
@@ -644,7 +743,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
                 PLX_LAUNCH(k_rowsum, dim3(gx, (unsigned)nframes), blk, 0, st, a);
             }
             PLX_LAUNCH(k_col_fwd, gcol, blk, P->lds_col, st, a);
-            PLX_LAUNCH(k_row, grow, blk, P->lds_row, st, a);
+            PLX_LAUNCH(k_row, grow, brow, P->lds_row, st, a);
             PLX_LAUNCH(k_col_inv, gcol, blk, P->lds_col, st, a);
             P->row_launches++;
         }

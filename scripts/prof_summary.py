@@ -1,0 +1,15 @@
+"""Summarise a rocprofv3 kernel_trace.csv: per-kernel totals, and for the SSFM kernels the average over
+ACTIVE launches (launches longer than 20 us; the chunked step loop also issues no-op launches)."""
+import csv, sys, collections
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.defaultdict(list)
+for r in rows:
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
+    name = name.split("(")[0][:48]
+    agg[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+tot = sum(sum(v) for v in agg.values())
+print("| kernel | launches | total ms | active launches | avg active us | % of GPU time |")
+print("|---|---|---|---|---|---|")
+for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+    act = [x for x in v if x > 20.0] or v
+    print("| `%s` | %d | %.2f | %d | %.1f | %.1f |" % (k, len(v), sum(v) / 1e3, len(act), sum(act) / len(act), 100 * sum(v) / tot))

@@ -115,6 +115,8 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
     return reinterpret_cast<std::atomic<unsigned long long> *>(p)->fetch_add(v);
 }
 // sincos(): glibc's (declared by <cmath> under _GNU_SOURCE)
+static inline int min(int a, int b) { return a < b ? a : b; }
+static inline int max(int a, int b) { return a > b ? a : b; }
 static inline long long __double_as_longlong(double d) { long long r; std::memcpy(&r, &d, 8); return r; }
 static inline double __longlong_as_double(long long l) { double r; std::memcpy(&r, &l, 8); return r; }
 
