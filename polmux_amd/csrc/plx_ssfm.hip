@@ -58,6 +58,8 @@ struct SsfmArgs {
     int *ndone;
     int p1, p2, nfc, dual, W, logW, T, logT, R, logR; // column tile: N1 rows x T complex (T = W*npol)
     int spm, xpm, manakov, pmd, nplates, brf_per_frame;
+    int nframes; // frames of the current propagate call (kernels return at once when all are done)
+    int dbg; // timing experiments only (PLX_SSFM_DBG): 1 skip column FFTs, 2 skip row FFTs, 4 skip Kerr math, 8 skip exp(-i beta dz)
     double alphalin, Lf, dzmax, dphimax, lcorr, invN;
 };
 
@@ -236,6 +238,7 @@ __global__ __launch_bounds__(256) void k_rowsum(SsfmArgs a)
 __global__ __launch_bounds__(256) void k_col_fwd(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
+    if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
     const FrameCtl *ctl = a.ctl + f;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256) void k_col_fwd(SsfmArgs a)
                 const int e = e0 + k * nthr;
                 if (e >= nel) continue;
                 cplx x = xv[k], y = yv[k];
-                if (a.spm) {
+                if (a.spm && !(a.dbg & 4)) {
                     const double P = x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y; // :834-835
                     double sn, cs;
                     sincos_small(-gamleff * P, &sn, &cs);                             // :837
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(256) void k_col_fwd(SsfmArgs a)
         }
     }
     __syncthreads();
-    lds_fft_dif(s, a.p1, T, 1, a.logT, tw, tid, nthr, true);
+    if (!(a.dbg & 1)) lds_fft_dif(s, a.p1, T, 1, a.logT, tw, tid, nthr, true);
     for (int e = tid; e < nel; e += nthr) {
         const int row = e >> a.logW, col = e & (W - 1);
         const size_t g = base + (size_t)row * N2 + col0 + col;
@@ -335,6 +338,7 @@ __global__ __launch_bounds__(256) void k_col_fwd(SsfmArgs a)
 __global__ __launch_bounds__(ROW_THREADS) void k_row(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
+    if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
     const FrameCtl *ctl = a.ctl + f;
@@ -371,7 +375,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row(SsfmArgs a)
         }
     }
     __syncthreads();
-    row_fft_dif(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
+    if (!(a.dbg & 2)) row_fft_dif(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     const double cur = ctl->cur;
     const double *bt = a.betat_p + (size_t)c * N + rowbase;
     if (!a.dual) {
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row(SsfmArgs a)
         // zero birefringence, one trunk (fiber.m:291-297): matR = I, deltabeta = 0
         for (int e = tid; e < nel; e += nthr) {
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-            const cplx h = cexpi(-(bt[e] * cur));
+            const cplx h = (a.dbg & 8) ? make_double2(1.0, bt[e]) : cexpi(-(bt[e] * cur));
             s[o] = cmul(h, s[o]);
             s[o + R * TSp] = cmul(h, s[o + R * TSp]);
         }
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row(SsfmArgs a)
         }
     }
     __syncthreads();
-    row_fft_dit(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
+    if (!(a.dbg & 2)) row_fft_dit(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     for (int e = tid; e < nel; e += nthr) {
         const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
         const cplx t = a.tpass[rowbase + e];
@@ -432,6 +436,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row(SsfmArgs a)
 __global__ __launch_bounds__(256) void k_col_inv(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
+    if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int fc = blockIdx.y, f = fc / a.nfc;
     const FrameCtl *ctl = a.ctl + f;
@@ -467,7 +472,7 @@ __global__ __launch_bounds__(256) void k_col_inv(SsfmArgs a)
         }
     }
     __syncthreads();
-    lds_fft_dit(s, a.p1, T, 1, a.logT, tw, tid, nthr, true);
+    if (!(a.dbg & 1)) lds_fft_dit(s, a.p1, T, 1, a.logT, tw, tid, nthr, true);
     const double sc = ctl->att * a.invN;
     double m = 0;
     for (int e = tid; e < nel; e += nthr) {
@@ -487,6 +492,270 @@ __global__ __launch_bounds__(256) void k_col_inv(SsfmArgs a)
     block_atomic_max(m, red, a.umax + fc, tid, nthr);
 }
 
+// ============================================================================
+// Persistent, software-pipelined forms of the three sweeps (dual-polarisation plans).
+// A workgroup walks over tiles (tile index += gridDim.x); while it transforms tile k out
+// of LDS, the global loads of tile k+1 are already in flight into registers (PF complex
+// per polarisation per thread), so HBM streaming overlaps the LDS/VALU phases instead of
+// alternating with them.  Chosen when the tile size matches PF x blockDim exactly; the
+// kernels above stay as the general form.
+template <int PF> __global__ __launch_bounds__(256) void k_col_fwd_p(SsfmArgs a, int tiles_x, int total)
+{
+    PLX_DYN_LDS(lds);
+    if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
+    const int tid = threadIdx.x;
+    const int N1 = 1 << a.p1, N2 = 1 << a.p2, T = a.T, W = a.W;
+    cplx *s = (cplx *)lds;
+    cplx *tw = s + ((size_t)N1 << a.logT);
+    lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, 256);
+    cplx xv[PF], yv[PF];
+    int tl = blockIdx.x;
+    bool have = false;
+    size_t gbase = 0;
+    auto issue = [&](int t) {
+        const int fc = t / tiles_x, bx = t - fc * tiles_x, f = fc / a.nfc;
+        have = !a.ctl[f].done;
+        gbase = ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * W;
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int e = tid + k * 256;
+                const size_t g = gbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
+                xv[k] = a.ux[g]; yv[k] = a.uy[g];
+            }
+        }
+    };
+    if (tl < total) issue(tl);
+    while (tl < total) {
+        const bool cur = have;
+        const size_t cbase = gbase;
+        if (cur) {
+            const int fc = tl / tiles_x, f = fc / a.nfc, c = fc - f * a.nfc;
+            const double gamleff = a.gam[c] * a.ctl[f].leff;
+#pragma unroll
+            for (int k = 0; k < PF; k++) { pin(xv[k]); pin(yv[k]); }
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                cplx x = xv[k], y = yv[k];
+                if (a.spm && !(a.dbg & 4)) {
+                    const double P = x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y; // :834-835
+                    double sn, cs;
+                    sincos_small(-gamleff * P, &sn, &cs);                             // :837
+                    const cplx nl = make_double2(cs, sn);
+                    x = cmul(x, nl);
+                    y = cmul(y, nl);
+                    if (!a.manakov) { // CNLSE rotation :842-850
+                        const double s3 = 2 * (x.x * y.y - x.y * y.x);
+                        double sp, cp;
+                        sincos_small(gamleff * s3 / 3, &sp, &cp);
+                        const cplx xx = make_double2(cp * x.x + sp * y.x, cp * x.y + sp * y.y);
+                        const cplx yy = make_double2(cp * y.x - sp * x.x, cp * y.y - sp * x.y);
+                        x = xx; y = yy;
+                    }
+                }
+                const int e = tid + k * 256;
+                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
+                s[o] = x;
+                s[o + W] = y;
+            }
+        }
+        __syncthreads();
+        const int nxt = tl + gridDim.x;
+        if (nxt < total) issue(nxt); else have = false;
+        if (cur) {
+            if (!(a.dbg & 1)) lds_fft_dif(s, a.p1, T, 1, a.logT, tw, tid, 256, true);
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int e = tid + k * 256;
+                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
+                const size_t g = cbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
+                a.ux[g] = s[o];
+                a.uy[g] = s[o + W];
+            }
+        }
+        __syncthreads();
+        tl = nxt;
+    }
+}
+
+template <int PF> __global__ __launch_bounds__(256) void k_col_inv_p(SsfmArgs a, int tiles_x, int total)
+{
+    PLX_DYN_LDS(lds);
+    if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
+    const int tid = threadIdx.x;
+    const int N1 = 1 << a.p1, N2 = 1 << a.p2, T = a.T, W = a.W;
+    cplx *s = (cplx *)lds;
+    cplx *tw = s + ((size_t)N1 << a.logT);
+    double *red = (double *)(tw + (N1 >> 1));
+    lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, 256);
+    cplx xv[PF], yv[PF];
+    int tl = blockIdx.x;
+    bool have = false;
+    size_t gbase = 0;
+    auto issue = [&](int t) {
+        const int fc = t / tiles_x, bx = t - fc * tiles_x, f = fc / a.nfc;
+        have = !a.ctl[f].done;
+        gbase = ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * W;
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int e = tid + k * 256;
+                const size_t g = gbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
+                xv[k] = a.ux[g]; yv[k] = a.uy[g];
+            }
+        }
+    };
+    if (tl < total) issue(tl);
+    while (tl < total) {
+        const bool cur = have;
+        const size_t cbase = gbase;
+        if (cur) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) { pin(xv[k]); pin(yv[k]); }
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int e = tid + k * 256;
+                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
+                s[o] = xv[k];
+                s[o + W] = yv[k];
+            }
+        }
+        __syncthreads();
+        const int nxt = tl + gridDim.x;
+        if (nxt < total) issue(nxt); else have = false;
+        if (cur) {
+            const int fc = tl / tiles_x, f = fc / a.nfc;
+            if (!(a.dbg & 1)) lds_fft_dit(s, a.p1, T, 1, a.logT, tw, tid, 256, true);
+            const double sc = a.ctl[f].att * a.invN;
+            double m = 0;
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int e = tid + k * 256;
+                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
+                const size_t g = cbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
+                const cplx x = cscale(s[o], sc), y = cscale(s[o + W], sc);
+                double p = x.x * x.x + x.y * x.y;
+                p = p + y.x * y.x;
+                p = p + y.y * y.y;
+                a.ux[g] = x;
+                a.uy[g] = y;
+                m = p > m ? p : m;
+            }
+            block_atomic_max(m, red, a.umax + fc, tid, 256); // contains a barrier
+        }
+        __syncthreads();
+        tl = nxt;
+    }
+}
+
+template <int PF> __global__ __launch_bounds__(ROW_THREADS) void k_row_p(SsfmArgs a, int tiles_x, int total)
+{
+    PLX_DYN_LDS(lds);
+    if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
+    const int tid = threadIdx.x;
+    const int N2 = 1 << a.p2, R = a.R, TSp = row_pitch(N2);
+    cplx *s = (cplx *)lds;
+    cplx *tw = s + (size_t)2 * R * TSp;
+    lds_load_twiddles(tw, a.tw2, N2 >> 1, tid, ROW_THREADS);
+    const size_t N = (size_t)1 << (a.p1 + a.p2);
+    cplx tv[PF], xv[PF], yv[PF];
+    int tl = blockIdx.x;
+    bool have = false;
+    size_t gbase = 0, rbase = 0;
+    auto issue = [&](int t) {
+        const int fc = t / tiles_x, bx = t - fc * tiles_x, f = fc / a.nfc;
+        have = !a.ctl[f].done;
+        rbase = (size_t)bx * R * N2;
+        gbase = (size_t)fc * N + rbase;
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int e = tid + k * ROW_THREADS;
+                tv[k] = a.tpass[rbase + e];
+                xv[k] = a.ux[gbase + e];
+                yv[k] = a.uy[gbase + e];
+            }
+        }
+    };
+    if (tl < total) issue(tl);
+    while (tl < total) {
+        const bool cur = have;
+        const size_t cg = gbase, cr = rbase;
+        if (cur) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) { pin(tv[k]); pin(xv[k]); pin(yv[k]); }
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int e = tid + k * ROW_THREADS;
+                const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+                s[o] = cmul(xv[k], tv[k]);
+                s[o + R * TSp] = cmul(yv[k], tv[k]);
+            }
+        }
+        __syncthreads();
+        const int nxt = tl + gridDim.x;
+        if (nxt < total) issue(nxt); else have = false;
+        if (cur) {
+            const int fc = tl / tiles_x, f = fc / a.nfc, c = fc - f * a.nfc;
+            const FrameCtl *ctl = a.ctl + f;
+            if (!(a.dbg & 2)) row_fft_dif(s, a.p2, a.logR + 1, tw, tid, ROW_THREADS);
+            const double curdz = ctl->cur;
+            const double *bt = a.betat_p + (size_t)c * N + cr;
+            if (!a.pmd) {
+#pragma unroll
+                for (int k = 0; k < PF; k++) {
+                    const int e = tid + k * ROW_THREADS;
+                    const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+                    const cplx h = (a.dbg & 8) ? make_double2(1.0, bt[e]) : cexpi(-(bt[e] * curdz));
+                    s[o] = cmul(h, s[o]);
+                    s[o + R * TSp] = cmul(h, s[o + R * TSp]);
+                }
+            } else {
+                const double *d1 = a.db1_p + (size_t)c * N + cr;
+                const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * 9 : 0);
+                const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem;
+                const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last, lcorr = a.lcorr;
+                for (int k = 0; k < PF; k++) {
+                    const int e = tid + k * ROW_THREADS;
+                    const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+                    const double btf = bt[e], d1f = d1[e];
+                    cplx x = s[o], y = s[o + R * TSp];
+                    for (int q = 1; q <= ntrunk; q++) {
+                        int plate = n0 + q - 1;
+                        plate = plate < 0 ? 0 : (plate >= a.nplates ? a.nplates - 1 : plate);
+                        const double *m = brf + (size_t)plate * 9;
+                        const cplx R11 = make_double2(m[0], m[1]), R12 = make_double2(m[2], m[3]);
+                        const cplx R21 = make_double2(m[4], m[5]), R22 = make_double2(m[6], m[7]);
+                        const double dzk = (q == 1) ? dzb_first : (q == ntrunk ? dzb_last : lcorr);
+                        cplx uux = cadd(cmulc(x, R11), cmulc(y, R21));                 // :920
+                        cplx uuy = cadd(cmulc(x, R12), cmulc(y, R22));                 // :921
+                        const double combeta = btf * dzk;                              // :924
+                        const double deltabeta = 0.5 * (d1f + m[8]) * dzk / lcorr;     // :925
+                        uux = cmul(cexpi(-(combeta + deltabeta)), uux);                // :927
+                        uuy = cmul(cexpi(-(combeta - deltabeta)), uuy);                // :928
+                        x = cadd(cmul(R11, uux), cmul(R12, uuy));                      // :931
+                        y = cadd(cmul(R21, uux), cmul(R22, uuy));                      // :932
+                    }
+                    s[o] = x;
+                    s[o + R * TSp] = y;
+                }
+            }
+            __syncthreads();
+            if (!(a.dbg & 2)) row_fft_dit(s, a.p2, a.logR + 1, tw, tid, ROW_THREADS);
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int e = tid + k * ROW_THREADS;
+                const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+                const cplx t = a.tpass[cr + e];
+                a.ux[cg + e] = cmulc(s[o], t);
+                a.uy[cg + e] = cmulc(s[o + R * TSp], t);
+            }
+        }
+        __syncthreads();
+        tl = nxt;
+    }
+}
+
 } // namespace
 
 // ================================================================= host side ===
@@ -504,6 +773,8 @@ struct plx_ssfm {
     std::vector<FrameCtl> h_ctl;
     int brf_sets = 0;
     size_t lds_col = 0, lds_row = 0;
+    int pf_col = 0, pf_row = 0;   // > 0: persistent prefetching kernels usable (tile == PF x threads)
+    int grid_col = 0, grid_row = 0;
     int64_t row_launches = 0, sample_steps = 0;
 };
 
@@ -600,6 +871,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     a.nplates = desc->nplates;
     a.alphalin = desc->alphalin; a.Lf = desc->length; a.dzmax = desc->dzmaxt; a.dphimax = desc->dphimaxt;
     a.lcorr = desc->length / desc->nplates; // fiber.m:507
+    if (const char *e = getenv("PLX_SSFM_DBG")) a.dbg = atoi(e);
     a.invN = 1.0 / (double)N;
 
     // ---- tables: spectral multipliers in the order the row pass sees them ----
@@ -654,7 +926,23 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
 
     P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 16 * sizeof(double);
     P->lds_row = ((size_t)(a.dual ? 2 : 1) * a.R * (N2 + N2 / 16) + N2 / 2) * sizeof(cplx);
-    if (allow_lds(k_col_fwd, P->lds_col) != hipSuccess || allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
+    // persistent software-pipelined sweeps: measured 5-8 % slower than the plain grid on MI355X at
+    // F = 256..1024 (profiles/), kept opt-in for experiments
+    if (a.dual && getenv("PLX_SSFM_PERSIST")) {
+        const int nel_col = N1 << a.logW, nel_row = a.R << a.p2;
+        if (nel_col == 8 * 256) P->pf_col = 8; else if (nel_col == 4 * 256) P->pf_col = 4;
+        if (nel_row == 4 * ROW_THREADS) P->pf_row = 4; else if (nel_row == 8 * ROW_THREADS) P->pf_row = 8;
+        int wg = (int)(160 * 1024 / (P->lds_col + 1024)); if (wg < 1) wg = 1; if (wg > 4) wg = 4;
+        P->grid_col = 256 * wg;
+        wg = (int)(160 * 1024 / (P->lds_row + 1024)); if (wg < 1) wg = 1; if (wg > 8) wg = 8;
+        P->grid_row = 256 * wg;
+        if (const char *e = getenv("PLX_SSFM_GRID_COL")) P->grid_col = atoi(e);
+        if (const char *e = getenv("PLX_SSFM_GRID_ROW")) P->grid_row = atoi(e);
+    }
+    if (allow_lds(k_col_fwd_p<8>, P->lds_col) != hipSuccess || allow_lds(k_col_inv_p<8>, P->lds_col) != hipSuccess ||
+        allow_lds(k_col_fwd_p<4>, P->lds_col) != hipSuccess || allow_lds(k_col_inv_p<4>, P->lds_col) != hipSuccess ||
+        allow_lds(k_row_p<4>, P->lds_row) != hipSuccess || allow_lds(k_row_p<8>, P->lds_row) != hipSuccess ||
+        allow_lds(k_col_fwd, P->lds_col) != hipSuccess || allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
         allow_lds(k_row, P->lds_row) != hipSuccess) {
         free_plan(P);
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
@@ -714,6 +1002,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     SsfmArgs a = P->a;
     a.ux = (cplx *)d_ux;
     a.uy = (cplx *)d_uy;
+    a.nframes = nframes;
     const int nfc = a.nfc, N1 = 1 << a.p1, N2 = 1 << a.p2;
     const unsigned FC = (unsigned)nframes * nfc;
     PLX_HIP(hipMemsetAsync(P->d_ctl, 0, sizeof(FrameCtl) * nframes, st));
@@ -742,9 +1031,17 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
                 if (gx > 256) gx = 256;
                 PLX_LAUNCH(k_rowsum, dim3(gx, (unsigned)nframes), blk, 0, st, a);
             }
-            PLX_LAUNCH(k_col_fwd, gcol, blk, P->lds_col, st, a);
-            PLX_LAUNCH(k_row, grow, brow, P->lds_row, st, a);
-            PLX_LAUNCH(k_col_inv, gcol, blk, P->lds_col, st, a);
+            const int tcx = (int)gcol.x, tct = (int)(gcol.x * FC), trx = (int)grow.x, trt = (int)(grow.x * FC);
+            const dim3 pgc((unsigned)(tct < P->grid_col ? tct : P->grid_col)), pgr((unsigned)(trt < P->grid_row ? trt : P->grid_row));
+            if (P->pf_col == 8) PLX_LAUNCH(k_col_fwd_p<8>, pgc, blk, P->lds_col, st, a, tcx, tct);
+            else if (P->pf_col == 4) PLX_LAUNCH(k_col_fwd_p<4>, pgc, blk, P->lds_col, st, a, tcx, tct);
+            else PLX_LAUNCH(k_col_fwd, gcol, blk, P->lds_col, st, a);
+            if (P->pf_row == 4) PLX_LAUNCH(k_row_p<4>, pgr, brow, P->lds_row, st, a, trx, trt);
+            else if (P->pf_row == 8) PLX_LAUNCH(k_row_p<8>, pgr, brow, P->lds_row, st, a, trx, trt);
+            else PLX_LAUNCH(k_row, grow, brow, P->lds_row, st, a);
+            if (P->pf_col == 8) PLX_LAUNCH(k_col_inv_p<8>, pgc, blk, P->lds_col, st, a, tcx, tct);
+            else if (P->pf_col == 4) PLX_LAUNCH(k_col_inv_p<4>, pgc, blk, P->lds_col, st, a, tcx, tct);
+            else PLX_LAUNCH(k_col_inv, gcol, blk, P->lds_col, st, a);
             P->row_launches++;
         }
         steps += chunk;
@@ -755,7 +1052,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
         PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, sizeof(int), hipMemcpyDeviceToHost, st));
         PLX_HIP(hipEventRecord(ev, st));
         pending = true;
-        if (chunk < 32) chunk *= 2;
+        if (chunk < 16) chunk *= 2;
         if (steps > kMaxSteps) { hipEventDestroy(ev); PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate"); }
     }
     PLX_HIP(hipMemcpyAsync(P->h_ctl.data(), P->d_ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost, st));

@@ -41,6 +41,8 @@ class HotPath:
         self.cfg = cfg
         self.F = int(max_frames)
         self.lib = _abi.get()
+        import os
+        self.group = int(os.environ.get("PLX_FIBRE_GROUP", "0"))
         self.dev = torch.device("cuda", torch.cuda.current_device())
         n = cfg.nfft
         # --- host side of fiber(): flag, conversions, tables (fiber.m:157-362) ---
@@ -135,8 +137,20 @@ class HotPath:
 
     def fibre(self, ux, uy):
         """ux, uy: [F, n] complex128 device tensors ([frame][channel=1][nfft]), propagated in place."""
+        F = ux.shape[0]
+        g = self.group or F
+        self._rows = self._steps = 0
         for _ in range(self.cfg.nspans):
-            self.lib.call("plx_ssfm_propagate_dev", self.ssfm, ux.data_ptr(), uy.data_ptr(), ux.shape[0], self.stream())
+            # frames are independent: propagating them in groups whose fields fit the 256 MiB Infinity
+            # Cache keeps the three sweeps of every step on-die instead of streaming HBM
+            for f0 in range(0, F, g):
+                n = min(g, F - f0)
+                self.lib.call("plx_ssfm_propagate_dev", self.ssfm, ux[f0:f0 + n].data_ptr(), uy[f0:f0 + n].data_ptr(), n,
+                              self.stream())
+                rows, steps = C.c_int64(), C.c_int64()
+                self.lib.call("plx_ssfm_stats", self.ssfm, C.byref(rows), C.byref(steps))
+                self._rows += rows.value
+                self._steps += steps.value
 
     def receive(self, ux, uy, noise_sigma=0.0, noise_seed=None):
         """2-sps pick (symbol centre + mid-symbol), CDE, DSP, decisions.  Returns err [F,2] (device)."""
@@ -179,6 +193,5 @@ class HotPath:
         return self.receive(ux, uy, noise_sigma, noise_seed)
 
     def ssfm_stats(self):
-        rows, steps = C.c_int64(), C.c_int64()
-        self.lib.call("plx_ssfm_stats", self.ssfm, C.byref(rows), C.byref(steps))
-        return rows.value, steps.value
+        """(row-pass launches, sample-steps) of the last fibre() call, summed over its frame groups"""
+        return self._rows, self._steps
