@@ -49,6 +49,27 @@ __device__ __forceinline__ void pin(cplx &v) { asm volatile("" : "+v"(v.x), "+v"
 __device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
 #endif
 
+// ---- agent-scope (whole-GPU) relaxed atomics for words shared between workgroups INSIDE a launch:
+// global_load/store ... sc1, served by the memory side, never by a possibly stale per-CU L1 / per-XCD
+// L2 line (CDNA guide, Guideline 16: "8-B agent atomics both sides").
+#ifdef PLX_EMU
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return emu_atomic_load_u32(p); }
+__device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { emu_atomic_store_u32(p, v); }
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return emu_atomic_load_u64(p); }
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { emu_atomic_store_u64(p, v); }
+__device__ __forceinline__ void drain_vmem() {}
+__device__ __forceinline__ void nap() { std::this_thread::yield(); }
+#else
+__device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(4); }
+#endif
+__device__ __forceinline__ double ld_agent_f64(const double *p) { return __longlong_as_double((long long)ld_agent((const unsigned long long *)p)); }
+__device__ __forceinline__ void st_agent_f64(double *p, double v) { st_agent((unsigned long long *)p, (unsigned long long)__double_as_longlong(v)); }
+
 // ---- error plumbing (host) ------------------------------------------------------
 void plx_set_error(const std::string &msg);
 #define PLX_HIP(call)                                                                          \

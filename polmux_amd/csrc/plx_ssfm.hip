@@ -56,6 +56,9 @@ struct SsfmArgs {
     FrameCtl *ctl;
     unsigned long long *umax;      // [F][nfc] bit pattern of max |u|^2 (>= 0)
     int *ndone;
+    unsigned *arrive, *epoch;      // [F] frame barrier of the fused column sweep (tickets / completed rounds)
+    double *pub;                   // [F][2] words published inside a launch: leff, done flag
+    int *syncerr;                  // set if a frame barrier timed out
     int p1, p2, nfc, dual, W, logW, T, logT, R, logR; // column tile: N1 rows x T complex (T = W*npol)
     int spm, xpm, manakov, pmd, nplates, brf_per_frame;
     int nframes; // frames of the current propagate call (kernels return at once when all are done)
@@ -135,10 +138,8 @@ __global__ __launch_bounds__(256) void k_umax(SsfmArgs a)
 // --------------------------------------------------------------- step control ---
 // nextstep (fiber.m:682-715), the loop head/tail of matrix_ssfm/scalar_ssfm
 // (:512-551, :585-636) and checkstep (:718-758), one lane per frame.
-__global__ void k_ctrl(SsfmArgs a, int nframes)
+template <bool AGENT> __device__ __forceinline__ void ctrl_step(const SsfmArgs &a, int f)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= nframes) return;
     FrameCtl c = a.ctl[f];
     if (c.done) return;
     if (c.started) {
@@ -153,10 +154,12 @@ __global__ void k_ctrl(SsfmArgs a, int nframes)
     // nextstep
     double Pmax = -INFINITY;
     for (int k = 0; k < a.nfc; k++) {
-        double Umax = __longlong_as_double((long long)a.umax[f * a.nfc + k]);
+        unsigned long long *up = a.umax + f * a.nfc + k;
+        const unsigned long long bits = AGENT ? ld_agent(up) : *up;
+        double Umax = __longlong_as_double((long long)bits);
         double gp = a.gam[k] * Umax;
         Pmax = gp > Pmax ? gp : Pmax;
-        a.umax[f * a.nfc + k] = 0ull;
+        if (AGENT) st_agent(up, 0ull); else *up = 0ull;
     }
     double leffn = a.dphimax / Pmax;
     double dl = a.alphalin * leffn;
@@ -209,6 +212,13 @@ __global__ void k_ctrl(SsfmArgs a, int nframes)
         }
     }
     a.ctl[f] = c;
+}
+
+__global__ void k_ctrl(SsfmArgs a, int nframes)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= nframes) return;
+    ctrl_step<false>(a, f);
 }
 
 // ------------------------------------------------- scalar XPM row sum (:795) ---
@@ -756,6 +766,152 @@ template <int PF> __global__ __launch_bounds__(ROW_THREADS) void k_row_p(SsfmArg
     }
 }
 
+// ============================================================================
+// Fused column sweep: inverse column transform of step s, the step controller, and the Kerr step +
+// forward column transform of step s+1 on the SAME LDS-resident tile -- one read and one write of the
+// field instead of two (the step is then 2 sweeps: 128 B of HBM traffic per dual-pol sample).
+// The only obstacle is nextstep's maximum over the whole frame (fiber.m:694-698): the tiles of one
+// frame are therefore handled by workgroups that are resident at the same time (persistent grid, a
+// multiple of tiles-per-frame and at most the chip's residency) and meet at a per-frame barrier:
+// ticket counter -> the last arriver runs ctrl_step and publishes (Leff, done) -> the others poll one
+// word.  All shared words use agent-scope atomics (CDNA guide G16); the next tile's loads are already
+// in flight while a workgroup waits.  Spins are bounded; a timeout raises an error on the host.
+template <int PF> __global__ __launch_bounds__(256) void k_colx(SsfmArgs a, int tiles_x, int tiles_pf, int total)
+{
+    PLX_DYN_LDS(lds);
+    if (*a.ndone >= a.nframes) return;
+    const int tid = threadIdx.x;
+    const int N1 = 1 << a.p1, N2 = 1 << a.p2, T = a.T, W = a.W;
+    cplx *s = (cplx *)lds;
+    cplx *tw = s + ((size_t)N1 << a.logT);
+    double *red = (double *)(tw + (N1 >> 1)); // [16] + broadcast slots [16..19]
+    lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, 256);
+    cplx xv[PF], yv[PF];
+    int tl = blockIdx.x;
+    bool have = false;
+    size_t gbase = 0;
+    auto issue = [&](int t) {
+        const int fc = t / tiles_x, bx = t - fc * tiles_x, f = fc / a.nfc;
+        have = !a.ctl[f].done;
+        gbase = ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * W;
+        if (have) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int e = tid + k * 256;
+                const size_t g = gbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
+                xv[k] = a.ux[g]; yv[k] = a.uy[g];
+            }
+        }
+    };
+    if (tl < total) issue(tl);
+    while (tl < total) {
+        const bool cur = have;
+        const size_t cbase = gbase;
+        const int fc = tl / tiles_x, f = fc / a.nfc, c = fc - f * a.nfc;
+        if (cur) {
+#pragma unroll
+            for (int k = 0; k < PF; k++) { pin(xv[k]); pin(yv[k]); }
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int e = tid + k * 256;
+                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
+                s[o] = xv[k];
+                s[o + W] = yv[k];
+            }
+        }
+        __syncthreads();
+        const int nxt = tl + gridDim.x;
+        if (nxt < total) issue(nxt); else have = false;
+        if (cur) {
+            const bool started = a.ctl[f].started != 0;
+            double sc = 1.0;
+            if (started) { // finish step s: ifft (1/N) and attenuation (:531-532)
+                if (!(a.dbg & 1)) lds_fft_dit(s, a.p1, T, 1, a.logT, tw, tid, 256, true);
+                sc = a.ctl[f].att * a.invN;
+            }
+            double m = 0;
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int e = tid + k * 256;
+                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
+                const cplx x = cscale(s[o], sc), y = cscale(s[o + W], sc);
+                double p = x.x * x.x + x.y * x.y;
+                p = p + y.x * y.x;
+                p = p + y.y * y.y;
+                s[o] = x;
+                s[o + W] = y;
+                m = p > m ? p : m;
+            }
+            m = wave_max(m);
+            if ((tid & 63) == 0) red[tid >> 6] = m;
+            __syncthreads();
+            if (tid == 0) {
+                double mm = red[0];
+                for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
+                const unsigned long long prev = atomicMax(a.umax + fc, (unsigned long long)__double_as_longlong(mm));
+                unsigned ticket = 0;
+                if (prev != ~0ull) ticket = atomicAdd(a.arrive + f, 1u); // (prev used: the max has completed first)
+                const unsigned round = ticket / (unsigned)tiles_pf + 1;
+                if ((ticket + 1) % (unsigned)tiles_pf == 0) { // last arriver of the frame: step controller
+                    ctrl_step<true>(a, f);
+                    st_agent_f64(a.pub + 2 * f, a.ctl[f].leff);
+                    st_agent_f64(a.pub + 2 * f + 1, a.ctl[f].done ? 1.0 : 0.0);
+                    drain_vmem();
+                    st_agent(a.epoch + f, round);
+                } else {
+                    unsigned spins = 0;
+                    while (ld_agent(a.epoch + f) < round && !(a.dbg & 16)) {
+                        nap();
+                        if (++spins > (1u << 21)) { atomicAdd(a.syncerr, 1); break; }
+                    }
+                }
+                red[16] = ld_agent_f64(a.pub + 2 * f);
+                red[17] = ld_agent_f64(a.pub + 2 * f + 1);
+            }
+            __syncthreads();
+            const double leff = red[16];
+            const bool finished = red[17] != 0.0;
+            if (!finished && a.spm && !(a.dbg & 4)) { // Kerr step of step s+1 on the resident tile (:832-852)
+                const double gamleff = a.gam[c] * leff;
+#pragma unroll
+                for (int k = 0; k < PF; k++) {
+                    const int e = tid + k * 256;
+                    const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
+                    cplx x = s[o], y = s[o + W];
+                    const double P = x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y;
+                    double sn, cs;
+                    sincos_small(-gamleff * P, &sn, &cs);
+                    const cplx nl = make_double2(cs, sn);
+                    x = cmul(x, nl);
+                    y = cmul(y, nl);
+                    if (!a.manakov) {
+                        const double s3 = 2 * (x.x * y.y - x.y * y.x);
+                        double sp, cp;
+                        sincos_small(gamleff * s3 / 3, &sp, &cp);
+                        const cplx xx = make_double2(cp * x.x + sp * y.x, cp * x.y + sp * y.y);
+                        const cplx yy = make_double2(cp * y.x - sp * x.x, cp * y.y - sp * x.y);
+                        x = xx; y = yy;
+                    }
+                    s[o] = x;
+                    s[o + W] = y;
+                }
+            }
+            __syncthreads();
+            if (!finished && !(a.dbg & 1)) lds_fft_dif(s, a.p1, T, 1, a.logT, tw, tid, 256, true);
+#pragma unroll
+            for (int k = 0; k < PF; k++) {
+                const int e = tid + k * 256;
+                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
+                const size_t g = cbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
+                a.ux[g] = s[o];
+                a.uy[g] = s[o + W];
+            }
+        }
+        __syncthreads();
+        tl = nxt;
+    }
+}
+
 } // namespace
 
 // ================================================================= host side ===
@@ -773,6 +929,9 @@ struct plx_ssfm {
     std::vector<FrameCtl> h_ctl;
     int brf_sets = 0;
     size_t lds_col = 0, lds_row = 0;
+    unsigned *d_sync = nullptr;   // arrive[F] | epoch[F] | syncerr
+    double *d_pub = nullptr;
+    int fused = 0, fused_grid = 0, tiles_pf = 0;
     int pf_col = 0, pf_row = 0;   // > 0: persistent prefetching kernels usable (tile == PF x threads)
     int grid_col = 0, grid_row = 0;
     int64_t row_launches = 0, sample_steps = 0;
@@ -790,7 +949,7 @@ static void free_plan(plx_ssfm *P)
     if (!P) return;
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
-    hipFree(P->d_ndone);
+    hipFree(P->d_ndone); hipFree(P->d_sync); hipFree(P->d_pub);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     delete P;
 }
@@ -924,7 +1083,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     a.gam = P->d_gam; a.ctl = P->d_ctl; a.umax = P->d_umax; a.ndone = P->d_ndone; a.psum = P->d_psum;
     P->h_ctl.resize(F);
 
-    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 16 * sizeof(double);
+    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double);
     P->lds_row = ((size_t)(a.dual ? 2 : 1) * a.R * (N2 + N2 / 16) + N2 / 2) * sizeof(cplx);
     // persistent software-pipelined sweeps: measured 5-8 % slower than the plain grid on MI355X at
     // F = 256..1024 (profiles/), kept opt-in for experiments
@@ -938,6 +1097,31 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         P->grid_row = 256 * wg;
         if (const char *e = getenv("PLX_SSFM_GRID_COL")) P->grid_col = atoi(e);
         if (const char *e = getenv("PLX_SSFM_GRID_ROW")) P->grid_row = atoi(e);
+    }
+    // fused column sweep (opt-in, PLX_SSFM_FUSE=1): needs the tile to be PF x 256 and all tiles of a frame
+    // co-resident.  Measured on MI355X it moves 1/3 less HBM traffic but is latency-bound at 2 workgroups
+    // per CU and ends up level with the plain three-sweep step (profiles/r01_notes.md), so the default
+    // stays the barrier-free form.
+    if (a.dual && getenv("PLX_SSFM_FUSE")) {
+        const int nel_col = N1 << a.logW, tiles_pf = nfc * (N2 / a.W);
+        int wg = (int)(160 * 1024 / (P->lds_col + 1024)); if (wg < 1) wg = 1; if (wg > 2) wg = 2;
+        const int cap = 256 * wg;
+        if ((nel_col == 8 * 256 || nel_col == 4 * 256 || nel_col == 16 * 256) && tiles_pf <= cap) {
+            P->fused = nel_col / 256;
+            P->tiles_pf = tiles_pf;
+            P->fused_grid = (cap / tiles_pf) * tiles_pf;
+            if (hipMalloc((void **)&P->d_sync, sizeof(unsigned) * (2 * (size_t)F + 16)) != hipSuccess ||
+                hipMalloc((void **)&P->d_pub, sizeof(double) * 2 * (size_t)F) != hipSuccess) {
+                free_plan(P);
+                PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed");
+            }
+            a.arrive = P->d_sync; a.epoch = P->d_sync + F; a.syncerr = (int *)(P->d_sync + 2 * (size_t)F); a.pub = P->d_pub;
+        }
+    }
+    if (allow_lds(k_colx<8>, P->lds_col) != hipSuccess || allow_lds(k_colx<4>, P->lds_col) != hipSuccess ||
+        allow_lds(k_colx<16>, P->lds_col) != hipSuccess) {
+        free_plan(P);
+        PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
     }
     if (allow_lds(k_col_fwd_p<8>, P->lds_col) != hipSuccess || allow_lds(k_col_inv_p<8>, P->lds_col) != hipSuccess ||
         allow_lds(k_col_fwd_p<4>, P->lds_col) != hipSuccess || allow_lds(k_col_inv_p<4>, P->lds_col) != hipSuccess ||
@@ -1008,7 +1192,11 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     PLX_HIP(hipMemsetAsync(P->d_ctl, 0, sizeof(FrameCtl) * nframes, st));
     PLX_HIP(hipMemsetAsync(P->d_umax, 0, sizeof(unsigned long long) * FC, st));
     PLX_HIP(hipMemsetAsync(P->d_ndone, 0, 64, st));
-    {
+    const bool fused = P->fused != 0;
+    if (fused) { // the first fused launch also forms nextstep's initial maximum
+        PLX_HIP(hipMemsetAsync(P->d_sync, 0, sizeof(unsigned) * (2 * (size_t)P->d.max_frames + 16), st));
+        PLX_HIP(hipMemsetAsync(P->d_pub, 0, sizeof(double) * 2 * (size_t)P->d.max_frames, st));
+    } else {
         unsigned gx = (unsigned)((P->N + 255) / 256);
         if (gx > 64) gx = 64;
         PLX_LAUNCH(k_umax, dim3(gx, FC), dim3(256), 16 * sizeof(double), st, a);
@@ -1025,6 +1213,22 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     bool pending = false;
     for (;;) {
         for (int sidx = 0; sidx < chunk; sidx++) {
+            if (fused) {
+                const int tcx = (int)gcol.x, tct = (int)(gcol.x * FC);
+                const dim3 gx((unsigned)(tct < P->fused_grid ? tct : P->fused_grid));
+#ifdef PLX_EMU
+                emu::g_concurrency = P->tiles_pf; // the emulator must keep one frame's workgroups alive together
+#endif
+                if (P->fused == 8) PLX_LAUNCH(k_colx<8>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
+                else if (P->fused == 4) PLX_LAUNCH(k_colx<4>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
+                else PLX_LAUNCH(k_colx<16>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
+#ifdef PLX_EMU
+                emu::g_concurrency = 1;
+#endif
+                PLX_LAUNCH(k_row, grow, brow, P->lds_row, st, a);
+                P->row_launches++;
+                continue;
+            }
             PLX_LAUNCH(k_ctrl, gctl, bctl, 0, st, a, nframes);
             if (!a.dual && a.xpm) {
                 unsigned gx = (unsigned)((P->N + 255) / 256);
@@ -1056,8 +1260,11 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
         if (steps > kMaxSteps) { hipEventDestroy(ev); PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate"); }
     }
     PLX_HIP(hipMemcpyAsync(P->h_ctl.data(), P->d_ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost, st));
+    int syncerr = 0;
+    if (fused) PLX_HIP(hipMemcpyAsync(&syncerr, P->a.syncerr, sizeof(int), hipMemcpyDeviceToHost, st));
     PLX_HIP(hipStreamSynchronize(st));
     hipEventDestroy(ev);
+    if (syncerr) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: frame barrier timed out (workgroups of a frame were not co-resident)");
     P->sample_steps = 0;
     for (int f = 0; f < nframes; f++) {
         if (!P->h_ctl[f].done) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: a frame did not reach the fibre end");

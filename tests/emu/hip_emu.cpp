@@ -3,9 +3,10 @@
 #include <chrono>
 
 namespace emu {
-BlockCtx g_ctx;
+thread_local BlockCtx *t_ctx = nullptr;
 thread_local dim3 t_threadIdx, t_blockIdx;
 thread_local unsigned t_linear;
+int g_concurrency = 1;
 
 namespace {
 struct Pool {
@@ -16,6 +17,7 @@ struct Pool {
     unsigned active = 0, remaining = 0;
     const std::function<void()> *body = nullptr;
     dim3 bidx;
+    BlockCtx ctx;
     bool stop = false;
 
     void worker(unsigned id)
@@ -28,13 +30,14 @@ struct Pool {
             seen = gen;
             if (id >= active) continue;
             lk.unlock();
-            const dim3 b = g_ctx.block;
+            const dim3 b = ctx.block;
+            t_ctx = &ctx;
             t_linear = id;
             t_threadIdx = dim3(id % b.x, (id / b.x) % b.y, id / (b.x * b.y));
             t_blockIdx = bidx;
             (*body)();
-            g_ctx.wave_bar[id / 64]->arrive_and_drop();
-            g_ctx.bar->arrive_and_drop();
+            ctx.wave_bar[id / 64]->arrive_and_drop();
+            ctx.bar->arrive_and_drop();
             lk.lock();
             if (--remaining == 0) cv_done.notify_all();
         }
@@ -46,16 +49,31 @@ struct Pool {
             th.emplace_back([this, id] { worker(id); });
         }
     }
-    void run_block(unsigned n, dim3 b, const std::function<void()> &f)
+    void start_block(dim3 grid, dim3 block, unsigned n, size_t shmem, dim3 b, const std::function<void()> &f)
     {
         ensure(n);
         std::unique_lock<std::mutex> lk(m);
+        ctx.grid = grid;
+        ctx.block = block;
+        ctx.nthreads = n;
+        ctx.xchg.assign(n, 0);
+        ctx.lds.assign(shmem ? shmem : 16, (char)0x7f); // poisoned LDS: uninitialised reads show up
+        ctx.bar = std::make_unique<std::barrier<>>((std::ptrdiff_t)n);
+        ctx.wave_bar.clear();
+        for (unsigned w = 0; w < (n + 63) / 64; w++) {
+            unsigned lanes = std::min(64u, n - w * 64);
+            ctx.wave_bar.push_back(std::make_unique<std::barrier<>>((std::ptrdiff_t)lanes));
+        }
         active = n;
         remaining = n;
         body = &f;
         bidx = b;
         ++gen;
         cv_start.notify_all();
+    }
+    void wait_block()
+    {
+        std::unique_lock<std::mutex> lk(m);
         cv_done.wait(lk, [&] { return remaining == 0; });
     }
     ~Pool()
@@ -68,9 +86,9 @@ struct Pool {
         for (auto &t : th) t.join();
     }
 };
-Pool &pool()
+std::vector<std::unique_ptr<Pool>> &pools()
 {
-    static Pool p;
+    static std::vector<std::unique_ptr<Pool>> p;
     return p;
 }
 } // namespace
@@ -81,24 +99,19 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &bo
     if (n == 0 || n > 1024) { std::fprintf(stderr, "emu: bad block size %u\n", n); std::abort(); }
     if (shmem > 160 * 1024) { std::fprintf(stderr, "emu: LDS request %zu > 160 KiB\n", shmem); std::abort(); }
     static const bool trace = std::getenv("PLX_EMU_TRACE") != nullptr;
-    if (trace) std::fprintf(stderr, "emu launch grid=(%u,%u,%u) block=%u lds=%zu\n", grid.x, grid.y, grid.z, n, shmem);
-    g_ctx.grid = grid;
-    g_ctx.block = block;
-    g_ctx.nthreads = n;
-    g_ctx.xchg.assign(n, 0);
+    if (trace) std::fprintf(stderr, "emu launch grid=(%u,%u,%u) block=%u lds=%zu conc=%d\n", grid.x, grid.y, grid.z, n, shmem, g_concurrency);
+    const unsigned conc = (unsigned)(g_concurrency < 1 ? 1 : g_concurrency);
+    auto &ps = pools();
+    while (ps.size() < conc) ps.push_back(std::make_unique<Pool>());
+    std::vector<dim3> ids;
     for (unsigned bz = 0; bz < grid.z; bz++)
         for (unsigned by = 0; by < grid.y; by++)
-            for (unsigned bx = 0; bx < grid.x; bx++) {
-                // fresh, poisoned LDS per workgroup so uninitialised reads show up
-                g_ctx.lds.assign(shmem ? shmem : 16, (char)0x7f);
-                g_ctx.bar = std::make_unique<std::barrier<>>((std::ptrdiff_t)n);
-                g_ctx.wave_bar.clear();
-                for (unsigned w = 0; w < (n + 63) / 64; w++) {
-                    unsigned lanes = std::min(64u, n - w * 64);
-                    g_ctx.wave_bar.push_back(std::make_unique<std::barrier<>>((std::ptrdiff_t)lanes));
-                }
-                pool().run_block(n, dim3(bx, by, bz), body);
-            }
+            for (unsigned bx = 0; bx < grid.x; bx++) ids.push_back(dim3(bx, by, bz));
+    for (size_t i = 0; i < ids.size(); i += conc) {
+        const size_t k = std::min((size_t)conc, ids.size() - i);
+        for (size_t j = 0; j < k; j++) ps[j]->start_block(grid, block, n, shmem, ids[i + j], body);
+        for (size_t j = 0; j < k; j++) ps[j]->wait_block();
+    }
 }
 } // namespace emu
 

@@ -56,19 +56,22 @@ struct BlockCtx {
     std::vector<uint64_t> xchg; // per-thread 8-byte exchange slot (2 slots for 16 B)
     std::vector<char> lds;
 };
-extern BlockCtx g_ctx;
+extern thread_local BlockCtx *t_ctx;   // the workgroup this OS thread belongs to
 extern thread_local dim3 t_threadIdx, t_blockIdx;
 extern thread_local unsigned t_linear;
+// number of workgroups executed concurrently (default 1).  Kernels whose workgroups wait for each
+// other inside a launch (frame barrier of the fused SSFM column sweep) need their partners alive.
+extern int g_concurrency;
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
-inline char *dyn_lds() { return g_ctx.lds.data(); }
+inline char *dyn_lds() { return t_ctx->lds.data(); }
 } // namespace emu
 
 #define threadIdx (emu::t_threadIdx)
 #define blockIdx (emu::t_blockIdx)
-#define blockDim (emu::g_ctx.block)
-#define gridDim (emu::g_ctx.grid)
+#define blockDim (emu::t_ctx->block)
+#define gridDim (emu::t_ctx->grid)
 
-static inline void __syncthreads() { emu::g_ctx.bar->arrive_and_wait(); }
+static inline void __syncthreads() { emu::t_ctx->bar->arrive_and_wait(); }
 
 template <class T> static inline T emu_shfl_src(T v, int src_lane)
 {
@@ -76,11 +79,12 @@ template <class T> static inline T emu_shfl_src(T v, int src_lane)
     unsigned lin = emu::t_linear, wave = lin / 64, lane = lin % 64;
     uint64_t bits = 0;
     std::memcpy(&bits, &v, sizeof(T));
-    emu::g_ctx.xchg[lin] = bits;
-    emu::g_ctx.wave_bar[wave]->arrive_and_wait();
+    emu::BlockCtx &cx = *emu::t_ctx;
+    cx.xchg[lin] = bits;
+    cx.wave_bar[wave]->arrive_and_wait();
     unsigned src = wave * 64 + (unsigned)(src_lane & 63);
-    uint64_t got = src < emu::g_ctx.nthreads ? emu::g_ctx.xchg[src] : bits;
-    emu::g_ctx.wave_bar[wave]->arrive_and_wait();
+    uint64_t got = src < cx.nthreads ? cx.xchg[src] : bits;
+    cx.wave_bar[wave]->arrive_and_wait();
     T r;
     std::memcpy(&r, &got, sizeof(T));
     (void)lane;
@@ -114,6 +118,10 @@ static inline unsigned long long atomicAdd(unsigned long long *p, unsigned long 
 {
     return reinterpret_cast<std::atomic<unsigned long long> *>(p)->fetch_add(v);
 }
+static inline unsigned emu_atomic_load_u32(const unsigned *p) { return reinterpret_cast<const std::atomic<unsigned> *>(p)->load(); }
+static inline void emu_atomic_store_u32(unsigned *p, unsigned v) { reinterpret_cast<std::atomic<unsigned> *>(p)->store(v); }
+static inline unsigned long long emu_atomic_load_u64(const unsigned long long *p) { return reinterpret_cast<const std::atomic<unsigned long long> *>(p)->load(); }
+static inline void emu_atomic_store_u64(unsigned long long *p, unsigned long long v) { reinterpret_cast<std::atomic<unsigned long long> *>(p)->store(v); }
 // sincos(): glibc's (declared by <cmath> under _GNU_SOURCE)
 static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }

@@ -522,3 +522,32 @@ def test_fiber_function_surface(lib, oracle):
         px.fiber(x, "zzzz")
     with pytest.raises(ValueError, match="Missing propagation type"):
         px.fiber(x)
+
+
+@pytest.mark.parametrize("var", ["PLX_SSFM_FUSE", "PLX_SSFM_PERSIST"])
+def test_optin_sweep_variants_match_oracle(lib, oracle, monkeypatch, var):
+    """The opt-in SSFM sweeps (fused col_inv+control+col_fwd behind a per-frame barrier; persistent
+    register-prefetching sweeps) reproduce the oracle like the default path, frames with different step counts."""
+    import torch
+    F = 20                                           # > 16 frames: the fused grid walks more than one round
+    c = _fibre_case(1024, 64, "g-s-", 2.0, length=2e4)
+    monkeypatch.setenv(var, "1")
+    plan = C.c_void_p()
+    lib.call("plx_ssfm_create", C.byref(plan), C.byref(_desc(c, frames=F)))
+    monkeypatch.delenv(var)
+    scale = np.sqrt(np.linspace(0.5, 6.0, F))
+    ux = _dev(np.stack([c["ux"][:, 0] * s for s in scale]))
+    uy = _dev(np.stack([c["uy"][:, 0] * s for s in scale]))
+    lib.call("plx_ssfm_propagate_dev", plan, ux.data_ptr(), uy.data_ptr(), F, torch.cuda.current_stream().cuda_stream)
+    ncyc = np.zeros(F, np.int32)
+    lib.call("plx_ssfm_results", plan, F, None, _vp(ncyc))
+    lib.call("plx_ssfm_destroy", plan)
+    gx, gy = ux.cpu().numpy(), uy.cpu().numpy()
+    for f in (0, 7, 15, 16, 19):
+        rc, ofd, onc, ox, oy = oracle.matrix_ssfm(c["ux"] * scale[f], c["uy"] * scale[f], c["t"]["betat"], c["t"]["db1"], c["dzm"],
+                                                  c["dph"], c["t"]["gam"], c["t"]["alphalin"], c["length"], 1, False, c["fls"],
+                                                  [0.0], [0.0], [0.0])
+        assert ncyc[f] == onc
+        assert np.abs(gx[f] - ox[:, 0]).max() <= FIELD_RTOL * np.abs(ox).max()
+        assert np.abs(gy[f] - oy[:, 0]).max() <= FIELD_RTOL * np.abs(oy).max()
+    assert len(set(ncyc.tolist())) > 3
