@@ -932,6 +932,7 @@ struct plx_dsp {
     int64_t Lin, L;
     int ncol, max_frames;
     cplx *d_a = nullptr, *d_b = nullptr, *d_M = nullptr, *d_h = nullptr, *d_wsc = nullptr;
+    cplx *d_Mrot = nullptr; // [2][max_frames][4]: constant rotation matrices of the CMA / EASI drivers (:155-156)
     double *d_wsr = nullptr;
     int use_lds = 0;
     size_t lds_cpe = 0;
@@ -941,6 +942,7 @@ extern "C" int plx_dsp_destroy(plx_dsp *P)
 {
     if (P) {
         hipFree(P->d_a); hipFree(P->d_b); hipFree(P->d_M); hipFree(P->d_h); hipFree(P->d_wsc); hipFree(P->d_wsr);
+        hipFree(P->d_Mrot);
         delete P;
     }
     return PLX_OK;
@@ -969,6 +971,19 @@ extern "C" int plx_dsp_create(plx_dsp **out, int64_t Lin, int32_t ncol, int32_t 
     if (ok && !P->use_lds)
         ok = hipMalloc((void **)&P->d_wsc, 2 * n * sizeof(cplx)) == hipSuccess &&
              hipMalloc((void **)&P->d_wsr, 2 * n * sizeof(double)) == hipSuccess;
+    if (ok) { // M = [cos sin; -sin cos] of cmapolardemux / easipolardemux with two Tx polarisations
+        std::vector<cplx> M((size_t)2 * max_frames * 4);
+        for (int m = 0; m < 2; m++) {
+            const double phi = m == 0 ? p->cma_phizero : p->easi_phizero;
+            for (int f = 0; f < max_frames; f++) {
+                cplx *q = &M[((size_t)m * max_frames + f) * 4];
+                q[0] = make_double2(cos(phi), 0); q[1] = make_double2(sin(phi), 0);
+                q[2] = make_double2(-sin(phi), 0); q[3] = make_double2(cos(phi), 0);
+            }
+        }
+        ok = hipMalloc((void **)&P->d_Mrot, M.size() * sizeof(cplx)) == hipSuccess &&
+             hipMemcpy(P->d_Mrot, M.data(), M.size() * sizeof(cplx), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (!ok) { plx_dsp_destroy(P); PLX_FAIL(PLX_ERR_HIP, "plx_dsp_create: device allocation failed"); }
     if (allow_lds(k_cpe, P->lds_cpe) != hipSuccess) { plx_dsp_destroy(P); PLX_FAIL(PLX_ERR_HIP, "plx_dsp_create: cannot reserve LDS"); }
     *out = P;
@@ -982,21 +997,17 @@ static int demux_stage(plx_dsp *P, int method, cplx *src, cplx *dst, int nframes
     const plx_dsp_params &p = P->p;
     const int txpol = method == PLX_DEMUX_CMA ? p.cma_txpolars : p.easi_txpolars;
     const double phi = method == PLX_DEMUX_CMA ? p.cma_phizero : p.easi_phizero;
-    if (txpol == 2) { // M = [cos sin; -sin cos]  :155-156
-        std::vector<cplx> M((size_t)nframes * 4);
-        for (int f = 0; f < nframes; f++) {
-            M[4 * f] = make_double2(cos(phi), 0); M[4 * f + 1] = make_double2(sin(phi), 0);
-            M[4 * f + 2] = make_double2(-sin(phi), 0); M[4 * f + 3] = make_double2(cos(phi), 0);
-        }
-        PLX_HIP(hipMemcpyAsync(P->d_M, M.data(), M.size() * sizeof(cplx), hipMemcpyHostToDevice, (hipStream_t)stream));
-        PLX_HIP(hipStreamSynchronize((hipStream_t)stream)); // M is a stack temporary
+    const cplx *Min = P->d_M;
+    if (txpol == 2) { // M = [cos sin; -sin cos]  :155-156 (constant, uploaded once at plan creation)
+        (void)phi;
+        Min = P->d_Mrot + (size_t)(method == PLX_DEMUX_CMA ? 0 : 1) * P->max_frames * 4;
     } else {
         PLX_LAUNCH(k_rotpolar, dim3((unsigned)nframes), dim3(256), 16 * sizeof(double), stream, (const cplx *)src,
                    (cplx *)nullptr, P->d_M, P->L, 0);
     }
     return plx_poldemux_dev(method, (const double *)src, (double *)dst, P->L, nframes,
                             method == PLX_DEMUX_CMA ? p.cma_taps : 1, method == PLX_DEMUX_CMA ? p.cma_mu : p.easi_mu,
-                            p.cma_R, (const double *)P->d_M, (double *)P->d_h, nullptr, stream);
+                            p.cma_R, (const double *)Min, (double *)P->d_h, nullptr, stream);
 }
 
 extern "C" int plx_dsp_run_dev(plx_dsp *P, const double *d_in, double *d_out, int nframes, void *stream)

@@ -152,8 +152,17 @@ class HotPath:
                 self._rows += rows.value
                 self._steps += steps.value
 
-    def receive(self, ux, uy, noise_sigma=0.0, noise_seed=None):
-        """2-sps pick (symbol centre + mid-symbol), CDE, DSP, decisions.  Returns err [F,2] (device)."""
+    def receive(self, ux, uy, noise_sigma=0.0, noise_seed=None, side_stream=None):
+        """2-sps pick (symbol centre + mid-symbol), CDE, DSP, decisions.  Returns err [F,2] (device).
+        With side_stream the whole receiver is enqueued on that stream behind the fibre of this batch, so
+        the latency-bound CMA recurrence overlaps the HBM-bound fibre sweeps of the NEXT batch."""
+        if side_stream is not None:
+            torch = self.torch
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            side_stream.wait_event(ready)
+            with torch.cuda.stream(side_stream):
+                return self.receive(ux, uy, noise_sigma, noise_seed)
         F = ux.shape[0]
         cfg = self.cfg
         half = cfg.nt // 2
