@@ -97,6 +97,12 @@ int plx_matrix_ssfm(double *uxr, double *uxi, double *uyr, double *uyi, const pl
                     const double *db0, const double *theta, const double *epsilon,
                     double *firstdz, int32_t *ncycle);
 int plx_scalar_ssfm(double *ur, double *ui, const plx_ssfm_desc *desc, double *firstdz, int32_t *ncycle);
+/* adaptive step size by local error (x.ltol): tolflag 2 = [firstdz,ncycle,u]=scalar_a_ssfm(...) with adaptssfm
+ * (fiber.m:639-679, 938-1009); tolflag 1 = x.dphiadapt: adaptive first step, then the constant-phase loop with
+ * the corrected dphimax (fiber.m:588-611).  trg.err = ltol, trg.safety = 0.9 in fiber.m:145-146.  Scalar fields
+ * only: a dual-polarisation descriptor returns PLX_ERR_REFERENCE with the message of fiber.m:374.               */
+int plx_scalar_ssfm_adaptive(double *ur, double *ui, const plx_ssfm_desc *desc, int tolflag, double ltol,
+                             double safety, double *firstdz, int32_t *ncycle, int32_t *nrej);
 
 /* ------------------------------------------------------ overlap-save CD equaliser --- */
 /* y = OverlapBothTrans(x, H, L)  CDE_OFDE.m:62-125, batched: x [nsig][nx], H [N] on

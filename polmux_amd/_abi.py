@@ -59,6 +59,8 @@ SIGNATURES = {
     "plx_matrix_ssfm": [_vp, _vp, _vp, _vp, C.POINTER(SsfmDesc), _vp, _vp, _vp, C.POINTER(_dbl),
                         C.POINTER(_i32)],
     "plx_scalar_ssfm": [_vp, _vp, C.POINTER(SsfmDesc), C.POINTER(_dbl), C.POINTER(_i32)],
+    "plx_scalar_ssfm_adaptive": [_vp, _vp, C.POINTER(SsfmDesc), C.c_int, _dbl, _dbl, C.POINTER(_dbl), C.POINTER(_i32),
+                                 C.POINTER(_i32)],
     "plx_cde_create": [C.POINTER(_vp), _i64, _i64, _vp],
     "plx_cde_destroy": [_vp],
     "plx_cde_apply_dev": [_vp, _vp, _vp, _i64, C.c_int, _vp],

@@ -62,6 +62,13 @@ struct SsfmArgs {
     int p1, p2, nfc, dual, W, logW, T, logT, R, logR; // column tile: N1 rows x T complex (T = W*npol)
     int spm, xpm, manakov, pmd, nplates, brf_per_frame;
     int nframes; // frames of the current propagate call (kernels return at once when all are done)
+    // host-driven sub-steps of the adaptive scheme (adaptssfm, fiber.m:938-1009): step length, effective
+    // length and attenuation come from the launch arguments instead of the per-frame controller
+    int force;
+    double f_cur, f_leff, f_sc;
+    // resume the constant-phase loop after an adaptive first step (tolflag == 1, fiber.m:588-611)
+    int resume, ncycle0;
+    double dz0, zdone0;
     int dbg; // timing experiments only (PLX_SSFM_DBG): 1 skip column FFTs, 2 skip row FFTs, 4 skip Kerr math, 8 skip exp(-i beta dz)
     double alphalin, Lf, dzmax, dphimax, lcorr, invN;
 };
@@ -172,9 +179,16 @@ template <bool AGENT> __device__ __forceinline__ void ctrl_step(const SsfmArgs &
     }
     if (!c.started) {
         c.started = 1;
-        c.firstdz = dz;
-        c.zprop = dz;
-        c.ncycle = 1;
+        if (a.resume) { // fiber.m:604-611: dz proposed by the adaptive first step, already capped at dzmax
+            dz = a.dz0;
+            c.firstdz = a.zdone0;
+            c.zprop = a.zdone0 + dz;
+            c.ncycle = a.ncycle0 + 1;
+        } else {
+            c.firstdz = dz;
+            c.zprop = dz;
+            c.ncycle = 1;
+        }
     } else {
         c.zprop = c.zprop + dz;
         c.ncycle = c.ncycle + 1;
@@ -221,6 +235,52 @@ __global__ void k_ctrl(SsfmArgs a, int nframes)
     ctrl_step<false>(a, f);
 }
 
+// -------------------------------------------- adaptive scheme: element-wise pieces ---
+// nl_step (fiber.m:776-804) followed by the attenuation of the half/quarter step (:973,:979,...), scalar fields.
+__global__ __launch_bounds__(256) void k_nl_att(cplx *u, const double *gam, size_t N, int nfc, int spm, int xpm,
+                                                double leff, double att)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (size_t)gridDim.x * blockDim.x) {
+        double tot = 0;
+        if (xpm)
+            for (int k = 0; k < nfc; k++) {
+                const cplx v = u[(size_t)k * N + i];
+                tot += v.x * v.x + v.y * v.y;
+            }
+        for (int k = 0; k < nfc; k++) {
+            cplx v = u[(size_t)k * N + i];
+            if (spm || xpm) {
+                double pw = v.x * v.x + v.y * v.y;
+                if (xpm) pw = spm ? 2 * tot - pw : 2 * (tot - pw);
+                v = cmul(v, cexpi(-gam[k] * pw * leff));
+            }
+            u[(size_t)k * N + i] = cscale(v, att);
+        }
+    }
+}
+
+// est_err numerator max|u-uh| (:997) -> atomicMax on the bit pattern
+__global__ __launch_bounds__(256) void k_maxdiff(const cplx *u, const cplx *uh, size_t n, unsigned long long *out)
+{
+    PLX_DYN_LDS(lds);
+    double *red = (double *)lds;
+    double m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double dr = u[i].x - uh[i].x, di = u[i].y - uh[i].y;
+        const double e = sqrt(dr * dr + di * di);
+        m = e > m ? e : m;
+    }
+    block_atomic_max(m, red, out, threadIdx.x, blockDim.x);
+}
+
+// Richardson extrapolation u = 4/3*uh - 1/3*u (:1004)
+__global__ __launch_bounds__(256) void k_richardson(cplx *u, const cplx *uh, size_t n)
+{
+    const double c43 = 4.0 / 3, c13 = 1.0 / 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        u[i] = make_double2(c43 * uh[i].x - c13 * u[i].x, c43 * uh[i].y - c13 * u[i].y);
+}
+
 // ------------------------------------------------- scalar XPM row sum (:795) ---
 __global__ __launch_bounds__(256) void k_rowsum(SsfmArgs a)
 {
@@ -259,7 +319,7 @@ __global__ __launch_bounds__(256) void k_col_fwd(SsfmArgs a)
     lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, nthr);
     const size_t base = (size_t)fc << (a.p1 + a.p2);
     const int col0 = blockIdx.x * W;
-    const double leff = ctl->leff;
+    const double leff = a.force ? a.f_leff : ctl->leff;
     const double gam = a.gam[c], gamleff = gam * leff;
     const int nel = N1 << a.logW;
     if (a.dual) {
@@ -386,7 +446,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row(SsfmArgs a)
     }
     __syncthreads();
     if (!(a.dbg & 2)) row_fft_dif(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
-    const double cur = ctl->cur;
+    const double cur = a.force ? a.f_cur : ctl->cur;
     const double *bt = a.betat_p + (size_t)c * N + rowbase;
     if (!a.dual) {
         for (int e = tid; e < nel; e += nthr) { // Hf = fastexp(-betat*dz) :771
@@ -483,7 +543,7 @@ __global__ __launch_bounds__(256) void k_col_inv(SsfmArgs a)
     }
     __syncthreads();
     if (!(a.dbg & 1)) lds_fft_dit(s, a.p1, T, 1, a.logT, tw, tid, nthr, true);
-    const double sc = ctl->att * a.invN;
+    const double sc = a.force ? a.f_sc : ctl->att * a.invN;
     double m = 0;
     for (int e = tid; e < nel; e += nthr) {
         const int row = e >> a.logW, col = e & (W - 1);
@@ -1351,4 +1411,170 @@ extern "C" int plx_scalar_ssfm(double *ur, double *ui, const plx_ssfm_desc *desc
 {
     if (desc && desc->dual_pol) PLX_FAIL(PLX_ERR_ARG, "plx_scalar_ssfm: descriptor is dual-polarisation");
     return gateway_ssfm(ur, ui, nullptr, nullptr, desc, nullptr, nullptr, nullptr, firstdz, ncycle);
+}
+
+// ======================================================= adaptive-step scheme (scalar fields) ===
+// scalar_a_ssfm / adaptssfm (fiber.m:639-679, 938-1009) and the dphiadapt first step of scalar_ssfm
+// (:588-611).  The accept/reject decision needs the global max|u-uh| on the host every trial, so this
+// path is host-driven: the element-wise pieces are the kernels k_nl_att / k_maxdiff / k_richardson and
+// the linear operator reuses the three transform sweeps with the step length forced from the launch.
+namespace {
+struct Adaptive {
+    plx_ssfm *P;
+    SsfmArgs a;
+    hipStream_t st;
+    size_t n;      // nfc * N
+    cplx *u, *uh, *stack;
+    unsigned long long *d_max;
+    unsigned long long h_max;
+    double alphalin;
+    int fls2, fls3;
+
+    void lin(cplx *x, double dz)
+    { // lin_step(betat*dz, x): x = ifft(fft(x).*fastexp(-betat*dz))
+        SsfmArgs b = a;
+        b.ux = x; b.uy = nullptr; b.force = 1; b.spm = 0; b.xpm = 0; b.f_cur = dz; b.f_leff = 0; b.f_sc = b.invN;
+        const int N1 = 1 << b.p1, N2 = 1 << b.p2;
+        const dim3 gcol((unsigned)(N2 / b.W), (unsigned)b.nfc), grow((unsigned)(N1 / b.R), (unsigned)b.nfc);
+        PLX_LAUNCH(k_col_fwd, gcol, dim3(256), P->lds_col, st, b);
+        PLX_LAUNCH(k_row, grow, dim3(ROW_THREADS), P->lds_row, st, b);
+        PLX_LAUNCH(k_col_inv, gcol, dim3(256), P->lds_col, st, b);
+    }
+    void nl_att(cplx *x, double dz)
+    { // nl_step(alphalin,gam,dz,x,...) then x = x*exp(-halfalpha*dz)
+        const double leff = (alphalin == 0) ? dz : (1 - exp(-alphalin * dz)) / alphalin;
+        const double att = exp(-(0.5 * alphalin) * dz);
+        unsigned g = (unsigned)((P->N + 255) / 256);
+        if (g > 2048) g = 2048;
+        PLX_LAUNCH(k_nl_att, dim3(g), dim3(256), 0, st, x, (const double *)a.gam, P->N, a.nfc, fls2, fls3, leff, att);
+    }
+    // one trial of adaptssfm; returns <0 on HIP failure
+    int trial(double &zdone, double &dz, double trg_err, double safety, int &nrej, int &ncycle)
+    {
+        const double dz1 = dz, dz2 = 0.5 * dz1, dz4 = 0.25 * dz1;
+        if (hipMemcpyAsync(stack, u, n * sizeof(cplx), hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
+        if (hipMemcpyAsync(uh, u, n * sizeof(cplx), hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
+        nl_att(u, dz2); lin(u, dz1); nl_att(u, dz2);                                        // :972-979
+        nl_att(uh, dz4); lin(uh, dz2); nl_att(uh, dz2); lin(uh, dz2); nl_att(uh, dz4);      // :983-993
+        if (hipMemsetAsync(d_max, 0, sizeof(unsigned long long), st) != hipSuccess) return -1;
+        unsigned g = (unsigned)((n + 255) / 256);
+        if (g > 1024) g = 1024;
+        PLX_LAUNCH(k_maxdiff, dim3(g), dim3(256), 16 * sizeof(double), st, (const cplx *)u, (const cplx *)uh, n, d_max);
+        if (hipMemcpyAsync(&h_max, d_max, sizeof(h_max), hipMemcpyDeviceToHost, st) != hipSuccess) return -1;
+        if (hipStreamSynchronize(st) != hipSuccess) return -1;
+        double emax;
+        std::memcpy(&emax, &h_max, sizeof(double));
+        const double est_err = emax / dz1;                                                  // :997
+        if (est_err > trg_err) {                                                            // reject :999-1002
+            dz = safety * sqrt(trg_err / est_err) * dz1;
+            if (hipMemcpyAsync(u, stack, n * sizeof(cplx), hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
+            nrej = nrej + 1;
+        } else {                                                                            // accept :1003-1008
+            PLX_LAUNCH(k_richardson, dim3(g), dim3(256), 0, st, u, (const cplx *)uh, n);
+            zdone = zdone + dz1;
+            dz = safety * sqrt(trg_err / est_err) * dz1;
+            ncycle = ncycle + 1;
+        }
+        return 0;
+    }
+};
+
+// host copy of nextstep (fiber.m:682-715) from the per-channel maxima
+double host_nextstep(double dzmax, double phimax, const double *gam, const double *umax, int nfc, double alphalin, double *pmax_out)
+{
+    double Pmax = -INFINITY;
+    for (int k = 0; k < nfc; k++) { const double gp = gam[k] * umax[k]; Pmax = gp > Pmax ? gp : Pmax; }
+    if (pmax_out) *pmax_out = Pmax;
+    const double leff = phimax / Pmax, dl = alphalin * leff;
+    if (dl >= 1) return dzmax;
+    const double step = (alphalin == 0) ? leff : -1 / alphalin * log(1 - dl);
+    return step > dzmax ? dzmax : step;
+}
+} // namespace
+
+extern "C" int plx_scalar_ssfm_adaptive(double *ur, double *ui, const plx_ssfm_desc *desc, int tolflag, double ltol,
+                                        double safety, double *firstdz, int32_t *ncycle_out, int32_t *nrej_out)
+{
+    if (!ur || !ui || !desc) PLX_FAIL(PLX_ERR_ARG, "plx_scalar_ssfm_adaptive: null argument");
+    if (desc->dual_pol) PLX_FAIL(PLX_ERR_REFERENCE, "adaptive step available in absence of polarization effects"); // fiber.m:374
+    if (tolflag != 1 && tolflag != 2) PLX_FAIL(PLX_ERR_ARG, "plx_scalar_ssfm_adaptive: tolflag must be 1 or 2");
+    plx_ssfm_desc d = *desc;
+    d.max_frames = 1;
+    plx_ssfm *P = nullptr;
+    int rc = plx_ssfm_create(&P, &d);
+    if (rc) return rc;
+    const size_t n = (size_t)d.nfft * d.nfc;
+    std::vector<double> h(2 * n);
+    for (size_t i = 0; i < n; i++) { h[2 * i] = ur[i]; h[2 * i + 1] = ui[i]; }
+    Adaptive A;
+    A.P = P; A.a = P->a; A.st = nullptr; A.n = n; A.u = A.uh = A.stack = nullptr; A.d_max = nullptr;
+    A.a.nframes = 1; A.alphalin = d.alphalin; A.fls2 = d.fls[2]; A.fls3 = d.fls[3];
+    auto cleanup = [&]() { hipFree(A.u); hipFree(A.uh); hipFree(A.stack); hipFree(A.d_max); plx_ssfm_destroy(P); };
+    if (hipMalloc((void **)&A.u, n * sizeof(cplx)) != hipSuccess || hipMalloc((void **)&A.uh, n * sizeof(cplx)) != hipSuccess ||
+        hipMalloc((void **)&A.stack, n * sizeof(cplx)) != hipSuccess || hipMalloc((void **)&A.d_max, 64) != hipSuccess ||
+        hipMemcpy(A.u, h.data(), n * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(P->d_ctl, 0, sizeof(FrameCtl)) != hipSuccess || hipMemset(P->d_ndone, 0, 64) != hipSuccess ||
+        hipMemset(P->d_umax, 0, sizeof(unsigned long long) * d.nfc) != hipSuccess) {
+        cleanup();
+        PLX_FAIL(PLX_ERR_HIP, "plx_scalar_ssfm_adaptive: device allocation/upload failed");
+    }
+    // first step from nextstep (:585 / :666): per-channel maxima of |u|^2
+    std::vector<unsigned long long> um(d.nfc);
+    {
+        SsfmArgs b = A.a;
+        b.ux = A.u; b.uy = nullptr;
+        unsigned gx = (unsigned)((P->N + 255) / 256);
+        if (gx > 64) gx = 64;
+        PLX_LAUNCH(k_umax, dim3(gx, (unsigned)d.nfc), dim3(256), 16 * sizeof(double), nullptr, b);
+        if (hipMemcpy(um.data(), P->d_umax, sizeof(unsigned long long) * d.nfc, hipMemcpyDeviceToHost) != hipSuccess) {
+            cleanup();
+            PLX_FAIL(PLX_ERR_HIP, "plx_scalar_ssfm_adaptive: readback failed");
+        }
+    }
+    std::vector<double> umax(d.nfc), gam(d.gam, d.gam + d.nfc);
+    for (int k = 0; k < d.nfc; k++) std::memcpy(&umax[k], &um[k], sizeof(double));
+    double maxpow = 0;
+    double dphimaxt = d.dphimaxt;
+    double dz = host_nextstep(d.dzmaxt, dphimaxt, gam.data(), umax.data(), d.nfc, d.alphalin, &maxpow);
+    int ncycle = 1, nrej = 0;
+    const double Lf = d.length;
+    if (tolflag == 2) { // scalar_a_ssfm :664-679
+        *firstdz = dz;
+        double zdone = 0;
+        while (zdone < Lf) {
+            if (zdone + dz > Lf) dz = Lf - zdone;
+            if (A.trial(zdone, dz, ltol, safety, nrej, ncycle)) { cleanup(); PLX_FAIL(PLX_ERR_HIP, "plx_scalar_ssfm_adaptive: HIP failure in adaptssfm"); }
+            if (dz > d.dzmaxt) dz = d.dzmaxt;
+        }
+        rc = (hipMemcpy(h.data(), A.u, n * sizeof(cplx), hipMemcpyDeviceToHost) == hipSuccess) ? PLX_OK : PLX_ERR_HIP;
+    } else { // dphiadapt: adaptive first step, then the constant-phase loop (:588-636)
+        if (dz >= d.dzmaxt) { // :589-597
+            if (d.alphalin == 0) dphimaxt = maxpow * dz;
+            else dphimaxt = maxpow * (1 - exp(-d.alphalin * dz)) / d.alphalin;
+        }
+        const double dzini = dz;
+        double zdone = 0;
+        while (zdone == 0) {
+            int nc = 0;
+            nrej = 0;
+            if (A.trial(zdone, dz, ltol, safety, nrej, nc)) { cleanup(); PLX_FAIL(PLX_ERR_HIP, "plx_scalar_ssfm_adaptive: HIP failure in adaptssfm"); }
+            ncycle = nc;
+        }
+        if (dz > d.dzmaxt) dz = d.dzmaxt;
+        dphimaxt = dphimaxt * (1 - exp(-d.alphalin * zdone)) / (1 - exp(-d.alphalin * dzini)); // :607
+        P->a.resume = 1; P->a.dz0 = dz; P->a.zdone0 = zdone; P->a.ncycle0 = ncycle; P->a.dphimax = dphimaxt;
+        rc = plx_ssfm_propagate_dev(P, (double *)A.u, nullptr, 1, nullptr);
+        if (!rc) {
+            rc = (hipMemcpy(h.data(), A.u, n * sizeof(cplx), hipMemcpyDeviceToHost) == hipSuccess) ? PLX_OK : PLX_ERR_HIP;
+            *firstdz = P->h_ctl[0].firstdz;
+            ncycle = P->h_ctl[0].ncycle;
+        }
+    }
+    cleanup();
+    if (rc == PLX_ERR_HIP) plx_set_error("plx_scalar_ssfm_adaptive: download failed");
+    if (rc) return rc;
+    for (size_t i = 0; i < n; i++) { ur[i] = h[2 * i]; ui[i] = h[2 * i + 1]; }
+    if (ncycle_out) *ncycle_out = ncycle;
+    if (nrej_out) *nrej_out = nrej;
+    return PLX_OK;
 }

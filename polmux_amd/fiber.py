@@ -121,8 +121,11 @@ def fiber(x, flag=None, rng=None):
     nfc, nfft = fx.shape
     if not _has(x, "dzmax") or x["dzmax"] > x["length"]:
         x["dzmax"] = x["length"]                                              # :139-141
-    if _has(x, "ltol"):
-        raise NotImplementedError("adaptive step (x.ltol, fiber.m:143-151,372-378) is not on the device yet")
+    tolflag = 0
+    if _has(x, "ltol"):                                                       # adaptive step-size, :143-151
+        if not _has(x, "dphimax"):
+            x["dphimax"] = math.inf
+        tolflag = 1 if x.get("dphiadapt") else 2
     fls, dphimaxt, dzmaxt = parse_flag(flag, nfc, x)
     isy = GSTATE.FIELDY is not None and GSTATE.FIELDY.numel() > 0
     isv = fls[1] == 1 or isy
@@ -164,6 +167,25 @@ def fiber(x, flag=None, rng=None):
 
     lib = _abi.get()
     gam = np.ascontiguousarray(t["gam"], dtype=float)
+    if tolflag == 2 and isv:
+        raise ValueError("adaptive step available in absence of polarization effects")   # :374
+    if tolflag and not isv:
+        # scalar_a_ssfm / dphiadapt (:376-377, :386-387): host-driven scheme behind one gateway call
+        from .gstate import to_device_field, to_host_field
+        d = _abi.SsfmDesc()
+        d.nfft, d.nfc, d.dual_pol, d.max_frames = nfft, nfc, 0, 1
+        for i in range(4):
+            d.fls[i] = fls[i]
+        d.dzmaxt, d.dphimaxt, d.alphalin, d.length, d.nplates, d.manakov = dzmaxt, dphimaxt, t["alphalin"], x["length"], 1, 0
+        d.gam, d.betat, d.db1 = gam.ctypes.data, t["betat"].ctypes.data, t["db1"].ctypes.data
+        u = to_host_field(fx)
+        ur, ui = np.asfortranarray(u.real.copy()), np.asfortranarray(u.imag.copy())
+        first, ncyc, nrej = C.c_double(), C.c_int32(), C.c_int32()
+        lib.call("plx_scalar_ssfm_adaptive", ur.ctypes.data, ui.ctypes.data, C.byref(d), tolflag, float(x["ltol"]),
+                 SAFETYFCT, C.byref(first), C.byref(ncyc), C.byref(nrej))
+        GSTATE.FIELDX = to_device_field(ur + 1j * ui)
+        fiber.last = dict(firstdz=first.value, ncycle=ncyc.value, nrej=nrej.value)
+        return None
     key = (nfft, nfc, int(isv), tuple(fls), dzmaxt, dphimaxt, t["alphalin"], x["length"], nplates, manakov,
            gam.tobytes(), t["betat"].tobytes(), t["db1"].tobytes())
 

@@ -97,6 +97,7 @@ def create_field(ftype, sigx, sigy=None, options=None):
     sigx = np.asarray(sigx, dtype=np.complex128)
     if sigx.ndim == 1:
         sigx = sigx.reshape(-1, 1)
+    GSTATE.FIELDY = GSTATE.FIELDY_TX = None
     isy = sigy is not None and np.size(sigy) > 0
     if isy:
         sigy = np.asarray(sigy, dtype=np.complex128).reshape(sigx.shape)

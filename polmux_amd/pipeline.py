@@ -69,6 +69,8 @@ class HotPath:
         self.ssfm = C.c_void_p()
         self.lib.call("plx_ssfm_create", C.byref(self.ssfm), C.byref(d))
         self.nplates = nplates
+        if self.pmd:   # Monte-Carlo style: an independent random birefringence draw per frame (fiber.m:274-276)
+            self.set_random_pmd(range(self.F))
         # --- Tx (host, once): Run_my_PDM_QPSK.m:101-117 ---
         ux, uy, bits, power = synth.pdm_qpsk_field(cfg.nsymb, cfg.nt, cfg.pavg_mw)
         self.tx_host = (ux, uy)

@@ -315,3 +315,26 @@ def test_emu_fused_and_persistent_variants(emu, oracle, monkeypatch):
             rc, ofd, onc, ox, oy = ref[f]
             assert ncyc[f] == onc
             assert np.abs(gx[f] - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
+
+
+@pytest.mark.parametrize("tolflag", [2, 1])
+def test_emu_adaptive_ssfm(emu, oracle, tolflag):
+    """scalar_a_ssfm / adaptssfm (fiber.m:639-679, 938-1009) and the dphiadapt first step (:588-611)."""
+    n, nt, nfc, L = 512, 8, 2, 1.2e4
+    fls = [1, 0, 1, 1]
+    betat, db1 = _tables(n, nt, fls, 1, nfc)
+    u = np.asfortranarray(np.stack([_qpsk_field(n, nt, 6.0, (2 + k, 5 + k))[0] for k in range(nfc)], 1))
+    gam = [1.2e-6, 1.3e-6]
+    dph = np.inf if tolflag == 2 else 2e-2
+    d = _desc(n, nfc, 0, fls, L, 4.6e-5, gam, L, dph, betat, db1)
+    ur, ui = np.asfortranarray(u.real.copy()), np.asfortranarray(u.imag.copy())
+    fd, nc, nr = C.c_double(), C.c_int32(), C.c_int32()
+    emu.call("plx_scalar_ssfm_adaptive", _vp(ur), _vp(ui), C.byref(d), tolflag, 1e-6, 0.9, C.byref(fd), C.byref(nc), C.byref(nr))
+    if tolflag == 2:
+        ofd, onc, onrej, ou = oracle.scalar_a_ssfm(u, betat, L, dph, gam, 4.6e-5, L, 1e-6, 0.9, fls)
+        assert nr.value == onrej and onc > 3
+    else:
+        ofd, onc, ou = oracle.scalar_ssfm(u, betat, L, dph, gam, 4.6e-5, L, fls, tolflag=1, trg_err=1e-6, trg_safety=0.9)
+        assert onc > 3
+    assert nc.value == onc and fd.value == pytest.approx(ofd, rel=1e-9)
+    assert np.abs((ur + 1j * ui) - ou).max() < 1e-9 * np.abs(ou).max()

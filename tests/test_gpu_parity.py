@@ -551,3 +551,44 @@ def test_optin_sweep_variants_match_oracle(lib, oracle, monkeypatch, var):
         assert np.abs(gx[f] - ox[:, 0]).max() <= FIELD_RTOL * np.abs(ox).max()
         assert np.abs(gy[f] - oy[:, 0]).max() <= FIELD_RTOL * np.abs(oy).max()
     assert len(set(ncyc.tolist())) > 3
+
+
+@pytest.mark.parametrize("tolflag", [2, 1])
+def test_adaptive_step_ssfm_vs_oracle(lib, oracle, tolflag):
+    """x.ltol: scalar_a_ssfm + adaptssfm (fiber.m:639-679, 938-1009); x.dphiadapt: adaptive first step then the
+    constant-phase loop (fiber.m:588-611) -- through fiber(x, flag) on GSTATE."""
+    import polmux_amd as px
+    from polmux_amd import synth
+    from polmux_amd.fiber import fiber_tables, parse_flag
+    from polmux_amd.gstate import GSTATE, to_host_field
+    nsymb, nt = 64, 16
+    px.reset_all(nsymb, nt, 1)
+    GSTATE.SYMBOLRATE = 28.0
+    px.lasersource(6.0, 1550.0)
+    sx, _, _, _ = synth.pdm_qpsk_field(nsymb, nt, 12.0)
+    px.create_field("sepfields", sx, None, dict(power="average"))
+    u0 = to_host_field(GSTATE.FIELDX)
+    x = dict(length=4e4, alphadB=0.2, aeff=80.0, n2=2.7e-20, disp=17.0, slope=0.0, ltol=1e-6)
+    x["lambda"] = 1550.0
+    if tolflag == 1:
+        x.update(dphiadapt=True, dphimax=2e-2, dzmax=2e4)
+    px.fiber(x, "g-s-")
+    got = to_host_field(GSTATE.FIELDX)
+    xx = dict(x)
+    xx.setdefault("dphimax", np.inf)
+    xx.setdefault("dzmax", x["length"])
+    fls, dph, dzm = parse_flag("g-s-", 1, xx)
+    t = fiber_tables(xx, fls, 1, 0.0)
+    if tolflag == 2:
+        ofd, onc, onrej, ou = oracle.scalar_a_ssfm(u0, t["betat"], dzm, dph, t["gam"], t["alphalin"], 4e4, 1e-6, 0.9, fls)
+        assert px.fiber.last["nrej"] == onrej
+    else:
+        ofd, onc, ou = oracle.scalar_ssfm(u0, t["betat"], dzm, dph, t["gam"], t["alphalin"], 4e4, fls, tolflag=1, trg_err=1e-6,
+                                          trg_safety=0.9)
+    assert px.fiber.last["ncycle"] == onc and onc > 3
+    assert px.fiber.last["firstdz"] == pytest.approx(ofd, rel=1e-9)
+    assert np.abs(got - ou).max() <= FIELD_RTOL * np.abs(ou).max()
+    # with polarisation effects the reference refuses (fiber.m:374)
+    px.create_field("sepfields", sx, sx, dict(power="average"))
+    with pytest.raises(ValueError, match="adaptive step available in absence of polarization effects"):
+        px.fiber(dict(x, ltol=1e-6, dphiadapt=False), "g-s-")
