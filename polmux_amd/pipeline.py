@@ -184,6 +184,27 @@ class HotPath:
                       self.err.data_ptr(), st)
         return self.err[:F]
 
+    def errors_resolved(self, F):
+        """Per-frame bit errors after resolving what a blind receiver cannot know: the pi/2 phase
+        ambiguity of the Viterbi&Viterbi estimate (per polarisation) and which CMA output carries which
+        transmitted tributary (the pol-swap check of ex20_coherent_polmux.m:160-173).  Eight calls of
+        the device decision/count kernel; returns an int64 tensor [F]."""
+        torch = self.torch
+        base = self.sym[:F].clone()
+        pats = (self.pat, torch.cat([self.pat[2:], self.pat[:2]]).contiguous())
+        best = []
+        for pat in pats:
+            b = None
+            for k in range(4):
+                self.sym[:F] = base * (1j ** k)
+                self.lib.call("plx_decide_count_dev", self.sym.data_ptr(), self.cfg.nsymb, 2, F, pat.data_ptr(), None,
+                              self.err.data_ptr(), self.stream())
+                e = self.err[:F].clone()
+                b = e if b is None else torch.minimum(b, e)
+            best.append(b.sum(1))
+        self.sym[:F] = base
+        return torch.minimum(best[0], best[1])
+
     def errors_min_over_rotations(self, F):
         """Resolve the pi/2 ambiguity of the blind phase estimate per polarisation (host-side
         convenience for BER sanity; the reference's scripts use differential decoding instead)."""
@@ -206,3 +227,49 @@ class HotPath:
     def ssfm_stats(self):
         """(row-pass launches, sample-steps) of the last fibre() call, summed over its frame groups"""
         return self._rows, self._steps
+
+
+class McCampaign:
+    """Monte-Carlo BER over random PMD + ASE realisations (the ex20-style loop around ber_estimate,
+    with ex24's random-birefringence fibre): realisation r gets its own birefringence draw and its own
+    noise, both keyed by r alone, so any sharding of the indices over GPUs gives the same counts."""
+
+    def __init__(self, cfg, frames_per_call, noise_sigma):
+        self.hp = HotPath(cfg, frames_per_call)
+        self.F = frames_per_call
+        self.sigma = noise_sigma
+
+    @property
+    def bits_per_realisation(self):
+        return 4 * self.hp.cfg.nsymb
+
+    def simulate(self, indices):
+        import torch
+        hp = self.hp
+        out = []
+        for i0 in range(0, len(indices), self.F):
+            idx = list(indices[i0:i0 + self.F])
+            n = len(idx)
+            if hp.pmd:
+                hp.set_random_pmd(idx)
+            ux, uy = hp.make_batch(n)
+            hp.fibre(ux, uy)
+            # receive() without its own noise; ASE keyed by realisation index is added here
+            cfg, st = hp.cfg, hp.stream()
+            rx = hp.rx[:n]
+            for pol, src in enumerate((ux, uy)):
+                hp.lib.call("plx_pick_dev", src.data_ptr(), rx.data_ptr() + pol * hp.Lrx * 16, cfg.nfft, hp.Lrx, 0,
+                            cfg.nt // 2, hp.rx_scale, n, 2 * hp.Lrx, st)
+            if self.sigma:
+                for k, r in enumerate(idx):
+                    g = torch.Generator(device=hp.dev)
+                    g.manual_seed(20260101 * 1000003 + int(r))
+                    nz = torch.randn((2, hp.Lrx, 2), generator=g, device=hp.dev, dtype=torch.float64)
+                    rx[k] += self.sigma * torch.view_as_complex(nz)
+            hp.lib.call("plx_cde_apply_dev", hp.cde, rx.data_ptr(), hp.eq.data_ptr(), hp.Lrx, 2 * n, st)
+            hp.lib.call("plx_dsp_run_dev", hp.dsp, hp.eq.data_ptr(), hp.sym.data_ptr(), n, st)
+            out.append(hp.errors_resolved(n).cpu().numpy())
+        return np.concatenate(out) if out else np.zeros(0, np.int64)
+
+    def close(self):
+        self.hp.close()

@@ -592,3 +592,30 @@ def test_adaptive_step_ssfm_vs_oracle(lib, oracle, tolflag):
     px.create_field("sepfields", sx, sx, dict(power="average"))
     with pytest.raises(ValueError, match="adaptive step available in absence of polarization effects"):
         px.fiber(dict(x, ltol=1e-6, dphiadapt=False), "g-s-")
+
+
+def test_monte_carlo_campaign_is_sharding_invariant(lib):
+    """ex24/ex20-style Monte-Carlo: random PMD + ASE realisations keyed by their index give the same error
+    counts whatever the batch composition, and the sequential ber_estimate replay stops at the same realisation."""
+    from polmux_amd import mc, pipeline
+    cfg = pipeline.HotPathConfig(nsymb=256, nt=16, flag="gps-", nplates=10, dgd=0.2, length=4e4, pavg_mw=1.0, cma_mu=1 / 600,
+                                 freqavg=50, dphimax=2e-2)
+    a = pipeline.McCampaign(cfg, frames_per_call=8, noise_sigma=0.28)
+    b = pipeline.McCampaign(cfg, frames_per_call=3, noise_sigma=0.28)
+    idx = list(range(12))
+    ea = a.simulate(idx)
+    eb = np.concatenate([b.simulate(idx[7:]), b.simulate(idx[:7])])
+    np.testing.assert_array_equal(ea, np.concatenate([eb[5:], eb[:5]]))
+    assert ea.sum() > 0 and ea.max() < a.bits_per_realisation // 4          # noisy but locked
+    x = dict(stop=(0.5, 68), nmin=20)
+    r1 = mc.ShardedBer(a.simulate, a.bits_per_realisation, x, per_rank_per_round=8).run(max_realisations=64)
+    r2 = mc.ShardedBer(b.simulate, b.bits_per_realisation, x, per_rank_per_round=3).run(max_realisations=64)
+    for u, v in zip(r1, r2):
+        np.testing.assert_array_equal(np.asarray(u, dtype=float), np.asarray(v, dtype=float))
+    assert 1e-4 < r1[1][0] < 0.2
+    # noise-free: every realisation demultiplexes once ambiguities are resolved (a stray error may sit at the
+    # frame edges, where OverlapBothTrans zero-pads, CDE_OFDE.m:92-102)
+    c = pipeline.McCampaign(cfg, frames_per_call=8, noise_sigma=0.0)
+    assert c.simulate(list(range(8))).max() <= 2
+    for m in (a, b, c):
+        m.close()
