@@ -181,6 +181,16 @@ int64_t plx_dsp_out_len(const plx_dsp *plan);
 int plx_decide_count_dev(const double *d_sym, int64_t L, int32_t ncol, int nframes, const uint8_t *d_pat,
                          uint8_t *d_pat_hat, int64_t *d_err, void *stream);
 
+/* ----------------------------------------------------------------- ampliflat --- */
+/* ampliflat(x,'gain',options), ampliflat.m:60-148 ("next" row): FIELD *= sqrt(gain) and
+ * FIELD += sigma(c) * n with n complex Gaussian, E|Re n|^2 = E|Im n|^2 = 1.  sigma: host [nfc] (NULL/0 = no
+ * ASE, :91-105).  d_noise: optional injected noise like options.noise [frame][X cols | Y cols][nfft] complex
+ * (:123-129, the parity route); otherwise a counter-based Philox-4x32-10 stream keyed by (seed, d_keys[frame] or
+ * frame).  asex/asey: ASE on x / y (options.onepol, :107-118).  d_uy may be NULL (single polarisation).        */
+int plx_ampliflat_dev(double *d_ux, double *d_uy, int64_t nfft, int32_t nfc, int nframes, double gain_lin,
+                      const double *sigma, const double *d_noise, uint64_t seed, const int64_t *d_keys,
+                      int32_t asex, int32_t asey, void *stream);
+
 /* ------------------------------------------------------------ small helpers --- */
 /* strided pick + scale used between fibre and CDE when the full front end
  * (receiver_cohmix + decimate) is not in the chain:

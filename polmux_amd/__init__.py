@@ -8,9 +8,10 @@ hand-written gfx950 kernels behind the C ABI of include/polmux_hip.h
 from ._abi import PolmuxError  # noqa: F401
 from .gstate import CONSTANTS, GSTATE, create_field, lasersource, reset_all  # noqa: F401
 from .fiber import fiber  # noqa: F401
+from .ampliflat import ampliflat  # noqa: F401
 from .rx import (CDE_OFDE, DspPdmCohQpsk, cmaadaptivefilter, easiadaptivefilter, fastexp, samp2pat)  # noqa: F401
 from .mc import ber_estimate, mc_estimate  # noqa: F401
 
-__all__ = ["PolmuxError", "GSTATE", "CONSTANTS", "reset_all", "create_field", "lasersource", "fiber", "CDE_OFDE",
+__all__ = ["PolmuxError", "GSTATE", "CONSTANTS", "reset_all", "create_field", "lasersource", "fiber", "ampliflat", "CDE_OFDE",
            "DspPdmCohQpsk", "cmaadaptivefilter", "easiadaptivefilter", "fastexp", "samp2pat", "ber_estimate",
            "mc_estimate"]

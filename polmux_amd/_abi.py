@@ -73,6 +73,7 @@ SIGNATURES = {
     "plx_dsp_run_dev": [_vp, _vp, _vp, C.c_int, _vp],
     "plx_dsp_out_len": [_vp],
     "plx_decide_count_dev": [_vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _vp],
+    "plx_ampliflat_dev": [_vp, _vp, _i64, _i32, C.c_int, _dbl, _vp, _vp, C.c_uint64, _vp, _i32, _i32, _vp],
     "plx_pick_dev": [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, C.c_int, _i64, _vp],
 }
 _RESTYPES = {"plx_dsp_out_len": _i64}

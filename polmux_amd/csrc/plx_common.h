@@ -31,11 +31,48 @@ __device__ __forceinline__ cplx cscale(cplx a, double s) { return make_double2(a
 __device__ __forceinline__ cplx cconj(cplx a) { return make_double2(a.x, -a.y); }
 __device__ __forceinline__ cplx cmuli(cplx a) { return make_double2(-a.y, a.x); }  // a * i
 __device__ __forceinline__ cplx cmulni(cplx a) { return make_double2(a.y, -a.x); } // a * (-i)
+// component-wise select (a ternary on two struct lvalues becomes a select of POINTERS, which pins
+// register arrays into scratch memory)
+__device__ __forceinline__ cplx csel(bool c, cplx a, cplx b) { return make_double2(c ? a.x : b.x, c ? a.y : b.y); }
 __device__ __forceinline__ cplx cexpi(double a)
 {
     double s, c;
     sincos(a, &s, &c);
     return make_double2(c, s);
+}
+
+// exp(-i*2*pi*x) for a phase x given in TURNS.  The linear step's phases betat*dz reach 1e4 rad; the
+// general sincos spends ~100 instructions on range reduction.  With the phase tables stored in turns the
+// reduction is exact (x - rint(x)), a quadrant split brings the angle to |psi| <= pi/4, and odd/even
+// Taylor polynomials to x^17 / x^16 (truncation < 1e-16) finish in ~30 FMAs.  The product x = turns*dz
+// carries the same 1e-16 relative rounding as the reference's betat*dz, i.e. ~1e-12 rad at 1e4 rad.
+__device__ __forceinline__ cplx cexp_neg_turns(double x)
+{
+    const double r = x - rint(x);            // [-0.5, 0.5] turns, exact
+    const double q = rint(4.0 * r);          // quadrant -2..2
+    const double psi = (r - 0.25 * q) * 6.28318530717958647692; // [-pi/4, pi/4]
+    const double z = psi * psi;
+    double ps = fma(z, 1.0 / 355687428096000.0, -1.0 / 1307674368000.0);
+    ps = fma(z, ps, 1.0 / 6227020800.0);
+    ps = fma(z, ps, -1.0 / 39916800.0);
+    ps = fma(z, ps, 1.0 / 362880.0);
+    ps = fma(z, ps, -1.0 / 5040.0);
+    ps = fma(z, ps, 1.0 / 120.0);
+    ps = fma(z, ps, -1.0 / 6.0);
+    const double sn = fma(psi * z, ps, psi);
+    double pc = fma(z, 1.0 / 20922789888000.0, -1.0 / 87178291200.0);
+    pc = fma(z, pc, 1.0 / 479001600.0);
+    pc = fma(z, pc, -1.0 / 3628800.0);
+    pc = fma(z, pc, 1.0 / 40320.0);
+    pc = fma(z, pc, -1.0 / 720.0);
+    pc = fma(z, pc, 1.0 / 24.0);
+    pc = fma(z, pc, -0.5);
+    const double cs = fma(z, pc, 1.0);
+    // angle = psi + q*pi/2; result = cos(angle) - i sin(angle)
+    const int qi = (int)q & 3;               // -2 -> 2, -1 -> 3
+    const double c = (qi == 0) ? cs : (qi == 1) ? -sn : (qi == 2) ? -cs : sn;
+    const double sI = (qi == 0) ? sn : (qi == 1) ? cs : (qi == 2) ? -sn : -cs;
+    return make_double2(c, -sI);
 }
 
 // Keep a batch of global loads issued back-to-back: an empty asm that "uses" the loaded value
@@ -47,6 +84,23 @@ __device__ __forceinline__ void pin(double &) {}
 #else
 __device__ __forceinline__ void pin(cplx &v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
 __device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
+#endif
+
+// ---- DPP lane exchange inside a 16-lane row (no LDS crossbar on the critical path) ----
+// xor-1 / xor-2 are quad permutes; 7 and 15 are the row_half_mirror / row_mirror pairings
+// (lane i <-> 7-i, i <-> 15-i), valid butterfly partners once the lower levels are reduced;
+// 8 is row_ror:8 (lane i <-> i^8: the two halves of a row swap).
+#ifdef PLX_EMU
+template <int X> __device__ __forceinline__ double lane_xchg(double v) { return __shfl_xor(v, X, 64); }
+#else
+template <int X> __device__ __forceinline__ double lane_xchg(double v)
+{
+    constexpr int ctrl = X == 1 ? 0xB1 : X == 2 ? 0x4E : X == 7 ? 0x141 : X == 8 ? 0x128 : 0x140;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
 #endif
 
 // ---- agent-scope (whole-GPU) relaxed atomics for words shared between workgroups INSIDE a launch:

@@ -175,6 +175,53 @@ __device__ __forceinline__ void r16_dit(cplx *x)
     }
 }
 
+// Second level of a 256-point transform held in registers: y[k] is point j + 16k of the transform
+// (k = r1 + 4 r2).  Stages m = 64 (q = 16) and m = 256 (q = 64) only combine points that share j, so
+// with the 16-point blocks done by r16_dit / r16_dif a 256-point column transform needs ONE LDS
+// exchange instead of four read+write passes.  tw: half table W_256^k, k < 128.
+__device__ __forceinline__ void lvl2_dit256(cplx *y, int j, const cplx *tw)
+{
+    const int k6 = 4 * j;
+    const cplx u1 = tw[k6], u2 = tw[2 * k6], u3 = tw3(tw, 3 * k6, 128);
+#pragma unroll
+    for (int r2 = 0; r2 < 4; r2++) { // m = 64
+        cplx c0 = y[4 * r2], c2 = y[4 * r2 + 1], c1 = y[4 * r2 + 2], c3 = y[4 * r2 + 3];
+        if (j) { c1 = cmulc(c1, u1); c2 = cmulc(c2, u2); c3 = cmulc(c3, u3); }
+        const cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
+        y[4 * r2] = cadd(s0, s2); y[4 * r2 + 1] = cadd(s1, s3); y[4 * r2 + 2] = csub(s0, s2); y[4 * r2 + 3] = csub(s1, s3);
+    }
+#pragma unroll
+    for (int r1 = 0; r1 < 4; r1++) { // m = 256
+        const int k8 = j + 16 * r1;
+        cplx c0 = y[r1], c2 = y[r1 + 4], c1 = y[r1 + 8], c3 = y[r1 + 12];
+        if (k8) { c1 = cmulc(c1, tw[k8]); c2 = cmulc(c2, tw[2 * k8]); c3 = cmulc(c3, tw3(tw, 3 * k8, 128)); }
+        const cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
+        y[r1] = cadd(s0, s2); y[r1 + 4] = cadd(s1, s3); y[r1 + 8] = csub(s0, s2); y[r1 + 12] = csub(s1, s3);
+    }
+}
+__device__ __forceinline__ void lvl2_dif256(cplx *y, int j, const cplx *tw)
+{
+#pragma unroll
+    for (int r1 = 0; r1 < 4; r1++) { // m = 256
+        const int k8 = j + 16 * r1;
+        const cplx a0 = y[r1], a1 = y[r1 + 4], a2 = y[r1 + 8], a3 = y[r1 + 12];
+        const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
+        cplx y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+        if (k8) { y1 = cmul(y1, tw[k8]); y2 = cmul(y2, tw[2 * k8]); y3 = cmul(y3, tw3(tw, 3 * k8, 128)); }
+        y[r1] = cadd(t0, t2); y[r1 + 4] = y2; y[r1 + 8] = y1; y[r1 + 12] = y3;
+    }
+    const int k6 = 4 * j;
+    const cplx u1 = tw[k6], u2 = tw[2 * k6], u3 = tw3(tw, 3 * k6, 128);
+#pragma unroll
+    for (int r2 = 0; r2 < 4; r2++) { // m = 64
+        const cplx a0 = y[4 * r2], a1 = y[4 * r2 + 1], a2 = y[4 * r2 + 2], a3 = y[4 * r2 + 3];
+        const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
+        cplx y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+        if (j) { y1 = cmul(y1, u1); y2 = cmul(y2, u2); y3 = cmul(y3, u3); }
+        y[4 * r2] = cadd(t0, t2); y[4 * r2 + 1] = y2; y[4 * r2 + 2] = y1; y[4 * r2 + 3] = y3;
+    }
+}
+
 // T = 1<<logT padded rows of M = 1<<logM (M >= 16) points each, row t at s + t*row_pitch(M).
 __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
 {

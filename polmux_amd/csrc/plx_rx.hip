@@ -176,21 +176,6 @@ __global__ __launch_bounds__(256) void k_cma(DemuxArgs a)
     if (frame_ok && t == 0 && a.passes) a.passes[f] = npass;
 }
 
-// ---- DPP lane exchange inside a 16-lane row (no LDS crossbar on the critical path) ----
-// xor-1 / xor-2 are quad permutes; 7 and 15 are the row_half_mirror / row_mirror pairings
-// (lane i <-> 7-i, i <-> 15-i), valid butterfly partners once the lower levels are reduced.
-#ifdef PLX_EMU
-template <int X> __device__ __forceinline__ double lane_xchg(double v) { return __shfl_xor(v, X, 64); }
-#else
-template <int X> __device__ __forceinline__ double lane_xchg(double v)
-{
-    constexpr int ctrl = X == 1 ? 0xB1 : X == 2 ? 0x4E : X == 7 ? 0x141 : 0x140;
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-#endif
 __device__ __forceinline__ double sum8(double v)
 {
     v += lane_xchg<1>(v);

@@ -105,6 +105,23 @@ __device__ __forceinline__ void sincos_small(double a, double *s, double *c)
     }
 }
 
+// branch-free Taylor form (callers guarantee |a| < 2^-4)
+__device__ __forceinline__ void sincos_taylor(double a, double *s, double *c)
+{
+    const double z = a * a;
+    double ps = fma(z, -1.0 / 39916800.0, 1.0 / 362880.0);
+    ps = fma(z, ps, -1.0 / 5040.0);
+    ps = fma(z, ps, 1.0 / 120.0);
+    ps = fma(z, ps, -1.0 / 6.0);
+    *s = fma(a * z, ps, a);
+    double pc = fma(z, 1.0 / 479001600.0, -1.0 / 3628800.0);
+    pc = fma(z, pc, 1.0 / 40320.0);
+    pc = fma(z, pc, -1.0 / 720.0);
+    pc = fma(z, pc, 1.0 / 24.0);
+    pc = fma(z, pc, -0.5);
+    *c = fma(z, pc, 1.0);
+}
+
 // block-wide max -> one atomicMax.  red: LDS scratch of >= 16 doubles.
 __device__ __forceinline__ void block_atomic_max(double v, double *red, unsigned long long *dst, int tid, int nthr)
 {
@@ -451,13 +468,13 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row(SsfmArgs a)
     if (!a.dual) {
         for (int e = tid; e < nel; e += nthr) { // Hf = fastexp(-betat*dz) :771
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-            s[o] = cmul(s[o], cexpi(-(bt[e] * cur)));
+            s[o] = cmul(s[o], cexp_neg_turns(bt[e] * cur));
         }
     } else if (!a.pmd) {
         // zero birefringence, one trunk (fiber.m:291-297): matR = I, deltabeta = 0
         for (int e = tid; e < nel; e += nthr) {
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-            const cplx h = (a.dbg & 8) ? make_double2(1.0, bt[e]) : cexpi(-(bt[e] * cur));
+            const cplx h = (a.dbg & 8) ? make_double2(1.0, bt[e]) : cexp_neg_turns(bt[e] * cur);
             s[o] = cmul(h, s[o]);
             s[o + R * TSp] = cmul(h, s[o + R * TSp]);
         }
@@ -481,8 +498,8 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row(SsfmArgs a)
                 cplx uuy = cadd(cmulc(x, R12), cmulc(y, R22));                 // :921
                 const double combeta = btf * dzk;                              // :924
                 const double deltabeta = 0.5 * (d1f + m[8]) * dzk / lcorr;     // :925
-                uux = cmul(cexpi(-(combeta + deltabeta)), uux);                // :927
-                uuy = cmul(cexpi(-(combeta - deltabeta)), uuy);                // :928
+                uux = cmul(cexp_neg_turns(combeta + deltabeta), uux);          // :927 (phases in turns)
+                uuy = cmul(cexp_neg_turns(combeta - deltabeta), uuy);          // :928
                 x = cadd(cmul(R11, uux), cmul(R12, uuy));                      // :931
                 y = cadd(cmul(R21, uux), cmul(R22, uuy));                      // :932
             }
@@ -776,7 +793,7 @@ template <int PF> __global__ __launch_bounds__(ROW_THREADS) void k_row_p(SsfmArg
                 for (int k = 0; k < PF; k++) {
                     const int e = tid + k * ROW_THREADS;
                     const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-                    const cplx h = (a.dbg & 8) ? make_double2(1.0, bt[e]) : cexpi(-(bt[e] * curdz));
+                    const cplx h = (a.dbg & 8) ? make_double2(1.0, bt[e]) : cexp_neg_turns(bt[e] * curdz);
                     s[o] = cmul(h, s[o]);
                     s[o + R * TSp] = cmul(h, s[o + R * TSp]);
                 }
@@ -801,8 +818,8 @@ template <int PF> __global__ __launch_bounds__(ROW_THREADS) void k_row_p(SsfmArg
                         cplx uuy = cadd(cmulc(x, R12), cmulc(y, R22));                 // :921
                         const double combeta = btf * dzk;                              // :924
                         const double deltabeta = 0.5 * (d1f + m[8]) * dzk / lcorr;     // :925
-                        uux = cmul(cexpi(-(combeta + deltabeta)), uux);                // :927
-                        uuy = cmul(cexpi(-(combeta - deltabeta)), uuy);                // :928
+                        uux = cmul(cexp_neg_turns(combeta + deltabeta), uux);          // :927 (phases in turns)
+                        uuy = cmul(cexp_neg_turns(combeta - deltabeta), uuy);          // :928
                         x = cadd(cmul(R11, uux), cmul(R12, uuy));                      // :931
                         y = cadd(cmul(R21, uux), cmul(R22, uuy));                      // :932
                     }
@@ -972,6 +989,178 @@ template <int PF> __global__ __launch_bounds__(256) void k_colx(SsfmArgs a, int 
     }
 }
 
+// ----------------------------------------------------------------------------------------------
+// k_colx16: the fused column sweep for the 256 x (8+8) tile with both column transforms held in
+// REGISTERS (16 points per thread, r16_* + lvl2_*256): per tile one LDS exchange per transform instead
+// of four read+write passes, the Kerr step on registers (the other polarisation of a sample sits in
+// lane t^8: one DPP row rotation), and the next tile's 16 loads per thread in flight meanwhile.
+// Thread = (j = tid>>4, t = tid&15): t < 8 -> column t of ux, t >= 8 -> column t-8 of uy.
+__global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf, int total)
+{
+    PLX_DYN_LDS(lds);
+    if (*a.ndone >= a.nframes) return;
+    const int tid = threadIdx.x, t = tid & 15, j = tid >> 4;
+    const int N2 = 1 << a.p2;
+    cplx *s = (cplx *)lds;                 // [256][16] exchange buffer
+    cplx *tw = s + 4096;                   // W_256^k, k < 128
+    double *red = (double *)(tw + 128);
+    lds_load_twiddles(tw, a.tw1, 128, tid, 256);
+    cplx *const fld = (t < 8) ? a.ux : a.uy;
+    const int colt = t & 7;
+    const bool isx = t < 8;
+    for (int tl = blockIdx.x; tl < total; tl += gridDim.x) {
+        const int fc = tl / tiles_x, bx = tl - fc * tiles_x, f = fc / a.nfc, c = fc - f * a.nfc;
+        const bool cur = !a.ctl[f].done;
+        const size_t cbase = ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt;
+        bool started = false;
+        if (cur) {
+            started = a.ctl[f].started != 0;
+            cplx x[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = fld[cbase + (size_t)(16 * j + k) * N2];
+#pragma unroll
+            for (int k = 0; k < 16; k++) pin(x[k]);
+            if (started) r16_dit(x);       // rows 16j .. 16j+15 of the (bit-reversed) column spectrum
+#pragma unroll
+            for (int k = 0; k < 16; k++) s[((16 * j + k) << 4) + t] = x[k];
+        }
+        __syncthreads();
+        if (cur) {
+            cplx y[16];                    // point j + 16k
+#pragma unroll
+            for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
+            double sc = 1.0;
+            if (started) {                 // finish step s: ifft (1/N), attenuation (:531-532)
+                lvl2_dit256(y, j, tw);
+                sc = a.ctl[f].att * a.invN;
+            }
+            double m = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                y[k] = cscale(y[k], sc);
+                // the other polarisation of the same sample lives in lane t^8
+                const cplx o = make_double2(lane_xchg<8>(y[k].x), lane_xchg<8>(y[k].y));
+                const cplx X = csel(isx, y[k], o), Y = csel(isx, o, y[k]);
+                double p = X.x * X.x + X.y * X.y;
+                p = p + Y.x * Y.x;
+                p = p + Y.y * Y.y;
+                m = p > m ? p : m;
+            }
+            m = wave_max(m);
+            if ((tid & 63) == 0) red[tid >> 6] = m;
+            __syncthreads();
+            if (tid == 0) {
+                double mm = red[0];
+                for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
+                // frame barrier with a FIXED leader (the workgroup of the frame's first tile): members publish
+                // their maximum and leave one ticket without waiting for its return value; the leader waits for
+                // the tickets, runs the step controller and publishes (epoch, Leff, done).
+                const unsigned prev_epoch = ld_agent(a.epoch + f);     // rounds completed so far (stable until we all arrive)
+                const unsigned round = prev_epoch + 1;
+                const bool leader = (tl % tiles_pf) == 0;
+                const unsigned long long prev = atomicMax(a.umax + fc, (unsigned long long)__double_as_longlong(mm));
+                if (!leader) {
+                    if (prev != ~0ull) atomicAdd(a.arrive + f, 1u);    // ordered after the max (its result is in hand)
+                    unsigned spins = 0;
+                    while (ld_agent(a.epoch + f) < round) {
+                        nap();
+                        if (++spins > (1u << 21)) { atomicAdd(a.syncerr, 1); break; }
+                    }
+                } else {
+                    const unsigned want = round * (unsigned)(tiles_pf - 1);
+                    unsigned spins = 0;
+                    while (prev != ~0ull && ld_agent(a.arrive + f) < want) {
+                        nap();
+                        if (++spins > (1u << 21)) { atomicAdd(a.syncerr, 1); break; }
+                    }
+                    ctrl_step<true>(a, f);
+                    st_agent_f64(a.pub + 2 * f, a.ctl[f].leff);
+                    st_agent_f64(a.pub + 2 * f + 1, a.ctl[f].done ? 1.0 : 0.0);
+                    drain_vmem();
+                    st_agent(a.epoch + f, round);
+                }
+                red[16] = ld_agent_f64(a.pub + 2 * f);
+                red[17] = ld_agent_f64(a.pub + 2 * f + 1);
+                red[18] = mm;
+            }
+            __syncthreads();
+            const double leff = red[16];
+            const bool finished = red[17] != 0.0;
+            if (finished) {                // the frame has reached the fibre end: write the field out
+#pragma unroll
+                for (int k = 0; k < 16; k++) fld[cbase + (size_t)(j + 16 * k) * N2] = y[k];
+            } else {
+                if (a.spm) {               // Kerr step of step s+1 (:832-852) on registers
+                    const double gamleff = a.gam[c] * leff;
+                    // |gamleff*P| <= gamleff * (tile maximum): a few mrad under the step controller, so the
+                    // Taylor form applies to the whole tile; otherwise ('--s-' exact single step) the rare
+                    // full-range path goes through LDS, one thread per polarisation pair.
+                    if (fabs(gamleff) * red[18] < 0.0625) {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const cplx o = make_double2(lane_xchg<8>(y[k].x), lane_xchg<8>(y[k].y));
+                            cplx X = csel(isx, y[k], o), Y = csel(isx, o, y[k]);
+                            const double P = X.x * X.x + X.y * X.y + Y.x * Y.x + Y.y * Y.y;
+                            double sn, cs;
+                            sincos_taylor(-gamleff * P, &sn, &cs);
+                            const cplx nl = make_double2(cs, sn);
+                            X = cmul(X, nl);
+                            Y = cmul(Y, nl);
+                            if (!a.manakov) {
+                                const double s3 = 2 * (X.x * Y.y - X.y * Y.x);
+                                double sp, cp;
+                                sincos_taylor(gamleff * s3 / 3, &sp, &cp);
+                                const cplx xx = make_double2(cp * X.x + sp * Y.x, cp * X.y + sp * Y.y);
+                                const cplx yy = make_double2(cp * Y.x - sp * X.x, cp * Y.y - sp * X.y);
+                                X = xx; Y = yy;
+                            }
+                            y[k] = csel(isx, X, Y);
+                        }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
+                        __syncthreads();
+                        if (isx) {
+                            for (int k = 0; k < 16; k++) {
+                                cplx X = s[((j + 16 * k) << 4) + t], Y = s[((j + 16 * k) << 4) + t + 8];
+                                const double P = X.x * X.x + X.y * X.y + Y.x * Y.x + Y.y * Y.y;
+                                const cplx nl = cexpi(-gamleff * P);
+                                X = cmul(X, nl);
+                                Y = cmul(Y, nl);
+                                if (!a.manakov) {
+                                    const double s3 = 2 * (X.x * Y.y - X.y * Y.x);
+                                    double sp, cp;
+                                    sincos(gamleff * s3 / 3, &sp, &cp);
+                                    const cplx xx = make_double2(cp * X.x + sp * Y.x, cp * X.y + sp * Y.y);
+                                    const cplx yy = make_double2(cp * Y.x - sp * X.x, cp * Y.y - sp * X.y);
+                                    X = xx; Y = yy;
+                                }
+                                s[((j + 16 * k) << 4) + t] = X;
+                                s[((j + 16 * k) << 4) + t + 8] = Y;
+                            }
+                        }
+                        __syncthreads();
+#pragma unroll
+                        for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
+                        __syncthreads();
+                    }
+                }
+                lvl2_dif256(y, j, tw);
+#pragma unroll
+                for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
+                __syncthreads();
+                cplx x[16];
+#pragma unroll
+                for (int k = 0; k < 16; k++) x[k] = s[((16 * j + k) << 4) + t];
+                r16_dif(x);
+#pragma unroll
+                for (int k = 0; k < 16; k++) fld[cbase + (size_t)(16 * j + k) * N2] = x[k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 } // namespace
 
 // ================================================================= host side ===
@@ -996,6 +1185,8 @@ struct plx_ssfm {
     int grid_col = 0, grid_row = 0;
     int64_t row_launches = 0, sample_steps = 0;
 };
+
+static const double kInv2Pi = 0.15915494309189533577;
 
 static int ilog2(int64_t v)
 {
@@ -1104,8 +1295,9 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             const unsigned k2 = plx_bitrev((unsigned)i, P->p2);
             const size_t k = (size_t)k1 + (size_t)N1 * k2, pos = (size_t)j * N2 + i;
             for (int c = 0; c < nfc; c++) {
-                bt[(size_t)c * N + pos] = desc->betat[(size_t)c * N + k];
-                if (have_db1) d1[(size_t)c * N + pos] = desc->db1[(size_t)c * N + k];
+                // phases are kept in TURNS (rad / 2 pi) for the exact range reduction of cexp_neg_turns
+                bt[(size_t)c * N + pos] = desc->betat[(size_t)c * N + k] * kInv2Pi;
+                if (have_db1) d1[(size_t)c * N + pos] = desc->db1[(size_t)c * N + k] * kInv2Pi;
             }
             const uint64_t e = ((uint64_t)i * k1) & (uint64_t)(N - 1); // n2*k1 mod N
             long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)e / (long double)N;
@@ -1170,6 +1362,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             P->fused = nel_col / 256;
             P->tiles_pf = tiles_pf;
             P->fused_grid = (cap / tiles_pf) * tiles_pf;
+            if (const char *e = getenv("PLX_SSFM_FUSE_GRID")) { int v = atoi(e); if (v >= tiles_pf && v <= cap) P->fused_grid = (v / tiles_pf) * tiles_pf; }
             if (hipMalloc((void **)&P->d_sync, sizeof(unsigned) * (2 * (size_t)F + 16)) != hipSuccess ||
                 hipMalloc((void **)&P->d_pub, sizeof(double) * 2 * (size_t)F) != hipSuccess) {
                 free_plan(P);
@@ -1178,7 +1371,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             a.arrive = P->d_sync; a.epoch = P->d_sync + F; a.syncerr = (int *)(P->d_sync + 2 * (size_t)F); a.pub = P->d_pub;
         }
     }
-    if (allow_lds(k_colx<8>, P->lds_col) != hipSuccess || allow_lds(k_colx<4>, P->lds_col) != hipSuccess ||
+    if (allow_lds(k_colx16, P->lds_col) != hipSuccess || allow_lds(k_colx<8>, P->lds_col) != hipSuccess || allow_lds(k_colx<4>, P->lds_col) != hipSuccess ||
         allow_lds(k_colx<16>, P->lds_col) != hipSuccess) {
         free_plan(P);
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
@@ -1224,7 +1417,7 @@ extern "C" int plx_ssfm_set_birefringence(plx_ssfm *P, const double *db0, const 
             m[2] = -st * ce; m[3] = ct * se;  // R12
             m[4] = st * ce;  m[5] = ct * se;  // R21
             m[6] = ct * ce;  m[7] = st * se;  // R22
-            m[8] = db0[i];
+            m[8] = db0[i] * kInv2Pi; // turns, like betat_p / db1_p
         }
     if (P->d_brf) { hipFree(P->d_brf); P->d_brf = nullptr; }
     PLX_HIP(hipMalloc((void **)&P->d_brf, t.size() * sizeof(double)));
@@ -1279,7 +1472,9 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
 #ifdef PLX_EMU
                 emu::g_concurrency = P->tiles_pf; // the emulator must keep one frame's workgroups alive together
 #endif
-                if (P->fused == 8) PLX_LAUNCH(k_colx<8>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
+                if (P->fused == 8 && a.p1 == 8 && a.W == 8 && !getenv("PLX_SSFM_NO_R16"))
+                    PLX_LAUNCH(k_colx16, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
+                else if (P->fused == 8) PLX_LAUNCH(k_colx<8>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
                 else if (P->fused == 4) PLX_LAUNCH(k_colx<4>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
                 else PLX_LAUNCH(k_colx<16>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
 #ifdef PLX_EMU

@@ -338,3 +338,43 @@ def test_emu_adaptive_ssfm(emu, oracle, tolflag):
         assert onc > 3
     assert nc.value == onc and fd.value == pytest.approx(ofd, rel=1e-9)
     assert np.abs((ur + 1j * ui) - ou).max() < 1e-9 * np.abs(ou).max()
+
+
+def test_emu_ampliflat_injected_and_philox(emu):
+    """ampliflat.m:78-148: gain, injected options.noise, one-polarisation ASE, and the statistics of the
+    counter-based device noise (keyed per frame)."""
+    n, nfc, F = 2048, 2, 2
+    r = np.random.default_rng(4)
+    ux = r.standard_normal((F, nfc, n)) + 1j * r.standard_normal((F, nfc, n))
+    uy = r.standard_normal((F, nfc, n)) + 1j * r.standard_normal((F, nfc, n))
+    noise = r.standard_normal((F, 2 * nfc, n)) + 1j * r.standard_normal((F, 2 * nfc, n))
+    sigma = np.array([0.3, 0.5])
+    gx, gy, nz = _il(ux), _il(uy), _il(noise)
+    emu.call("plx_ampliflat_dev", _vp(gx), _vp(gy), n, nfc, F, 4.0, _vp(sigma), _vp(nz), 0, None, 1, 1, None)
+    ox = gx.view(np.complex128).reshape(F, nfc, n); oy = gy.view(np.complex128).reshape(F, nfc, n)
+    np.testing.assert_allclose(ox, 2.0 * ux + sigma[None, :, None] * noise[:, :nfc], rtol=1e-15, atol=1e-15)
+    np.testing.assert_allclose(oy, 2.0 * uy + sigma[None, :, None] * noise[:, nfc:], rtol=1e-15, atol=1e-15)
+    # 'asex': noise on x only; no sigma: pure gain
+    gx, gy = _il(ux), _il(uy)
+    emu.call("plx_ampliflat_dev", _vp(gx), _vp(gy), n, nfc, F, 4.0, _vp(sigma), _vp(nz), 0, None, 1, 0, None)
+    np.testing.assert_allclose(gy.view(np.complex128).reshape(F, nfc, n), 2.0 * uy, rtol=1e-15)
+    gx, gy = _il(ux), _il(uy)
+    emu.call("plx_ampliflat_dev", _vp(gx), None, n, nfc, F, 0.25, None, None, 0, None, 1, 1, None)
+    np.testing.assert_allclose(gx.view(np.complex128).reshape(F, nfc, n), 0.5 * ux, rtol=1e-15)
+    # device Philox noise: zero field in, unit-variance quadratures out, frames keyed independently
+    z = np.zeros(F * nfc * n * 2)
+    zy = np.zeros_like(z)
+    keys = np.array([7, 7], dtype=np.int64)
+    one = np.ones(nfc)
+    emu.call("plx_ampliflat_dev", _vp(z), _vp(zy), n, nfc, F, 1.0, _vp(one), None, 1234, _vp(keys), 1, 1, None)
+    zz = z.view(np.complex128).reshape(F, nfc, n)
+    np.testing.assert_array_equal(zz[0], zz[1])                          # same key -> same realisation
+    assert abs(zz.real.std() - 1) < 0.03 and abs(zz.imag.std() - 1) < 0.03 and abs(zz.mean()) < 0.05
+    assert abs(np.corrcoef(zz[0, 0].real, zz[0, 1].real)[0, 1]) < 0.08    # channels / polarisations independent
+    assert abs(np.corrcoef(zz[0, 0].real, zy.view(np.complex128).reshape(F, nfc, n)[0, 0].real)[0, 1]) < 0.08
+    z2 = np.zeros_like(z)
+    keys2 = np.array([7, 8], dtype=np.int64)
+    emu.call("plx_ampliflat_dev", _vp(z2), None, n, nfc, F, 1.0, _vp(one), None, 1234, _vp(keys2), 1, 1, None)
+    w = z2.view(np.complex128).reshape(F, nfc, n)
+    np.testing.assert_array_equal(w[0], zz[0])
+    assert not np.array_equal(w[1], zz[1])

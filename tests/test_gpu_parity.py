@@ -619,3 +619,44 @@ def test_monte_carlo_campaign_is_sharding_invariant(lib):
     assert c.simulate(list(range(8))).max() <= 2
     for m in (a, b, c):
         m.close()
+
+
+def test_ampliflat_function_surface(lib):
+    """ampliflat(x,'gain',options) on GSTATE: gain, sigma formula (ampliflat.m:91-102), options.noise injection
+    (:123-129), 'asex' (:107-118), device noise statistics; and a 2-span fibre/amplifier chain conserving power."""
+    import polmux_amd as px
+    from polmux_amd import synth
+    from polmux_amd.ampliflat import ase_sigma
+    from polmux_amd.gstate import GSTATE, to_host_field
+    nsymb, nt = 256, 16
+    px.reset_all(nsymb, nt, 1)
+    GSTATE.SYMBOLRATE = 28.0
+    px.lasersource(2.0, 1550.0)
+    sx, sy, _, _ = synth.pdm_qpsk_field(nsymb, nt, 2.0)
+    px.create_field("sepfields", sx, sy, dict(power="average"))
+    x0, y0 = to_host_field(GSTATE.FIELDX), to_host_field(GSTATE.FIELDY)
+    r = np.random.default_rng(3)
+    n = r.standard_normal((nsymb * nt, 2)) + 1j * r.standard_normal((nsymb * nt, 2))
+    g = px.ampliflat(16.0, "gain", dict(f=5.0, noise=n))
+    assert g == pytest.approx(10 ** 1.6)
+    sig = ase_sigma(5.0, g, 1)
+    want = 10 ** 0.5 * 6.62606896e-34 * 299792458.0 / 1550.0 * (g - 1) / 4 * nt * 28.0 * 1e21
+    assert sig[0] ** 2 == pytest.approx(want, rel=1e-12)
+    np.testing.assert_allclose(to_host_field(GSTATE.FIELDX)[:, 0], np.sqrt(g) * x0[:, 0] + sig[0] * n[:, 0], rtol=1e-13)
+    np.testing.assert_allclose(to_host_field(GSTATE.FIELDY)[:, 0], np.sqrt(g) * y0[:, 0] + sig[0] * n[:, 1], rtol=1e-13)
+    px.create_field("sepfields", sx * 0, sy * 0)
+    px.ampliflat(20.0, "gain", dict(f=6.0, onepol="asex"), seed=5)
+    nx, ny = to_host_field(GSTATE.FIELDX)[:, 0], to_host_field(GSTATE.FIELDY)[:, 0]
+    s2 = ase_sigma(6.0, 100.0, 1)[0]
+    assert not ny.any() and abs(nx.real.std() / s2 - 1) < 0.05 and abs(nx.imag.std() / s2 - 1) < 0.05
+    with pytest.raises(ValueError, match="wrong string atype"):
+        px.ampliflat(1.0, "nope")
+    # span + amplifier restoring the loss: average power back to the launch value
+    px.create_field("sepfields", sx, sy)
+    fib = dict(length=8e4, alphadB=0.2, aeff=80.0, n2=2.7e-20, disp=17.0, slope=0.0, dphimax=5e-3, dzmax=2e4)
+    fib["lambda"] = 1550.0
+    for _ in range(2):
+        px.fiber(fib, "g-s-")
+        px.ampliflat(16.0, "gain")
+    p = float((GSTATE.FIELDX.abs() ** 2 + GSTATE.FIELDY.abs() ** 2).mean())
+    assert p == pytest.approx(2.0, rel=1e-9)
