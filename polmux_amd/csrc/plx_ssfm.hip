@@ -322,7 +322,8 @@ __global__ __launch_bounds__(256) void k_rowsum(SsfmArgs a)
 // batches of COL_CH per thread before any arithmetic, to keep >= 64 KiB in flight
 // per CU.
 #define COL_CH 4
-__global__ __launch_bounds__(256) void k_col_fwd(SsfmArgs a)
+#define COL_THREADS_MAX 512
+__global__ __launch_bounds__(COL_THREADS_MAX) void k_col_fwd(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
     if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
@@ -422,7 +423,7 @@ __global__ __launch_bounds__(256) void k_col_fwd(SsfmArgs a)
 // transform, all on one LDS-resident row set (padded layout, see plx_fft.h).
 #define ROW_THREADS 128
 #define ROW_CH 4
-__global__ __launch_bounds__(ROW_THREADS) void k_row(SsfmArgs a)
+__global__ __launch_bounds__(256) void k_row(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
     if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(ROW_THREADS) void k_row(SsfmArgs a)
 // ------------------------------------------------------ pass 3: inverse columns ---
 // Completes ifft (1/N), applies the attenuation of the step (:531-532) and feeds
 // nextstep's global maximum (:694-696) -- no extra pass over the field.
-__global__ __launch_bounds__(256) void k_col_inv(SsfmArgs a)
+__global__ __launch_bounds__(COL_THREADS_MAX) void k_col_inv(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
     if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
@@ -1454,8 +1455,13 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
         if (gx > 64) gx = 64;
         PLX_LAUNCH(k_umax, dim3(gx, FC), dim3(256), 16 * sizeof(double), st, a);
     }
-    const dim3 gcol((unsigned)(N2 / a.W), FC), grow((unsigned)(N1 / a.R), FC), blk(256), brow(ROW_THREADS);
+    const dim3 gcol((unsigned)(N2 / a.W), FC), grow((unsigned)(N1 / a.R), FC), blk(256);
     const dim3 gctl((unsigned)((nframes + 63) / 64)), bctl(64);
+    int colthr = 512; // measured: 512-thread column workgroups (2 per CU, 16 waves) beat 256 by 3-12 %
+    if (const char *e = getenv("PLX_SSFM_COL_THREADS")) { int v = atoi(e); if (v == 128 || v == 256 || v == 512) colthr = v; }
+    const dim3 bcol((unsigned)colthr);
+    int rowthr = ROW_THREADS;
+    if (const char *e = getenv("PLX_SSFM_ROW_THREADS")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) rowthr = v; }
     P->row_launches = 0;
     // Data-dependent trip count (fiber.m:518): steps are enqueued in chunks; the
     // completed-frame counter of chunk k is read back while chunk k+1 executes.
@@ -1480,7 +1486,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
 #endif
-                PLX_LAUNCH(k_row, grow, brow, P->lds_row, st, a);
+                PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
                 P->row_launches++;
                 continue;
             }
@@ -1494,13 +1500,13 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
             const dim3 pgc((unsigned)(tct < P->grid_col ? tct : P->grid_col)), pgr((unsigned)(trt < P->grid_row ? trt : P->grid_row));
             if (P->pf_col == 8) PLX_LAUNCH(k_col_fwd_p<8>, pgc, blk, P->lds_col, st, a, tcx, tct);
             else if (P->pf_col == 4) PLX_LAUNCH(k_col_fwd_p<4>, pgc, blk, P->lds_col, st, a, tcx, tct);
-            else PLX_LAUNCH(k_col_fwd, gcol, blk, P->lds_col, st, a);
-            if (P->pf_row == 4) PLX_LAUNCH(k_row_p<4>, pgr, brow, P->lds_row, st, a, trx, trt);
-            else if (P->pf_row == 8) PLX_LAUNCH(k_row_p<8>, pgr, brow, P->lds_row, st, a, trx, trt);
-            else PLX_LAUNCH(k_row, grow, brow, P->lds_row, st, a);
+            else PLX_LAUNCH(k_col_fwd, gcol, bcol, P->lds_col, st, a);
+            if (P->pf_row == 4) PLX_LAUNCH(k_row_p<4>, pgr, dim3(ROW_THREADS), P->lds_row, st, a, trx, trt);
+            else if (P->pf_row == 8) PLX_LAUNCH(k_row_p<8>, pgr, dim3(ROW_THREADS), P->lds_row, st, a, trx, trt);
+            else PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
             if (P->pf_col == 8) PLX_LAUNCH(k_col_inv_p<8>, pgc, blk, P->lds_col, st, a, tcx, tct);
             else if (P->pf_col == 4) PLX_LAUNCH(k_col_inv_p<4>, pgc, blk, P->lds_col, st, a, tcx, tct);
-            else PLX_LAUNCH(k_col_inv, gcol, blk, P->lds_col, st, a);
+            else PLX_LAUNCH(k_col_inv, gcol, bcol, P->lds_col, st, a);
             P->row_launches++;
         }
         steps += chunk;
