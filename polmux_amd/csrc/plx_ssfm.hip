@@ -518,6 +518,66 @@ __global__ __launch_bounds__(256) void k_row(SsfmArgs a)
     }
 }
 
+// ----------------------------------------------- pass 2, register-blocked (N2 = 256) ---
+// The row pass for 256-point rows with every transform level in registers: thread (j, t) owns points
+// j + 16k of transform t (t = pol*R + r), loads them straight from HBM (16 lanes = 256 contiguous bytes),
+// runs lvl2_dif256, exchanges ONCE through LDS (padded: lane stride 17 slots), finishes with r16_dif,
+// applies exp(-i beta dz) at the 16 bit-reversed bins it holds, and goes back the same way: 4 LDS
+// passes and 2 barriers instead of 16 passes and ~10 barriers of the general kernel.  Dual-polarisation
+// plans without PMD (the waveplate loop needs both polarisations of a bin in one thread: k_row).
+// Opt-in (PLX_SSFM_ROW16=1): on MI355X it times the same as k_row -- the row pass is not LDS-bound.
+__global__ __launch_bounds__(256) void k_row16(SsfmArgs a)
+{
+    PLX_DYN_LDS(lds);
+    if (*a.ndone >= a.nframes) return;
+    const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
+    const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
+    const FrameCtl *ctl = a.ctl + f;
+    if (ctl->done) return;
+    const int R = a.R, pol = t >= R ? 1 : 0, r = t - pol * R;
+    cplx *s = (cplx *)lds;                 // [2R][272]
+    cplx *tw = s + (size_t)2 * R * 272;    // W_256^k, k < 128
+    lds_load_twiddles(tw, a.tw2, 128, tid, blockDim.x);
+    const size_t N = (size_t)1 << (a.p1 + a.p2);
+    const size_t rowoff = ((size_t)blockIdx.x * R + r) << 8;   // row start inside the frame
+    cplx *const u = (pol ? a.uy : a.ux) + (size_t)fc * N + rowoff;
+    const cplx *const tp = a.tpass + rowoff;
+    cplx x[16];
+    {
+        cplx tv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { x[k] = u[j + 16 * k]; tv[k] = tp[j + 16 * k]; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { pin(x[k]); pin(tv[k]); }
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = cmul(x[k], tv[k]);
+    }
+    __syncthreads();                        // twiddles staged
+    lvl2_dif256(x, j, tw);
+    cplx *const st = s + t * 272;
+#pragma unroll
+    for (int k = 0; k < 16; k++) st[j + 17 * k] = x[k];          // row_phys(j + 16k)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = st[17 * j + k];          // block j: points 16j .. 16j+15
+    r16_dif(x);
+    {
+        const double cur = a.force ? a.f_cur : ctl->cur;
+        const double *bt = a.betat_p + (size_t)c * N + rowoff + 16 * j;
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = cmul(cexp_neg_turns(bt[k] * cur), x[k]);   // :927-928 with matR = I
+    }
+    r16_dit(x);
+#pragma unroll
+    for (int k = 0; k < 16; k++) st[17 * j + k] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = st[j + 17 * k];
+    lvl2_dit256(x, j, tw);
+#pragma unroll
+    for (int k = 0; k < 16; k++) u[j + 16 * k] = cmulc(x[k], tp[j + 16 * k]);
+}
+
 // ------------------------------------------------------ pass 3: inverse columns ---
 // Completes ifft (1/N), applies the attenuation of the step (:531-532) and feeds
 // nextstep's global maximum (:694-696) -- no extra pass over the field.
@@ -1182,6 +1242,7 @@ struct plx_ssfm {
     unsigned *d_sync = nullptr;   // arrive[F] | epoch[F] | syncerr
     double *d_pub = nullptr;
     int fused = 0, fused_grid = 0, tiles_pf = 0;
+    int row16 = 0;                // register-blocked row pass usable (N2 == 256, dual, no PMD)
     int pf_col = 0, pf_row = 0;   // > 0: persistent prefetching kernels usable (tile == PF x threads)
     int grid_col = 0, grid_row = 0;
     int64_t row_launches = 0, sample_steps = 0;
@@ -1351,6 +1412,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         if (const char *e = getenv("PLX_SSFM_GRID_COL")) P->grid_col = atoi(e);
         if (const char *e = getenv("PLX_SSFM_GRID_ROW")) P->grid_row = atoi(e);
     }
+    P->row16 = (a.dual && !a.pmd && a.p2 == 8 && a.R <= 8 && getenv("PLX_SSFM_ROW16")) ? 1 : 0;   // opt-in: measured equal to k_row (profiles/r01_notes.md)
     // fused column sweep (opt-in, PLX_SSFM_FUSE=1): needs the tile to be PF x 256 and all tiles of a frame
     // co-resident.  Measured on MI355X it moves 1/3 less HBM traffic but is latency-bound at 2 workgroups
     // per CU and ends up level with the plain three-sweep step (profiles/r01_notes.md), so the default
@@ -1372,6 +1434,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             a.arrive = P->d_sync; a.epoch = P->d_sync + F; a.syncerr = (int *)(P->d_sync + 2 * (size_t)F); a.pub = P->d_pub;
         }
     }
+    if (allow_lds(k_row16, P->lds_row) != hipSuccess) { free_plan(P); PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS"); }
     if (allow_lds(k_colx16, P->lds_col) != hipSuccess || allow_lds(k_colx<8>, P->lds_col) != hipSuccess || allow_lds(k_colx<4>, P->lds_col) != hipSuccess ||
         allow_lds(k_colx<16>, P->lds_col) != hipSuccess) {
         free_plan(P);
@@ -1486,7 +1549,8 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
 #endif
-                PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
+                if (P->row16) PLX_LAUNCH(k_row16, grow, dim3((unsigned)(32 * a.R)), P->lds_row, st, a);
+                else PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
                 P->row_launches++;
                 continue;
             }
@@ -1503,6 +1567,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
             else PLX_LAUNCH(k_col_fwd, gcol, bcol, P->lds_col, st, a);
             if (P->pf_row == 4) PLX_LAUNCH(k_row_p<4>, pgr, dim3(ROW_THREADS), P->lds_row, st, a, trx, trt);
             else if (P->pf_row == 8) PLX_LAUNCH(k_row_p<8>, pgr, dim3(ROW_THREADS), P->lds_row, st, a, trx, trt);
+            else if (P->row16) PLX_LAUNCH(k_row16, grow, dim3((unsigned)(32 * a.R)), P->lds_row, st, a);
             else PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
             if (P->pf_col == 8) PLX_LAUNCH(k_col_inv_p<8>, pgc, blk, P->lds_col, st, a, tcx, tct);
             else if (P->pf_col == 4) PLX_LAUNCH(k_col_inv_p<4>, pgc, blk, P->lds_col, st, a, tcx, tct);

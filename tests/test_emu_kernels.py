@@ -293,28 +293,35 @@ def test_emu_dsp_chain(emu, oracle, kw):
 
 def test_emu_fused_and_persistent_variants(emu, oracle, monkeypatch):
     """The opt-in sweeps (PLX_SSFM_FUSE: col_inv + step control + col_fwd with a per-frame barrier;
-    PLX_SSFM_PERSIST: register-prefetching persistent sweeps) give the same fields and step counts."""
+    PLX_SSFM_PERSIST: register-prefetching persistent sweeps; PLX_SSFM_P1=4 -> 256-point rows through
+    the general k_row and, with PLX_SSFM_ROW16, the register-blocked k_row16) give the same fields and step counts."""
     n, nt, L = 4096, 64, 1.5e3
     fls = [1, 0, 1, 0]
     betat, db1 = _tables(n, nt, fls, 1)
     fields = [_qpsk_field(n, nt, p)[:2] for p in (6.0, 9.0, 12.0)]
     ref = [oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0]) for f in fields]
-    for var in ("PLX_SSFM_FUSE", "PLX_SSFM_PERSIST"):
-        monkeypatch.setenv(var, "1")
-        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=3)
+    for env in ({"PLX_SSFM_FUSE": "1"}, {"PLX_SSFM_PERSIST": "1"}, {"PLX_SSFM_P1": "4"},
+                {"PLX_SSFM_P1": "4", "PLX_SSFM_ROW16": "1"}):
+        nf = 1 if "PLX_SSFM_P1" in env else 3          # the row variants have no cross-frame machinery
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=nf)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
-        monkeypatch.delenv(var)
-        ux = _il(np.stack([f[0] for f in fields])); uy = _il(np.stack([f[1] for f in fields]))
-        emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 3, None)
-        ncyc = np.zeros(3, np.int32)
-        emu.call("plx_ssfm_results", plan, 3, None, _vp(ncyc))
+        for k in env:
+            monkeypatch.delenv(k)
+        ux = _il(np.stack([f[0] for f in fields[:nf]])); uy = _il(np.stack([f[1] for f in fields[:nf]]))
+        emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), nf, None)
+        ncyc = np.zeros(nf, np.int32)
+        emu.call("plx_ssfm_results", plan, nf, None, _vp(ncyc))
         emu.call("plx_ssfm_destroy", plan)
-        gx = ux.view(np.complex128).reshape(3, n)
-        for f in range(3):
+        gx = ux.view(np.complex128).reshape(nf, n)
+        gy = uy.view(np.complex128).reshape(nf, n)
+        for f in range(nf):
             rc, ofd, onc, ox, oy = ref[f]
             assert ncyc[f] == onc
             assert np.abs(gx[f] - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
+            assert np.abs(gy[f] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
 
 
 @pytest.mark.parametrize("tolflag", [2, 1])
