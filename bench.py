@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--pavg", type=float, default=2.0)
     ap.add_argument("--flag", default="g-s-")
     ap.add_argument("--noise", type=float, default=0.05, help="receiver noise sigma per quadrature (full scale 1)")
+    ap.add_argument("--frontend", default="pick", choices=["pick", "cohmix"],
+                    help="pick: 2-sps sampling supplied by the harness (SURVEY 8d C1); cohmix: receiver_cohmix + ADC + decimate on the device")
     ap.add_argument("--no-overlap", action="store_true", help="run the receiver on the fibre stream (no stream overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=1)
@@ -80,8 +82,14 @@ def cpu_baseline(cfg, hp, nframes):
     for _ in range(nframes):
         rc, fd, nc, ox, oy = plxo.matrix_ssfm(hp.tx_host[0], hp.tx_host[1], betat, db1, min(cfg.dzmax, cfg.length),
                                               cfg.dphimax, gam, hp.alphalin, cfg.length, 1, 0, hp.fls, [0.0], [0.0], [0.0])
-        half = cfg.nt // 2
-        rx = np.stack([ox[::half, 0], oy[::half, 0]], 1) * hp.rx_scale
+        if hp.front is not None:
+            from oracle import front
+            t = hp.front_tables
+            cur = front.receiver_cohmix(ox[:, 0], oy[:, 0], t["hopt"], t["elo"], t["hel"], True)
+            rx = front.rx_front(cur, True, cfg.adcbits, hp.front_shifts, t["decim"], t["fir"])
+        else:
+            half = cfg.nt // 2
+            rx = np.stack([ox[::half, 0], oy[::half, 0]], 1) * hp.rx_scale
         ex, ey, _ = plxo.cde_ofde(rx[:, 0], rx[:, 1], 2 * cfg.symbolrate * 1e9, cfg.lam * 1e-9, cfg.length, cfg.disp * 1e-6,
                                   cfg.slope * 1e-6, cfg.fft_length, cfg.cde_L)
         op = plxo.dsp_params(power_mw=hp.power_mw, applypol=True, polmethod="cma", cma_mu=cfg.cma_mu, cma_taps=cfg.cma_taps,
@@ -105,7 +113,7 @@ def main():
     from polmux_amd import _abi, pipeline
     _abi.get().call("plx_set_device", local)
 
-    cfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag=a.flag)
+    cfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag=a.flag, frontend=a.frontend)
     F = a.frames
     hp = pipeline.HotPath(cfg, max_frames=F)
     n = cfg.nfft
@@ -181,7 +189,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Run_my_PDM_QPSK-style (BASELINE config[1]): 28 Gbaud PDM-QPSK, 2^%d-sample "
                                    "dual-pol frame, 1x80 km SSMF span fiber('%s'), CDE_OFDE 256/128, CMA 7 taps + "
-                                   "V&V carrier recovery" % (int(np.log2(n)), a.flag),
+                                   "V&V carrier recovery; front end: %s" % (int(np.log2(n)), a.flag, a.frontend),
                        "frames_per_gpu_per_step": F, "nsymb": a.nsymb, "nt": a.nt, "pavg_mw": a.pavg,
                        "ssfm_steps_per_frame": sample_steps / (a.steps * F * n), "rx_noise_sigma": a.noise,
                        "fibre_ms_per_step": fib / a.steps, "rxdsp_ms_per_step": rxm / a.steps,

@@ -191,6 +191,36 @@ int plx_ampliflat_dev(double *d_ux, double *d_uy, int64_t nfft, int32_t nfc, int
                       const double *sigma, const double *d_noise, uint64_t seed, const int64_t *d_keys,
                       int32_t asex, int32_t asey, void *stream);
 
+/* ------------------------------------------------------------ coherent front end --- */
+/* The step between fiber() and CDE_OFDE(): receiver_cohmix.m:165-307 (optical filter x post-compensation,
+ * LO mixing in two 90-degree hybrids, balanced or single photodiodes, electrical low-pass) followed by
+ * RxPdmCohQpsk.m:36-72 (ADC quantisation, timing shift, decimation, I/Q recombination), batched over frames.
+ * Tables are on the fft-ordered grid GSTATE.FN and are built by the caller (myfilter.m, :143-168, :193-227). */
+typedef struct plx_front plx_front;
+typedef struct plx_front_desc {
+    int64_t nfft;            /* samples per frame                                                        */
+    int32_t dual_pol;        /* 1: GSTATE.FIELDY present (isy, :229), 0: X only                          */
+    int32_t max_frames;
+    int32_t balanced;        /* 1: balanced detection (default), 0: x.pdtype == 'normal' (:265-278)      */
+    int32_t adcbits;         /* RxParams.adcbits when RxParams.applyadc, 0: no ADC (RxPdmCohQpsk.m:36-40) */
+    int32_t decim;           /* DecimationRate (RxPdmCohQpsk.m:49-53); 1: keep every sample              */
+    int32_t ntaps;           /* taps of the decimation FIR (17 for decimate(x,r,16,'fir')), odd          */
+    const double *fir;       /* [ntaps] host                                                             */
+    const double *hopt_re, *hopt_im;   /* [nfft] Hf of receiver_cohmix.m:165-168 (hopt_im may be NULL)   */
+    const double *hel_re, *hel_im;     /* [nfft] Hf of receiver_cohmix.m:296   (hel_im may be NULL)      */
+    const double *elo_re, *elo_im;     /* [nfft] Elo of receiver_cohmix.m:227, or NULL: Elo = elo_scalar */
+    double elo_scalar;       /* LO_Ecw = 10^(x.lopower/20) (:221-225)                                    */
+} plx_front_desc;
+int plx_front_create(plx_front **plan, const plx_front_desc *desc);
+int plx_front_destroy(plx_front *plan);
+int64_t plx_front_out_len(const plx_front *plan);   /* ceil(nfft / decim) */
+/* d_ux, d_uy: [nframes][nfft] complex128 fields, OVERWRITTEN: on return they hold the filtered photocurrents
+ * of each polarisation as I + jQ (the columns [IricX IricY] of receiver_cohmix.m:300-307) before ADC/shift.
+ * shift: host, [1 + dual_pol] circular shifts round(-delay*NT) of fastshift (RxPdmCohQpsk.m:42-44), or NULL.
+ * d_out: [nframes][1 + dual_pol][out_len] complex128 RxSamples (RxPdmCohQpsk.m:63-72).                     */
+int plx_front_run_dev(plx_front *plan, double *d_ux, double *d_uy, int nframes, const int64_t *shift,
+                      double *d_out, void *stream);
+
 /* ------------------------------------------------------------ small helpers --- */
 /* strided pick + scale used between fibre and CDE when the full front end
  * (receiver_cohmix + decimate) is not in the chain:

@@ -40,6 +40,13 @@ class DspParams(C.Structure):
                 ("freqavg", C.c_int32), ("phasavg", C.c_int32), ("poworder", C.c_int32)]
 
 
+class FrontDesc(C.Structure):
+    _fields_ = [("nfft", C.c_int64), ("dual_pol", C.c_int32), ("max_frames", C.c_int32), ("balanced", C.c_int32),
+                ("adcbits", C.c_int32), ("decim", C.c_int32), ("ntaps", C.c_int32), ("fir", C.c_void_p),
+                ("hopt_re", C.c_void_p), ("hopt_im", C.c_void_p), ("hel_re", C.c_void_p), ("hel_im", C.c_void_p),
+                ("elo_re", C.c_void_p), ("elo_im", C.c_void_p), ("elo_scalar", C.c_double)]
+
+
 _vp, _i32, _i64, _dbl, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_size_t
 
 # name -> argtypes; every symbol include/polmux_hip.h declares (tests check the list
@@ -74,9 +81,13 @@ SIGNATURES = {
     "plx_dsp_out_len": [_vp],
     "plx_decide_count_dev": [_vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _vp],
     "plx_ampliflat_dev": [_vp, _vp, _i64, _i32, C.c_int, _dbl, _vp, _vp, C.c_uint64, _vp, _i32, _i32, _vp],
+    "plx_front_create": [C.POINTER(_vp), C.POINTER(FrontDesc)],
+    "plx_front_destroy": [_vp],
+    "plx_front_out_len": [_vp],
+    "plx_front_run_dev": [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
     "plx_pick_dev": [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, C.c_int, _i64, _vp],
 }
-_RESTYPES = {"plx_dsp_out_len": _i64}
+_RESTYPES = {"plx_dsp_out_len": _i64, "plx_front_out_len": _i64}
 
 
 class Binding:

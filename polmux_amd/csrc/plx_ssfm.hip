@@ -24,6 +24,7 @@
 // lock-step launches while every frame keeps the reference's own step sequence.
 #include "../../include/polmux_hip.h"
 #include "plx_fft.h"
+#include "plx_internal.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -49,6 +50,7 @@ struct SsfmArgs {
     cplx *ux, *uy;
     const double *betat_p, *db1_p; // [nfc][N], bit-reversed/transposed order
     const cplx *tpass;             // [N] inter-pass twiddles W_N^(n2*k1), same order
+    const cplx *hmul;              // [N] general spectral multiplier replacing exp(-i betat dz) (filter passes), same order
     const cplx *tw1, *tw2;         // half tables W_N1^k, W_N2^k
     const double *gam;             // [nfc] effective gamma (x8/9 when Manakov, :499-501)
     const double *brf;             // [sets][nplates][9]: R11 R12 R21 R22 (re,im) db0
@@ -469,13 +471,13 @@ __global__ __launch_bounds__(256) void k_row(SsfmArgs a)
     if (!a.dual) {
         for (int e = tid; e < nel; e += nthr) { // Hf = fastexp(-betat*dz) :771
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-            s[o] = cmul(s[o], cexp_neg_turns(bt[e] * cur));
+            s[o] = cmul(s[o], a.hmul ? a.hmul[rowbase + e] : cexp_neg_turns(bt[e] * cur));
         }
     } else if (!a.pmd) {
         // zero birefringence, one trunk (fiber.m:291-297): matR = I, deltabeta = 0
         for (int e = tid; e < nel; e += nthr) {
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-            const cplx h = (a.dbg & 8) ? make_double2(1.0, bt[e]) : cexp_neg_turns(bt[e] * cur);
+            const cplx h = a.hmul ? a.hmul[rowbase + e] : (a.dbg & 8) ? make_double2(1.0, bt[e]) : cexp_neg_turns(bt[e] * cur);
             s[o] = cmul(h, s[o]);
             s[o + R * TSp] = cmul(h, s[o + R * TSp]);
         }
@@ -1596,6 +1598,50 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
         if (!P->h_ctl[f].done) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: a frame did not reach the fibre end");
         P->sample_steps += (int64_t)P->h_ctl[f].ncycle * (int64_t)P->N * nfc;
     }
+    PLX_HIP(hipGetLastError());
+    return PLX_OK;
+}
+
+// ---- the plan's FFT engine as a spectral filter (library-internal, plx_internal.h) ----
+int plx_ssfm_filter_table(plx_ssfm *P, const double *h_re, const double *h_im, cplx **d_out)
+{
+    if (!P || !h_re || !d_out) PLX_FAIL(PLX_ERR_ARG, "filter table: null argument");
+    const int N1 = 1 << P->p1, N2 = 1 << P->p2;
+    std::vector<cplx> h(P->N);
+    for (int j = 0; j < N1; j++) {
+        const unsigned k1 = plx_bitrev((unsigned)j, P->p1);
+        for (int i = 0; i < N2; i++) {
+            const size_t k = (size_t)k1 + (size_t)N1 * plx_bitrev((unsigned)i, P->p2);
+            h[(size_t)j * N2 + i] = make_double2(h_re[k], h_im ? h_im[k] : 0.0);
+        }
+    }
+    cplx *d = nullptr;
+    if (hipMalloc((void **)&d, P->N * sizeof(cplx)) != hipSuccess ||
+        hipMemcpy(d, h.data(), P->N * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess) {
+        if (d) (void)hipFree(d);
+        PLX_FAIL(PLX_ERR_HIP, "filter table: device allocation/upload failed");
+    }
+    *d_out = d;
+    return PLX_OK;
+}
+
+int plx_ssfm_filter_dev(plx_ssfm *P, cplx *d_ux, cplx *d_uy, const cplx *d_hmul, int nframes, void *stream)
+{
+    if (!P || !d_ux || !d_hmul) PLX_FAIL(PLX_ERR_ARG, "filter: null argument");
+    if (nframes < 1 || nframes > P->d.max_frames) PLX_FAIL(PLX_ERR_ARG, "filter: nframes outside [1, max_frames]");
+    if (P->a.dual && !d_uy) PLX_FAIL(PLX_ERR_ARG, "filter: dual-polarisation plan needs d_uy");
+    hipStream_t st = (hipStream_t)stream;
+    SsfmArgs b = P->a;
+    b.ux = d_ux; b.uy = d_uy; b.nframes = nframes; b.hmul = d_hmul;
+    b.force = 1; b.spm = 0; b.xpm = 0; b.pmd = 0; b.f_cur = 0; b.f_leff = 0; b.f_sc = b.invN;
+    const int N1 = 1 << b.p1, N2 = 1 << b.p2;
+    const unsigned FC = (unsigned)nframes * b.nfc;
+    PLX_HIP(hipMemsetAsync(P->d_ctl, 0, sizeof(FrameCtl) * nframes, st));   // no frame is "done"
+    PLX_HIP(hipMemsetAsync(P->d_ndone, 0, 64, st));
+    const dim3 gcol((unsigned)(N2 / b.W), FC), grow((unsigned)(N1 / b.R), FC);
+    PLX_LAUNCH(k_col_fwd, gcol, dim3(512), P->lds_col, st, b);
+    PLX_LAUNCH(k_row, grow, dim3(ROW_THREADS), P->lds_row, st, b);
+    PLX_LAUNCH(k_col_inv, gcol, dim3(512), P->lds_col, st, b);
     PLX_HIP(hipGetLastError());
     return PLX_OK;
 }

@@ -25,7 +25,11 @@ class HotPathConfig:
     def __init__(self, nsymb=1024, nt=64, symbolrate=28.0, pavg_mw=2.0, lam=1550.0, flag="g-s-",
                  length=8e4, alphadB=0.2, aeff=80.0, n2=2.7e-20, disp=17.0, slope=0.0, dphimax=5e-3, dzmax=2e4,
                  dgd=0.1, nplates=100, manakov="no", nspans=1, fft_length=256, cde_L=128, applypol=True,
-                 polmethod="cma", cma_taps=7, cma_mu=1 / 6000, freqavg=500, phasavg=3, poworder=2):
+                 polmethod="cma", cma_taps=7, cma_mu=1 / 6000, freqavg=500, phasavg=3, poworder=2,
+                 frontend="pick", oftype="gauss", obw=1.9, oord=3, eftype="bessel5", ebw=0.65, eord=4, lopower=0.0,
+                 adcbits=5):
+        """frontend: 'pick' = 2-sps sampling supplied by the harness; 'cohmix' = the reference's own
+        receiver_cohmix + ADC + decimate chain (RxPdmCohQpsk.m, Run_my_PDM_QPSK.m:52-73 defaults) on the device."""
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -97,6 +101,21 @@ class HotPath:
         # receive scale: undo the span loss and bring symbols to the 4*sqrt(P) full scale that
         # DspPdmCohQpsk divides by (DspPdmCohQpsk.m:22-23, "2* -> see receiver_cohmix")
         self.rx_scale = 4.0 * math.sqrt(power) / math.sqrt(power / 2.0) * math.exp(0.5 * self.alphalin * cfg.length * cfg.nspans)
+        self.front = None
+        if cfg.frontend == "cohmix":
+            from . import rxfront
+            rp = dict(oftype=cfg.oftype, obw=cfg.obw, oord=cfg.oord, eftype=cfg.eftype, ebw=cfg.ebw, eord=cfg.eord,
+                      lopower=cfg.lopower)
+            hopt, elo, hel, post_delay, _ = rxfront._front_tables(1, rp, nfc=1)
+            # in-line amplifier restoring the span loss, folded into the optical filter table (no extra sweep)
+            hopt = hopt * math.exp(0.5 * self.alphalin * cfg.length * cfg.nspans)
+            r = cfg.nt // 2                                                    # RxPdmCohQpsk.m:49-53, 2 samples/symbol
+            delay = rxfront.evaldelay(cfg.oftype, cfg.obw * 0.5) + rxfront.evaldelay(cfg.eftype, cfg.ebw) + post_delay
+            self.front_shifts = [rxfront._mround(-delay * cfg.nt)] * 2         # 'theory' delay, RxPdmCohQpsk.m:124-137
+            self.front_tables = dict(hopt=hopt, elo=elo, hel=hel, fir=rxfront.fir1_lowpass(16, 1.0 / r), decim=r)
+            self.front = rxfront._Front(n, True, self.F, hopt, elo, hel, True, cfg.adcbits, r, self.front_tables["fir"])
+        elif cfg.frontend != "pick":
+            raise ValueError("frontend must be 'pick' or 'cohmix'")
         c128 = torch.complex128
         self.rx = torch.empty((self.F, 2, self.Lrx), dtype=c128, device=self.dev)
         self.eq = torch.empty_like(self.rx)
@@ -108,6 +127,9 @@ class HotPath:
             if h:
                 self.lib.call(name, h)
         self.ssfm = self.cde = self.dsp = None
+        if self.front is not None:
+            self.front.close()
+            self.front = None
 
     # ------------------------------------------------------------------ inputs ---
     def make_batch(self, nframes, launch_scale=None):
@@ -155,7 +177,7 @@ class HotPath:
                 self._steps += steps.value
 
     def receive(self, ux, uy, noise_sigma=0.0, noise_seed=None, side_stream=None):
-        """2-sps pick (symbol centre + mid-symbol), CDE, DSP, decisions.  Returns err [F,2] (device).
+        """Front end (2-sps pick, or receiver_cohmix + ADC + decimate), CDE, DSP, decisions.  Returns err [F,2] (device).
         With side_stream the whole receiver is enqueued on that stream behind the fibre of this batch, so
         the latency-bound CMA recurrence overlaps the HBM-bound fibre sweeps of the NEXT batch."""
         if side_stream is not None:
@@ -170,9 +192,12 @@ class HotPath:
         half = cfg.nt // 2
         st = self.stream()
         rx = self.rx[:F]
-        for pol, src in enumerate((ux, uy)):   # rx[f][pol][i] = scale * u_pol[f][i*half]
-            self.lib.call("plx_pick_dev", src.data_ptr(), rx.data_ptr() + pol * self.Lrx * 16, cfg.nfft, self.Lrx, 0,
-                          half, self.rx_scale, F, 2 * self.Lrx, st)
+        if self.front is not None:             # receiver_cohmix + ADC + decimate; ux, uy are consumed
+            self.front.run(ux, uy, self.front_shifts, out=rx)
+        else:
+            for pol, src in enumerate((ux, uy)):   # rx[f][pol][i] = scale * u_pol[f][i*half]
+                self.lib.call("plx_pick_dev", src.data_ptr(), rx.data_ptr() + pol * self.Lrx * 16, cfg.nfft, self.Lrx, 0,
+                              half, self.rx_scale, F, 2 * self.Lrx, st)
         if noise_sigma:
             g = self.torch.Generator(device=self.dev)
             g.manual_seed(int(noise_seed or 0))

@@ -1,0 +1,306 @@
+"""Coherent front end: the step between fiber() and CDE_OFDE(), mirroring the reference signatures
+
+  Hf = myfilter(ftype, f, bw, ord)                         myfilter.m:40-152
+  y = evaldelay(ftype, bw)                                 evaldelay.m
+  [Iric, x] = receiver_cohmix(ich, x)                      receiver_cohmix.m:95-307
+  [RxSamples, worsteyeop] = RxPdmCohQpsk(chNum, symbolPattern, RxParams)   RxPdmCohQpsk.m:3-87
+
+Host code builds the O(Nfft) tables (filters, local oscillator, decimation FIR) once; the per-sample work
+(two spectral filters, hybrids + photodiodes, ADC, timing shift, decimation) runs on the GPU behind
+plx_front_* (include/polmux_hip.h).  No CPU implementation exists here.
+
+decimate(x,r,16,'fir') is MathWorks Signal Processing Toolbox code, not part of the reference: the FIR is
+the published fir1 design (Hamming-windowed ideal low-pass, unit DC gain) and the edge/phase convention is
+the one stated in DESIGN.md ("front end"); parity is unpinned at that boundary.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _abi
+from .gstate import GSTATE, CONSTANTS
+
+# myfilter.m:59-71
+_R4P2R2 = 2.61312592975275
+_B1, _B2, _B3 = 3.86370330515627315, 7.4641016151377546, 9.1416201726856413
+_B4, _B5 = _B2, _B1
+_BB = 0.3863
+_D0, _D1, _D2, _D3, _D4 = 945, 945, 420, 105, 15
+
+
+def myfilter(ftype, f, bw, ord=None):
+    """Hf = myfilter(ftype, f, bw, ord): frequency response on the grid f, 3-dB bandwidth bw (myfilter.m:73-152)."""
+    x = np.asarray(f, dtype=float).reshape(-1) / bw
+    ftype = ftype.lower()
+    if ftype == "movavg":
+        return np.sinc(x)
+    if ftype == "gauss":
+        return np.exp(-0.5 * math.log(2) * x * x)
+    if ftype == "gauss_off":
+        return np.exp(-0.5 * math.log(2) * (x - ord / bw) * (x - ord / bw))
+    if ftype == "butt2":
+        return 1.0 / (1 - x * x + 1j * math.sqrt(2) * x)
+    if ftype == "butt4":
+        x2 = x * x
+        umx2 = 1 - x2
+        return 1.0 / (umx2 * umx2 - math.sqrt(2) * x2 + 1j * _R4P2R2 * x * umx2)
+    if ftype == "butt6":
+        x2 = x * x; x3 = x2 * x; x4 = x3 * x; x5 = x4 * x; x6 = x5 * x
+        return 1.0 / (1. - _B2 * x2 + _B4 * x4 - x6 + 1j * (_B1 * x - _B3 * x3 + _B5 * x5))
+    if ftype == "ideal":
+        return (np.abs(x) <= 1).astype(float)
+    if ftype == "bessel5":
+        om = 2 * math.pi * x * _BB
+        om2 = om * om; om3 = om2 * om; om4 = om3 * om; om5 = om4 * om
+        pre = _D0 - _D2 * om2 + _D4 * om4
+        pim = _D1 * om - _D3 * om3 + om5
+        return _D0 / (pre + 1j * pim)
+    if ftype == "rc1":
+        return 1.0 / (1 + 1j * x)
+    if ftype == "rc2":
+        return 1.0 / (1 + 1j * math.sqrt(math.sqrt(2) - 1) * x) ** 2
+    if ftype == "supergauss":
+        if ord is None:
+            raise ValueError("missing superGauss order")
+        return np.exp(-0.5 * math.log(2) * x ** (2 * ord))
+    raise ValueError("the filter ftype does not exist.")
+
+
+def evaldelay(ftype, bw):
+    """Group delay of myfilter's responses in symbols (evaldelay.m)."""
+    ftype = ftype.lower()
+    if ftype in ("movavg", "gauss", "gauss_off", "ideal", "supergauss"):
+        return 0.0
+    if ftype == "butt2":
+        return 1.11 * math.sqrt(2) / (2 * math.pi * bw)
+    if ftype == "butt4":
+        return 1.1 * _R4P2R2 / (2 * math.pi * bw)
+    if ftype == "butt6":
+        return 1.1 * _B1 / (2 * math.pi * bw)
+    if ftype == "bessel5":
+        return _BB / bw
+    if ftype == "rc1":
+        return 1 / (2 * math.pi * bw)
+    if ftype == "rc2":
+        return (math.sqrt(2) - 1) / (math.pi * bw)
+    raise ValueError("the filter ftype does not exist.")
+
+
+def fir1_lowpass(order, wn):
+    """fir1(order, wn): Hamming-windowed ideal low-pass, cut-off wn (1 = Nyquist), scaled to unit gain at DC
+    (the documented window-method design; order+1 taps)."""
+    k = np.arange(order + 1)
+    w = 0.54 - 0.46 * np.cos(2 * math.pi * k / order)
+    b = wn * np.sinc(wn * (k - order / 2.0)) * w
+    return b / b.sum()
+
+
+def _nmod(a, n):
+    return (np.asarray(a) - 1) % n + 1
+
+
+def _front_tables(ich, x, rng=None, nfc=None):
+    """Everything receiver_cohmix.m:97-227,296 derives from x and GSTATE: (hopt, elo or scalar, hel, post_delay, b2b)."""
+    CL = CONSTANTS.CLIGHT
+    fn = np.asarray(GSTATE.FN, dtype=float)
+    nfft = fn.size
+    if nfc is None:
+        nfc = GSTATE.FIELDX.shape[0]
+    if nfc != GSTATE.NCH:
+        raise NotImplementedError("receiver_cohmix on a 'unique' multi-channel field (spectral channel selection, "
+                                  "receiver_cohmix.m:104-125) is outside the accelerated path; use 'sepfields'")
+    b2b = False
+    if "b2b" in x:                                                    # :132-141
+        if x["b2b"] != "b2b":
+            raise ValueError("the b2b field must be 'b2b'")
+        b2b = True
+    post_delay = 0.0
+    if "dpost" in x and not b2b:                                      # :149-168
+        lamv = np.atleast_1d(np.asarray(GSTATE.LAMBDA, dtype=float))
+        maxl, minl = lamv.max(), lamv.min()
+        lamc = 2 * maxl * minl / (maxl + minl)
+        lam = x["lambda"]
+        b20z = -lam ** 2 / 2 / math.pi / CL * x["dpost"] * 1e-3
+        b30z = (lam / 2 / math.pi / CL) ** 2 * (2 * lam * x["dpost"] + lam ** 2 * x["slopez"]) * 1e-3
+        d_i0 = 2 * math.pi * CL * (1.0 / lamv[ich - 1] - 1 / lam)
+        d_ic = 2 * math.pi * CL * (1.0 / lamv[ich - 1] - 1 / lamc)
+        d_c0 = 2 * math.pi * CL * (1.0 / lamc - 1 / lam)
+        beta1z = b20z * d_ic + 0.5 * b30z * (d_i0 ** 2 - d_c0 ** 2)
+        beta2z = b20z + b30z * d_i0
+        omega = 2 * math.pi * GSTATE.SYMBOLRATE * fn
+        betat = omega * beta1z + 0.5 * omega ** 2 * beta2z + omega ** 3 * b30z / 6
+        post_delay = GSTATE.SYMBOLRATE * beta1z
+        hf = np.cos(-betat) + 1j * np.sin(-betat)                     # fastexp(-betat)
+    else:
+        hf = np.ones(nfft, dtype=complex)
+    hopt = hf * myfilter(x["oftype"], fn, 0.5 * x["obw"], x.get("oord"))   # :169
+    if x.get("lodetuning"):                                           # :193-203
+        minfreq = GSTATE.SYMBOLRATE * 1e9 / GSTATE.NSYMB
+        kdet = math.floor(x["lodetuning"] / minfreq)
+        det = 2 * math.pi * kdet / nfft * np.arange(1, nfft + 1)
+    else:
+        det = None
+    if "lophasenoise" in x:                                           # :204-208
+        pn = np.asarray(x["lophasenoise"], dtype=float).reshape(-1)
+        if pn.size != nfft:
+            raise ValueError("Incompatible vector.")
+    elif "lolinewidth" in x:                                          # :209-216 (randn -> numpy Generator)
+        rng = rng or np.random.default_rng()
+        fnz = math.sqrt(2 * math.pi * x["lolinewidth"] / GSTATE.NT) * rng.standard_normal(nfft)
+        fnz[0] = 0
+        pn = np.cumsum(fnz)
+        pn = pn - np.arange(nfft) / (nfft - 1) * pn[-1]               # Brownian bridge
+    else:
+        pn = None
+    ecw = 10 ** (x["lopower"] / 20) if "lopower" in x else 1.0        # :220-224
+    if det is None and pn is None:
+        elo = ecw                                                     # fastexp(0) = 1
+    else:
+        ph = (0 if det is None else det) + (0 if pn is None else pn)
+        elo = ecw * (np.cos(ph) + 1j * np.sin(ph))                    # :227
+    hel = myfilter(x["eftype"], fn, x["ebw"], x.get("eord"))          # :296
+    return hopt, elo, hel, post_delay, b2b
+
+
+class _Front:
+    """A plx_front plan plus the host tables that built it."""
+
+    def __init__(self, nfft, dual, max_frames, hopt, elo, hel, balanced=True, adcbits=0, decim=1, fir=None):
+        self.lib = _abi.get()
+        d = _abi.FrontDesc()
+        d.nfft, d.dual_pol, d.max_frames, d.balanced, d.adcbits, d.decim = nfft, int(dual), max_frames, int(balanced), adcbits, decim
+        keep = []
+
+        def vec(a):
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            keep.append(a)
+            return a.ctypes.data
+
+        hopt = np.asarray(hopt, dtype=complex); hel = np.asarray(hel, dtype=complex)
+        d.hopt_re, d.hopt_im = vec(hopt.real), vec(hopt.imag)
+        d.hel_re, d.hel_im = vec(hel.real), vec(hel.imag)
+        if np.ndim(elo) == 0:
+            if np.imag(elo) != 0:
+                elo = np.full(nfft, elo, dtype=complex)
+            else:
+                d.elo_scalar = float(np.real(elo))
+        if np.ndim(elo) != 0:
+            elo = np.asarray(elo, dtype=complex)
+            d.elo_re, d.elo_im = vec(elo.real), vec(elo.imag)
+        if decim > 1:
+            d.ntaps, d.fir = len(fir), vec(fir)
+        self.plan = C.c_void_p()
+        self.lib.call("plx_front_create", C.byref(self.plan), C.byref(d))
+        self.nout = int(self.lib.lib.plx_front_out_len(self.plan))
+        self.dual, self.nfft = bool(dual), nfft
+
+    def run(self, ux, uy, shifts=None, out=None):
+        """ux, uy: torch complex128 [F, nfft] (overwritten with the photocurrents I + jQ); returns [F, npol, nout]."""
+        import torch
+        F = ux.shape[0]
+        npol = 2 if self.dual else 1
+        if out is None:
+            out = torch.empty((F, npol, self.nout), dtype=torch.complex128, device=ux.device)
+        sh = (C.c_int64 * 2)(*(list(shifts) + [0, 0])[:2]) if shifts is not None else None
+        self.lib.call("plx_front_run_dev", self.plan, ux.data_ptr(), uy.data_ptr() if self.dual else None, F, sh,
+                      out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        return out
+
+    def close(self):
+        if self.plan:
+            self.lib.call("plx_front_destroy", self.plan)
+            self.plan = None
+
+
+def _channel_fields(ich, b2b):
+    fx = GSTATE.FIELDX_TX if b2b else GSTATE.FIELDX
+    fy = GSTATE.FIELDY_TX if b2b else GSTATE.FIELDY
+    if fx is None:
+        raise ValueError("GSTATE.FIELDX is empty")
+    ux = fx[ich - 1:ich].clone()
+    if GSTATE.FIELDY is None:
+        return ux, None
+    uy = fy[ich - 1:ich].clone() if fy is not None else ux * 0          # :230-236
+    return ux, uy
+
+
+def receiver_cohmix(ich, x, rng=None):
+    """[Iric, x] = receiver_cohmix(ich, x): photocurrents [Nfft x 2] (X: I, Q) or [Nfft x 4] ([X Y]) as a torch
+    float64 CUDA tensor, and x with post_delay added (receiver_cohmix.m:95-307).  x.avgebx/avgeby (:185-187,
+    diagnostics) are not produced."""
+    import torch
+    hopt, elo, hel, post_delay, b2b = _front_tables(ich, x, rng)
+    ux, uy = _channel_fields(ich, b2b)
+    balanced = not (x.get("pdtype") == "normal")                      # :265-269
+    fr = _Front(ux.shape[1], uy is not None, 1, hopt, elo, hel, balanced)
+    try:
+        fr.run(ux, uy)
+    finally:
+        fr.close()
+    cols = [ux[0].real, ux[0].imag] + ([uy[0].real, uy[0].imag] if uy is not None else [])
+    x = dict(x)
+    x["post_delay"] = post_delay
+    return torch.stack(cols, 1), x
+
+
+def theory_delay(ich, x, isy, post_delay):
+    """delay of mygeteyeinfo with x.delay == 'theory' (RxPdmCohQpsk.m:124-137)."""
+    if x.get("b2b") == "b2b":
+        avg = 0.0
+    elif isy:
+        avg = 0.5 * (GSTATE.DELAY[0, ich - 1] + GSTATE.DELAY[1, ich - 1])
+    else:
+        avg = GSTATE.DELAY[0, ich - 1]
+    return avg + evaldelay(x["oftype"], x["obw"] * 0.5) + evaldelay(x["eftype"], x["ebw"]) + post_delay
+
+
+def rx_plan(chNum, RxParams, isy, max_frames=1, rng=None):
+    """The plx_front plan + timing shifts of one RxPdmCohQpsk configuration, for batched use (pipeline.HotPath)."""
+    if RxParams.get("rec") != "coherent":
+        raise ValueError("Flag X.rec must be 'coherent'")
+    hopt, elo, hel, post_delay, b2b = _front_tables(chNum, RxParams, rng)
+    if RxParams.get("delay") != "theory" and "delay_symbols" not in RxParams:
+        raise NotImplementedError("delay estimation by correlation (corrdelay.m) is host-side diagnostics outside the "
+                                  "accelerated path: use RxParams.delay = 'theory'")
+    dual = GSTATE.FIELDY is not None
+    npol = 2 if (dual and isy) else 1
+    if "delay_symbols" in RxParams:
+        delay = np.ones(npol) * np.asarray(RxParams["delay_symbols"], dtype=float)
+    else:
+        delay = np.ones(npol) * theory_delay(chNum, RxParams, isy, post_delay)
+    shifts = [int(_mround(-d * GSTATE.NT)) for d in delay]            # RxPdmCohQpsk.m:43
+    r = RxParams["sps"] if RxParams.get("workatbaudrate") else RxParams["sps"] / 2   # :49-53
+    if r != int(r) or r < 1:
+        raise ValueError("the decimation rate must be a positive integer")
+    r = int(r)
+    fir = fir1_lowpass(16, 1.0 / r) if r > 1 else None
+    nfft = GSTATE.FIELDX.shape[1]
+    balanced = not (RxParams.get("pdtype") == "normal")
+    adc = int(RxParams["adcbits"]) if RxParams.get("applyadc") else 0
+    # a Y field created along propagation carries no pattern: only X is used then (RxPdmCohQpsk.m:20-33)
+    fr = _Front(nfft, npol == 2, max_frames, hopt, elo, hel, balanced, adc, r, fir)
+    return fr, shifts, dict(post_delay=post_delay, delay=delay, decim=r, fir=fir, hopt=hopt, elo=elo, hel=hel, b2b=b2b)
+
+
+def _mround(v):
+    """MATLAB round (half away from zero)."""
+    return math.floor(abs(v) + 0.5) * (1 if v >= 0 else -1)
+
+
+def RxPdmCohQpsk(chNum, symbolPattern, RxParams, rng=None):
+    """[RxSamples, worsteyeop] = RxPdmCohQpsk(chNum, symbolPattern, RxParams)  RxPdmCohQpsk.m:3-87.
+    RxSamples: torch complex128 [nout, 1 or 2] on the GPU.  worsteyeop (the eye-opening diagnostic of
+    mygeteyeinfo, :139-166) is not evaluated on the device path and is returned as NaN; RxParams.applydcf
+    (DispCompFilter, :74-84) is served by CDE_OFDE in this chain and raises if requested."""
+    if RxParams.get("applydcf"):
+        raise NotImplementedError("RxParams.applydcf (DispCompFilter) is not part of the accelerated path; use CDE_OFDE")
+    sp = np.asarray(symbolPattern)
+    isy = GSTATE.FIELDY is not None and sp.ndim == 2 and sp.shape[1] != 1      # :27-33
+    fr, shifts, info = rx_plan(chNum, RxParams, isy, 1, rng)
+    try:
+        ux, uy = _channel_fields(chNum, info["b2b"])
+        out = fr.run(ux, uy if fr.dual else None, shifts)
+    finally:
+        fr.close()
+    return out[0].transpose(0, 1).contiguous(), float("nan")

@@ -1,0 +1,37 @@
+# dev tool: multi-channel dual-pol matrix_ssfm gateway vs oracle.  args: nch nplates flag slope length nt
+import sys, ctypes as C, numpy as np
+import os; ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0,ROOT)
+from polmux_amd import _abi
+from oracle import plxo as oracle
+from polmux_amd import synth
+from polmux_amd._abi import SsfmDesc
+from polmux_amd.fiber import parse_flag, fiber_tables
+from polmux_amd.gstate import GSTATE
+import polmux_amd as px
+emu=_abi.get()
+nsymb,nt,nch,nplates=64,int(sys.argv[6]) if len(sys.argv)>6 else 16,int(sys.argv[1]),int(sys.argv[2])
+flag=sys.argv[3]
+n=nsymb*nt
+px.reset_all(nsymb,nt,nch); GSTATE.SYMBOLRATE=28.0
+GSTATE.NCH=nch; GSTATE.LAMBDA=1550.0+0.4*(np.arange(nch)-(nch-1)/2) if nch>1 else np.array([1550.0])
+LL=float(sys.argv[5]) if len(sys.argv)>5 else 8e4
+x=dict(length=LL, alphadB=0.2, aeff=80.0, n2=2.7e-20, disp=17.0, slope=float(sys.argv[4]), dphimax=5e-3, dzmax=2e4, dgd=0.2, manakov="no"); x["lambda"]=1550.0
+fls,dph,dzm=parse_flag(flag,nch,x)
+dgdrms=x["dgd"]/nplates
+t=fiber_tables(x,fls,nch,dgdrms)
+cols=[synth.pdm_qpsk_field(nsymb,nt,3.0*(1+0.1*(k%5)),2+2*k,3+2*k) for k in range(nch)]
+sx=np.stack([c[0] for c in cols],1); sy=np.stack([c[1] for c in cols],1)
+r=np.random.default_rng(100)
+db0=r.random(nplates)*2*np.pi-np.pi; th=r.random(nplates)*np.pi-np.pi/2; ep=0.5*np.arcsin(r.random(nplates)*2-1)
+d=SsfmDesc(); d.nfft,d.nfc,d.dual_pol,d.max_frames=n,nch,1,1
+for i in range(4): d.fls[i]=fls[i]
+d.dzmaxt,d.dphimaxt,d.alphalin,d.length,d.nplates,d.manakov=dzm,dph,t["alphalin"],LL,nplates,0
+gam=np.ascontiguousarray(t["gam"]); d.gam,d.betat,d.db1=gam.ctypes.data,t["betat"].ctypes.data,t["db1"].ctypes.data
+planes=[np.asfortranarray(v.copy()) for v in (sx.real,sx.imag,sy.real,sy.imag)]
+fd,nc=C.c_double(),C.c_int32()
+vp=lambda a:C.c_void_p(a.ctypes.data)
+emu.call("plx_matrix_ssfm",*[vp(p) for p in planes],C.byref(d),vp(db0),vp(th),vp(ep),C.byref(fd),C.byref(nc))
+rc,ofd,onc,ox,oy=oracle.matrix_ssfm(sx,sy,t["betat"],t["db1"],dzm,dph,gam,t["alphalin"],LL,nplates,False,fls,db0,th,ep)
+gx=planes[0]+1j*planes[1]
+print("nc",nc.value,onc,"fd",fd.value,ofd,"relerr per ch",np.abs(gx-ox).max(0)/np.abs(ox).max())
+print("max betat*L", np.abs(t["betat"]).max()*8e4)

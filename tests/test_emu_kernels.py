@@ -385,3 +385,69 @@ def test_emu_ampliflat_injected_and_philox(emu):
     w = z2.view(np.complex128).reshape(F, nfc, n)
     np.testing.assert_array_equal(w[0], zz[0])
     assert not np.array_equal(w[1], zz[1])
+
+
+def _front_case(nsymb, nt, seed=5):
+    from polmux_amd import rxfront
+    n = nsymb * nt
+    ux, uy, bits, pw = synth.pdm_qpsk_field(nsymb, nt, 2.0, 4, 5)
+    fn = synth.fn_grid(nsymb, nt)
+    omega = 2 * np.pi * 28 * fn
+    hopt = np.exp(-1j * (0.5 * omega ** 2 * 3.1e-3)) * rxfront.myfilter("gauss", fn, 0.95)
+    hel = rxfront.myfilter("bessel5", fn, 0.65)
+    r = np.random.default_rng(seed)
+    pn = np.cumsum(r.standard_normal(n)) * 0.01
+    elo = 10 ** (1.5 / 20) * np.exp(1j * (2 * np.pi * 3 / n * np.arange(1, n + 1) + pn))
+    return n, ux, uy, hopt, hel, elo
+
+
+def _front_desc(n, dual, frames, hopt, hel, elo, balanced, bits, r, fir):
+    from polmux_amd._abi import FrontDesc
+    d = FrontDesc()
+    d.nfft, d.dual_pol, d.max_frames, d.balanced, d.adcbits, d.decim = n, dual, frames, balanced, bits, r
+    keep = [np.ascontiguousarray(v, dtype=np.float64) for v in (hopt.real, hopt.imag, hel.real, hel.imag)]
+    d.hopt_re, d.hopt_im, d.hel_re, d.hel_im = (k.ctypes.data for k in keep)
+    if np.ndim(elo):
+        keep += [np.ascontiguousarray(elo.real), np.ascontiguousarray(elo.imag)]
+        d.elo_re, d.elo_im = keep[-2].ctypes.data, keep[-1].ctypes.data
+    else:
+        d.elo_scalar = float(elo)
+    if r > 1:
+        keep.append(np.ascontiguousarray(fir, dtype=np.float64))
+        d.ntaps, d.fir = len(fir), keep[-1].ctypes.data
+    d._keep = keep
+    return d
+
+
+@pytest.mark.parametrize("dual,balanced,bits,r,lo_table", [(1, 1, 5, 16, True), (0, 0, 0, 1, False), (1, 1, 0, 8, False)])
+def test_emu_front_end(emu, dual, balanced, bits, r, lo_table):
+    """plx_front_*: optical filter + hybrids + photodiodes + low-pass (receiver_cohmix.m:183-307), ADC + fastshift +
+    decimation (RxPdmCohQpsk.m:36-72) against oracle/front.py; two frames with different content."""
+    from oracle import front
+    from polmux_amd import rxfront
+    n, ux, uy, hopt, hel, elo = _front_case(64, 16)
+    if not lo_table:
+        elo = 1.25
+    fir = rxfront.fir1_lowpass(16, 1.0 / r) if r > 1 else None
+    d = _front_desc(n, dual, 2, hopt, hel, elo, balanced, bits, r, fir)
+    plan = C.c_void_p()
+    emu.call("plx_front_create", C.byref(plan), C.byref(d))
+    nout = emu.lib.plx_front_out_len(plan)
+    assert nout == -(-n // r)
+    fx = np.stack([ux, 0.7j * np.roll(ux, 37)]); fy = np.stack([uy, 1.3 * np.roll(uy, -11)])
+    gx, gy = _il(fx), _il(fy)
+    out = np.zeros(2 * (dual + 1) * nout * 2)
+    sh = (C.c_int64 * 2)(-13, 21)
+    emu.call("plx_front_run_dev", plan, _vp(gx), _vp(gy) if dual else None, 2, sh, _vp(out), None)
+    emu.call("plx_front_destroy", plan)
+    out = out.view(np.complex128).reshape(2, dual + 1, nout)
+    cur_x = gx.view(np.complex128).reshape(2, n); cur_y = gy.view(np.complex128).reshape(2, n)
+    for f in range(2):
+        want = front.receiver_cohmix(fx[f], fy[f] if dual else None, hopt, elo, hel, bool(balanced))
+        got = np.stack([cur_x[f].real, cur_x[f].imag] + ([cur_y[f].real, cur_y[f].imag] if dual else []), 1)
+        assert np.abs(got - want).max() < 1e-12 * np.abs(want).max()
+        # downstream of the (discontinuous) ADC: the oracle continues from the device's own currents
+        rx = front.rx_front(got, bool(dual), bits, [-13, 21 if dual else -13], r, fir)
+        assert np.abs(out[f].T - rx).max() <= 1e-14 * np.abs(rx).max()
+        full = front.rx_front(want, bool(dual), bits, [-13, 21 if dual else -13], r, fir)
+        assert np.mean(np.abs(out[f].T - full) > 1e-9 * np.abs(full).max()) < 0.01   # at most isolated LSB flips
