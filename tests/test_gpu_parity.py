@@ -845,3 +845,45 @@ def test_hot_path_with_reference_front_end_vs_oracle(lib, oracle):
     assert err.cpu().numpy()[0].tolist() == e
     assert int(hp.errors_resolved(2).sum()) == 0                        # noise-free span: error-free after ambiguity resolution
     hp.close()
+
+
+def test_run_my_pdm_qpsk_script_vs_oracle(lib, oracle):
+    """examples/run_my_pdm_qpsk.py = Run_my_PDM_QPSK.m:100-199 on the device path (shipped parameters at a quarter of
+    the shipped length), against the oracle chain fed with the same Tx field: decoded bits identical, symbols 1e-7."""
+    import importlib.util
+    import os
+    from oracle import front
+    from polmux_amd import rxfront
+    from polmux_amd.fiber import fiber_tables, parse_flag
+    from polmux_amd.gstate import GSTATE, to_host_field
+    spec = importlib.util.spec_from_file_location("run_my_pdm_qpsk", os.path.join(os.path.dirname(__file__), "..", "examples",
+                                                                                    "run_my_pdm_qpsk.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    nsymb, nt = 1024, 64
+    res = mod.main(nsymb, nt, quiet=True)
+    assert len(res["lines"]) == 2 and res["lines"][0].startswith("Ch 1 Pol X Match: ")
+    fib, rp = res["fib"], res["RxParams"]
+    tx_x, tx_y = to_host_field(GSTATE.FIELDX_TX), to_host_field(GSTATE.FIELDY_TX)
+    fls, dph, dzm = parse_flag("g---", 1, fib)
+    t = fiber_tables(fib, fls, 1, 0.0)
+    rc, fd, nc, ox, oy = oracle.matrix_ssfm(tx_x, tx_y, t["betat"], t["db1"], dzm, dph, t["gam"], t["alphalin"], fib["length"],
+                                            1, 0, fls, [0.0], [0.0], [0.0])
+    assert nc == 1                                                                 # linear: one exact step, fiber.m:162-165
+    hopt, elo, hel, post_delay, _ = rxfront._front_tables(1, rp)
+    cur = front.receiver_cohmix(ox[:, 0], oy[:, 0], hopt, elo, hel, True)
+    shift = rxfront._mround(-rxfront.theory_delay(1, rp, True, post_delay) * nt)
+    rx = front.rx_front(cur, True, 5, [shift, shift], nt // 2, rxfront.fir1_lowpass(16, 2.0 / nt))
+    grx = res["RxSamplCompXY"].cpu().numpy()
+    assert np.mean(np.abs(grx - rx) > 1e-9 * np.abs(rx).max()) < 2e-3
+    ex, ey, _ = oracle.cde_ofde(rx[:, 0], rx[:, 1], 20e9, 1310e-9, fib["length"], 60e-6, 0.0, 256, 128)
+    power = float(GSTATE.POWER[0])
+    op = oracle.dsp_params(power_mw=power, applypol=False, freqavg=500, phasavg=3, poworder=2)
+    ref = oracle.dsp_pdm_coh_qpsk(np.stack([ex, ey], 1), op)
+    sym = res["OutSampCompXY"].cpu().numpy().T
+    if np.abs(grx - rx).max() <= 1e-9 * np.abs(rx).max():
+        np.testing.assert_allclose(sym, ref, atol=1e-7)
+    want = oracle.samp2pat_coherent(np.angle(ref))
+    np.testing.assert_array_equal(res["RxBits4D"], want)
+    m = int((res["TxBits4D"][0][:, :2] == want[:, :2]).sum())
+    assert res["lines"][0] == "Ch 1 Pol X Match: %d / %d | Errors: %d" % (m, 2 * nsymb, 2 * nsymb - m)
