@@ -221,6 +221,23 @@ int64_t plx_front_out_len(const plx_front *plan);   /* ceil(nfft / decim) */
 int plx_front_run_dev(plx_front *plan, double *d_ux, double *d_uy, int nframes, const int64_t *shift,
                       double *d_out, void *stream);
 
+/* ------------------------------------------------------------------ inverse PMD --- */
+/* inverse_pmd(brf, options)  inverse_pmd.m:91-145: the per-frequency PMD matrix U of a link of `nfibers` fibres
+ * (brf{n} as returned by fiber), Uinv = U^H, and its application to a unique dual-polarisation field.
+ * set_link: ntrunk[nfibers]; db0/theta/epsilon concatenated over fibres, [nsets][sum ntrunk] (nsets = 1: one link
+ * for every frame; nsets = frames: a waveplate draw per frame); lcorr[nfibers]; betat, db1: [nfibers][nfft]
+ * (brf{n}.betat, brf{n}.db1); mat: options.mat as 8 doubles (row-major re,im) or NULL; apply_gvd 0: options.gvd='no'. */
+typedef struct plx_pmdinv plx_pmdinv;
+int plx_pmdinv_create(plx_pmdinv **plan, int64_t nfft, int max_frames);
+int plx_pmdinv_destroy(plx_pmdinv *plan);
+int plx_pmdinv_set_link(plx_pmdinv *plan, int nfibers, const int32_t *ntrunk, const double *db0, const double *theta,
+                        const double *epsilon, const double *lcorr, const double *betat, const double *db1,
+                        const double *mat, int apply_gvd, int nsets);
+/* FIELD = ifft(Uinv * fft(FIELD)) in place, d_ux/d_uy [nframes][nfft] complex128 (inverse_pmd.m:139-145) */
+int plx_pmdinv_apply_dev(plx_pmdinv *plan, double *d_ux, double *d_uy, int nframes, void *stream);
+/* host copies of U and/or Uinv of one frame in MATLAB's [2][2][nfft] column-major layout, interleaved complex */
+int plx_pmdinv_matrices(plx_pmdinv *plan, int frame, double *U, double *Uinv);
+
 /* ------------------------------------------------------------ small helpers --- */
 /* strided pick + scale used between fibre and CDE when the full front end
  * (receiver_cohmix + decimate) is not in the chain:

@@ -85,6 +85,11 @@ SIGNATURES = {
     "plx_front_destroy": [_vp],
     "plx_front_out_len": [_vp],
     "plx_front_run_dev": [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
+    "plx_pmdinv_create": [C.POINTER(_vp), _i64, C.c_int],
+    "plx_pmdinv_destroy": [_vp],
+    "plx_pmdinv_set_link": [_vp, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int],
+    "plx_pmdinv_apply_dev": [_vp, _vp, _vp, C.c_int, _vp],
+    "plx_pmdinv_matrices": [_vp, C.c_int, _vp, _vp],
     "plx_pick_dev": [_vp, _vp, _i64, _i64, _i64, _i64, _dbl, C.c_int, _i64, _vp],
 }
 _RESTYPES = {"plx_dsp_out_len": _i64, "plx_front_out_len": _i64}

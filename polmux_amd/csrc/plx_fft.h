@@ -333,8 +333,8 @@ __device__ __forceinline__ void lds_load_twiddles(cplx *dst, const cplx *__restr
     for (int k = tid; k < halfM; k += nthr) dst[k] = src[k];
 }
 
-// ---- host helpers ---------------------------------------------------------------
-static inline unsigned plx_bitrev(unsigned i, int bits)
+// ---- index helper (host and device) ----------------------------------------------
+__host__ __device__ static inline unsigned plx_bitrev(unsigned i, int bits)
 {
     unsigned r = 0;
     for (int b = 0; b < bits; b++) r = (r << 1) | ((i >> b) & 1u);

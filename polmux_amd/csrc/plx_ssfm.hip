@@ -51,6 +51,7 @@ struct SsfmArgs {
     const double *betat_p, *db1_p; // [nfc][N], bit-reversed/transposed order
     const cplx *tpass;             // [N] inter-pass twiddles W_N^(n2*k1), same order
     const cplx *hmul;              // [N] general spectral multiplier replacing exp(-i betat dz) (filter passes), same order
+    const cplx *umat;              // [F][N][3] per frequency: SU(2) row (U11, U12) and scalar Hgvd; applies (Hgvd U)^H (inverse_pmd.m:130-141)
     const cplx *tw1, *tw2;         // half tables W_N1^k, W_N2^k
     const double *gam;             // [nfc] effective gamma (x8/9 when Manakov, :499-501)
     const double *brf;             // [sets][nplates][9]: R11 R12 R21 R22 (re,im) db0
@@ -477,6 +478,13 @@ __global__ __launch_bounds__(256) void k_row(SsfmArgs a)
         // zero birefringence, one trunk (fiber.m:291-297): matR = I, deltabeta = 0
         for (int e = tid; e < nel; e += nthr) {
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+            if (a.umat) { // Uinv = conj(Hgvd) [conj(U11) -U12; conj(U12) U11] applied to [x; y]  (inverse_pmd.m:130-141)
+                const cplx *um = a.umat + 3 * ((size_t)f * N + rowbase + e);
+                const cplx u11 = um[0], u12 = um[1], hg = um[2], x = s[o], y = s[o + R * TSp];
+                s[o] = cmulc(csub(cmulc(x, u11), cmul(u12, y)), hg);
+                s[o + R * TSp] = cmulc(cadd(cmulc(x, u12), cmul(u11, y)), hg);
+                continue;
+            }
             const cplx h = a.hmul ? a.hmul[rowbase + e] : (a.dbg & 8) ? make_double2(1.0, bt[e]) : cexp_neg_turns(bt[e] * cur);
             s[o] = cmul(h, s[o]);
             s[o + R * TSp] = cmul(h, s[o + R * TSp]);
@@ -1625,14 +1633,17 @@ int plx_ssfm_filter_table(plx_ssfm *P, const double *h_re, const double *h_im, c
     return PLX_OK;
 }
 
-int plx_ssfm_filter_dev(plx_ssfm *P, cplx *d_ux, cplx *d_uy, const cplx *d_hmul, int nframes, void *stream)
+void plx_ssfm_geometry(const plx_ssfm *P, int *p1, int *p2) { *p1 = P->p1; *p2 = P->p2; }
+
+int plx_ssfm_filter_dev(plx_ssfm *P, cplx *d_ux, cplx *d_uy, const cplx *d_hmul, int nframes, void *stream, const cplx *d_umat)
 {
-    if (!P || !d_ux || !d_hmul) PLX_FAIL(PLX_ERR_ARG, "filter: null argument");
+    if (!P || !d_ux || (!d_hmul && !d_umat)) PLX_FAIL(PLX_ERR_ARG, "filter: null argument");
+    if (d_umat && (!P->a.dual || P->a.nfc != 1)) PLX_FAIL(PLX_ERR_ARG, "filter: matrix tables need a dual-polarisation single-field plan");
     if (nframes < 1 || nframes > P->d.max_frames) PLX_FAIL(PLX_ERR_ARG, "filter: nframes outside [1, max_frames]");
     if (P->a.dual && !d_uy) PLX_FAIL(PLX_ERR_ARG, "filter: dual-polarisation plan needs d_uy");
     hipStream_t st = (hipStream_t)stream;
     SsfmArgs b = P->a;
-    b.ux = d_ux; b.uy = d_uy; b.nframes = nframes; b.hmul = d_hmul;
+    b.ux = d_ux; b.uy = d_uy; b.nframes = nframes; b.hmul = d_hmul; b.umat = d_umat;
     b.force = 1; b.spm = 0; b.xpm = 0; b.pmd = 0; b.f_cur = 0; b.f_leff = 0; b.f_sc = b.invN;
     const int N1 = 1 << b.p1, N2 = 1 << b.p2;
     const unsigned FC = (unsigned)nframes * b.nfc;

@@ -451,3 +451,55 @@ def test_emu_front_end(emu, dual, balanced, bits, r, lo_table):
         assert np.abs(out[f].T - rx).max() <= 1e-14 * np.abs(rx).max()
         full = front.rx_front(want, bool(dual), bits, [-13, 21 if dual else -13], r, fir)
         assert np.mean(np.abs(out[f].T - full) > 1e-9 * np.abs(full).max()) < 0.01   # at most isolated LSB flips
+
+
+def test_emu_inverse_pmd(emu, oracle):
+    """plx_pmdinv_*: U / Uinv per frequency (inverse_pmd.m:103-136) and the application to two frames with their own
+    waveplate draws (:139-145) against oracle/pmdinv.py; options.mat and options.gvd = 'no'."""
+    from oracle import pmdinv
+    nsymb, nt, n = 64, 16, 1024
+    fn = synth.fn_grid(nsymb, nt)
+    omega = 2 * np.pi * 10.0 * fn
+    betat = 0.5 * omega ** 2 * -2.17e-8 + omega ** 3 * 1.3e-10 / 6
+    links = []
+    for nplates, seed, L, dgd in ((6, 1, 5e4, 0.3), (3, 2, 2e4, 0.6)):
+        r = np.random.default_rng(seed)
+        sets = [(r.random(nplates) * 2 * np.pi - np.pi, r.random(nplates) * np.pi - np.pi / 2, 0.5 * np.arcsin(r.random(nplates) * 2 - 1))
+                for _ in range(2)]
+        links.append(dict(nplates=nplates, lcorr=L / nplates, betat=betat * (1 + 0.1 * seed), db1=dgd / nplates / 10.0 * omega, sets=sets))
+    ux, uy, _, _ = synth.pdm_qpsk_field(nsymb, nt, 2.0)
+    fx = np.stack([ux, 1j * np.roll(uy, 5)]); fy = np.stack([uy, 0.5 * np.roll(ux, -9)])
+    c, s = np.cos(0.3), np.sin(0.3)
+    M = np.array([[c, s * 1j], [s * 1j, c]])
+    for opts in (None, dict(mat=M), dict(gvd="no")):
+        plan = C.c_void_p()
+        emu.call("plx_pmdinv_create", C.byref(plan), n, 2)
+        ntr = np.array([l["nplates"] for l in links], dtype=np.int32)
+        cat = lambda i: np.ascontiguousarray(np.stack([np.concatenate([l["sets"][f][i] for l in links]) for f in range(2)]))
+        db0, th, ep = cat(0), cat(1), cat(2)
+        lc = np.array([l["lcorr"] for l in links])
+        bt = np.ascontiguousarray(np.stack([l["betat"] for l in links])); d1 = np.ascontiguousarray(np.stack([l["db1"] for l in links]))
+        mat = None
+        if opts and "mat" in opts:
+            mat = np.ascontiguousarray(np.stack([M.real, M.imag], -1).reshape(-1))
+        emu.call("plx_pmdinv_set_link", plan, 2, _vp(ntr), _vp(db0), _vp(th), _vp(ep), _vp(lc), _vp(bt), _vp(d1),
+                 _vp(mat) if mat is not None else None, 0 if (opts and opts.get("gvd") == "no") else 1, 2)
+        gx, gy = _il(fx), _il(fy)
+        emu.call("plx_pmdinv_apply_dev", plan, _vp(gx), _vp(gy), 2, None)
+        gx = gx.view(np.complex128).reshape(2, n); gy = gy.view(np.complex128).reshape(2, n)
+        for f in range(2):
+            brf = [dict(db0=l["sets"][f][0], theta=l["sets"][f][1], epsilon=l["sets"][f][2], lcorr=l["lcorr"], betat=l["betat"],
+                        db1=l["db1"]) for l in links]
+            Uinv, U, wx, wy = pmdinv.inverse_pmd(brf, fx[f], fy[f], opts)
+            assert np.abs(gx[f] - wx).max() < 1e-12 * np.abs(wx).max()
+            assert np.abs(gy[f] - wy).max() < 1e-12 * np.abs(wy).max()
+            gU = np.zeros((n, 2, 2), dtype=complex); gUi = np.zeros_like(gU)
+            emu.call("plx_pmdinv_matrices", plan, f, _vp(gU), _vp(gUi))
+            np.testing.assert_allclose(np.transpose(gU, (2, 1, 0)), U, atol=1e-13)
+            np.testing.assert_allclose(np.transpose(gUi, (2, 1, 0)), Uinv, atol=1e-13)
+        emu.call("plx_pmdinv_destroy", plan)
+    plan = C.c_void_p()
+    emu.call("plx_pmdinv_create", C.byref(plan), n, 1)
+    with pytest.raises(Exception, match="set_link has not been called"):
+        emu.call("plx_pmdinv_apply_dev", plan, _vp(_il(fx)), _vp(_il(fy)), 1, None)
+    emu.call("plx_pmdinv_destroy", plan)

@@ -887,3 +887,79 @@ def test_run_my_pdm_qpsk_script_vs_oracle(lib, oracle):
     np.testing.assert_array_equal(res["RxBits4D"], want)
     m = int((res["TxBits4D"][0][:, :2] == want[:, :2]).sum())
     assert res["lines"][0] == "Ch 1 Pol X Match: %d / %d | Errors: %d" % (m, 2 * nsymb, 2 * nsymb - m)
+
+
+# ==================================================================== inverse PMD ===
+def test_inverse_pmd_surface_restores_field_and_matches_oracle(lib, oracle):
+    """inverse_pmd(brf) after fiber(.,'gp--') (ex24-style, 2^16 samples, 100 waveplates): the field comes back to the
+    transmitted one up to the attenuation (inverse_pmd.m help / SURVEY 8c iv); [Uinv, U] equal the oracle's per
+    frequency and Uinv*U = I (8c v); options.apply / options.gvd / cascaded fibres; the 'unique field' error."""
+    import polmux_amd as px
+    from oracle import pmdinv
+    from polmux_amd import synth
+    from polmux_amd.gstate import GSTATE, to_host_field
+    nsymb, nt = 1024, 64
+    px.reset_all(nsymb, nt, 1)
+    GSTATE.SYMBOLRATE = 10.0
+    px.lasersource(1.0, 1550.0)
+    sx, sy, _, _ = synth.pdm_qpsk_field(nsymb, nt, 1.0)
+    px.create_field("sepfields", sx, sy)
+    x = dict(length=5e4, alphadB=0.2, aeff=80.0, n2=2.7e-20, disp=17.0, slope=0.057, dphimax=5e-3, dzmax=2e4, dgd=0.5,
+             nplates=100, manakov="no")
+    x["lambda"] = 1550.0
+    brf1 = px.fiber(x, "gp--", rng=np.random.default_rng(7))
+    x2 = dict(x, length=3e4, nplates=30, dgd=0.2)
+    brf2 = px.fiber(x2, "gp--", rng=np.random.default_rng(8))
+    assert np.all(GSTATE.DISP != 0)
+    fx, fy = to_host_field(GSTATE.FIELDX)[:, 0], to_host_field(GSTATE.FIELDY)[:, 0]
+    Uinv, U = px.inverse_pmd([brf1, brf2], dict(apply="no"), nargout=2)             # 'no': matrices only (:138)
+    np.testing.assert_array_equal(to_host_field(GSTATE.FIELDX)[:, 0], fx)
+    oUinv, oU, wx, wy = pmdinv.inverse_pmd([brf1, brf2], fx, fy)
+    np.testing.assert_allclose(U, oU, atol=1e-12)
+    np.testing.assert_allclose(Uinv, oUinv, atol=1e-12)
+    for k in (0, 1, 4097, 65535):
+        np.testing.assert_allclose(Uinv[:, :, k] @ U[:, :, k], np.eye(2), atol=1e-12)
+    assert px.inverse_pmd([brf1, brf2]) is None
+    gx, gy = to_host_field(GSTATE.FIELDX)[:, 0], to_host_field(GSTATE.FIELDY)[:, 0]
+    assert np.abs(gx - wx).max() <= 1e-11 * np.abs(wx).max() and np.abs(gy - wy).max() <= 1e-11 * np.abs(wy).max()
+    att = np.exp(-0.5 * np.log(10) * 1e-4 * 0.2 * 8e4)
+    assert np.abs(gx - sx * att).max() <= 1e-10 and np.abs(gy - sy * att).max() <= 1e-10
+    np.testing.assert_array_equal(GSTATE.DISP, np.zeros((2, 1)))                    # :145
+    # options.gvd = 'no' on a single fibre: PMD removed, scalar dispersion left in place
+    px.create_field("sepfields", sx, sy)
+    brf = px.fiber(x, "gp--", rng=np.random.default_rng(9))
+    px.inverse_pmd(brf, dict(gvd="no"))
+    want = np.fft.ifft(np.fft.fft(sx) * np.exp(-1j * brf["betat"][:, 0] * 5e4)) * np.exp(-0.5 * np.log(10) * 1e-4 * 0.2 * 5e4)
+    assert np.abs(to_host_field(GSTATE.FIELDX)[:, 0] - want).max() <= 1e-10
+    px.reset_all(64, 16, 2)
+    GSTATE.SYMBOLRATE = 10.0
+    px.lasersource(1.0, 1550.0, 0.4)
+    c = synth.pdm_qpsk_field(64, 16, 1.0)
+    px.create_field("sepfields", np.stack([c[0], c[0]], 1), np.stack([c[1], c[1]], 1))
+    with pytest.raises(ValueError, match="unique field"):
+        px.inverse_pmd(brf)
+
+
+def test_inverse_pmd_batch_per_frame_draws(lib, oracle):
+    """Monte-Carlo use: F frames, each with its own waveplate draw, through HotPath's fibre ('gp--') and one batched
+    plx_pmdinv_apply_dev: every frame returns to the transmitted field."""
+    import torch
+    from polmux_amd import pipeline
+    from polmux_amd.pmdinv import PmdInverse
+    cfg = pipeline.HotPathConfig(nsymb=256, nt=32, flag="gp--", nplates=16, dgd=0.4)
+    F = 5
+    hp = pipeline.HotPath(cfg, max_frames=F)
+    db0, th, ep = hp.set_random_pmd(range(10, 10 + F))
+    ux, uy = hp.make_batch(F)
+    hp.fibre(ux, uy)
+    assert float((ux[0] - ux[1]).abs().max()) > 1e-3                                # the draws differ
+    gam, betat, db1 = hp._keep
+    inv = PmdInverse(cfg.nfft, F)
+    inv.set_link([dict(db0=db0, theta=th, epsilon=ep, lcorr=cfg.length / cfg.nplates, betat=betat, db1=db1)], None, nsets=F)
+    inv.apply(ux, uy)
+    inv.close()
+    _sync()
+    att = math.exp(-0.5 * hp.alphalin * cfg.length)
+    for f in range(F):
+        assert float((ux[f] / att - hp.tx[0]).abs().max()) < 1e-11 and float((uy[f] / att - hp.tx[1]).abs().max()) < 1e-11
+    hp.close()
