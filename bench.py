@@ -44,9 +44,12 @@ def parse():
     ap.add_argument("--noise", type=float, default=0.05, help="receiver noise sigma per quadrature (full scale 1)")
     ap.add_argument("--frontend", default="pick", choices=["pick", "cohmix"],
                     help="pick: 2-sps sampling supplied by the harness (SURVEY 8d C1); cohmix: receiver_cohmix + ADC + decimate on the device")
+    ap.add_argument("--mc", action="store_true",
+                    help="BASELINE config[3] style step: fiber('gps-') with a fresh random-birefringence draw per frame "
+                         "and per step (Monte-Carlo PMD realisations), receiver noise as ASE stand-in")
     ap.add_argument("--no-overlap", action="store_true", help="run the receiver on the fibre stream (no stream overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=1)
+    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the batch the CPU baseline processes (~0.4 s each)")
     return ap.parse_args()
 
 
@@ -113,6 +116,8 @@ def main():
     from polmux_amd import _abi, pipeline
     _abi.get().call("plx_set_device", local)
 
+    if a.mc:
+        a.flag = "gps-"
     cfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag=a.flag, frontend=a.frontend)
     F = a.frames
     hp = pipeline.HotPath(cfg, max_frames=F)
@@ -133,7 +138,7 @@ def main():
     # receiver on its own HIP stream: Rx of batch i overlaps the fibre of batch i+1 (both inside the timed region)
     rx_stream = None if a.no_overlap else torch.cuda.Stream()
     err_total = torch.zeros(2, dtype=torch.int64, device="cuda")
-    errs = []
+    errs, resolved = [], []
     fib_ms, rx_ms, row_launches, sample_steps = [], [], 0, 0
     for i in range(a.warmup):
         ux, uy = batches[i]
@@ -144,6 +149,8 @@ def main():
         ux, uy = batches[i]
         e0, e1, e2 = ev.create(), ev.create(), ev.create()
         ev.record(e0, stream)
+        if a.mc:   # realisation index = (rank, step, frame): fresh waveplates, keyed so that sharding does not change them
+            hp.set_random_pmd(range((rank * total + i) * F, (rank * total + i + 1) * F))
         hp.fibre(ux, uy)
         ev.record(e1, stream)
         rs = rx_stream.cuda_stream if rx_stream is not None else stream
@@ -154,8 +161,12 @@ def main():
         if rx_stream is not None:
             with torch.cuda.stream(rx_stream):
                 errs.append(err.sum(0))
+                if a.mc:   # a blind receiver behind random birefringence: resolve pol swap + pi/2 ambiguity (ex20:160-173)
+                    resolved.append(hp.errors_resolved(F).sum())
         else:
             errs.append(err.sum(0))
+            if a.mc:
+                resolved.append(hp.errors_resolved(F).sum())
         fib_ms.append((e0, e1)); rx_ms.append((e1, e2))
         rl, ss = hp.ssfm_stats()
         row_launches += rl; sample_steps += ss
@@ -163,11 +174,15 @@ def main():
     dt = time.perf_counter() - t0
     for e in errs:
         err_total += e
+    res_total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    for r_ in resolved:
+        res_total += r_
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         dist.all_reduce(err_total, op=dist.ReduceOp.SUM)       # the one exchange step (RCCL over xGMI)
+        dist.all_reduce(res_total, op=dist.ReduceOp.SUM)
     fib = sum(ev.elapsed_ms(x, y) for x, y in fib_ms)
     rxm = sum(ev.elapsed_ms(x, y) for x, y in rx_ms)
 
@@ -193,7 +208,10 @@ def main():
                        "frames_per_gpu_per_step": F, "nsymb": a.nsymb, "nt": a.nt, "pavg_mw": a.pavg,
                        "ssfm_steps_per_frame": sample_steps / (a.steps * F * n), "rx_noise_sigma": a.noise,
                        "fibre_ms_per_step": fib / a.steps, "rxdsp_ms_per_step": rxm / a.steps,
-                       "bit_errors_xy": err_total.cpu().tolist()},
+                       "mc_realisations_per_s": float(world) * a.steps * F / dt, "fresh_pmd_per_realisation": bool(a.mc),
+                       "bit_errors_xy": err_total.cpu().tolist(),
+                       "bit_errors_resolved": int(res_total.item()) if a.mc else None,
+                       "bits": int(world) * a.steps * F * 4 * a.nsymb},
             "roofline": {"bound": "hbm", "kernel": "SSFM step (k_col_fwd + k_row + k_col_inv)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": SSFM_BYTES_PER_SAMPLE_STEP * F * n,

@@ -80,6 +80,10 @@ int plx_ssfm_destroy(plx_ssfm *plan);
  * used by frame f = s (nsets == 1: shared by all frames).                          */
 int plx_ssfm_set_birefringence(plx_ssfm *plan, const double *db0, const double *theta,
                                const double *epsilon, int nsets);
+/* the same, stream-ordered and without waiting: the tables take effect for propagate calls enqueued on
+ * `stream` after this call (Monte-Carlo loops draw the next batch's waveplates while the GPU is busy) */
+int plx_ssfm_set_birefringence_dev(plx_ssfm *plan, const double *db0, const double *theta,
+                                   const double *epsilon, int nsets, void *stream);
 /* Propagate nframes frames in place.  d_ux/d_uy: device, interleaved complex128,
  * layout [frame][channel][nfft]; d_uy NULL for a scalar plan.  Asynchronous on
  * `stream` except for the bounded polling of the data-dependent step loop.         */

@@ -60,6 +60,7 @@ SIGNATURES = {
     "plx_ssfm_create": [C.POINTER(_vp), C.POINTER(SsfmDesc)],
     "plx_ssfm_destroy": [_vp],
     "plx_ssfm_set_birefringence": [_vp, _vp, _vp, _vp, C.c_int],
+    "plx_ssfm_set_birefringence_dev": [_vp, _vp, _vp, _vp, C.c_int, _vp],
     "plx_ssfm_propagate_dev": [_vp, _vp, _vp, C.c_int, _vp],
     "plx_ssfm_results": [_vp, C.c_int, _vp, _vp],
     "plx_ssfm_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64)],

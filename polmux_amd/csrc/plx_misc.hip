@@ -60,7 +60,9 @@ __device__ __forceinline__ void philox4x32(uint32_t c0, uint32_t c1, uint32_t c2
 struct AmpArgs {
     cplx *ux, *uy;          // [frame][nfc][nfft]
     const cplx *noise;      // optional injected unit noise [frame][2*nfc][nfft] ([X cols | Y cols], ampliflat.m:123-129)
-    const double *sigma;    // [nfc] sqrt(mW), ampliflat.m:91-102
+    const double *sigma;    // [nfc] sqrt(mW), ampliflat.m:91-102 (device copy, only when nfc > 32)
+    double sig_v[32];       // the same by value: no allocation, no synchronisation on the usual path
+    int has_sigma;
     const int64_t *keys;    // optional per-frame RNG keys
     int64_t nfft;
     int nfc, asex, asey;
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void k_ampliflat(AmpArgs a)
 {
     const int f = blockIdx.z, c = blockIdx.y;
     const size_t base = ((size_t)f * a.nfc + c) * (size_t)a.nfft;
-    const double sg = a.sqrt_gain, sig = a.sigma ? a.sigma[c] : 0.0;
+    const double sg = a.sqrt_gain, sig = !a.has_sigma ? 0.0 : (a.sigma ? a.sigma[c] : a.sig_v[c]);
     const uint64_t key = a.keys ? (uint64_t)a.keys[f] : (uint64_t)f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.nfft; i += (int64_t)gridDim.x * blockDim.x) {
         for (int pol = 0; pol < 2; pol++) {
@@ -167,7 +169,9 @@ extern "C" int plx_ampliflat_dev(double *d_ux, double *d_uy, int64_t nfft, int32
     AmpArgs a;
     a.ux = (cplx *)d_ux; a.uy = (cplx *)d_uy; a.noise = (const cplx *)d_noise; a.keys = d_keys; a.nfft = nfft;
     a.nfc = nfc; a.asex = asex; a.asey = asey; a.sqrt_gain = sqrt(gain_lin); a.seed = seed; a.sigma = nullptr;
-    if (sigma) {
+    a.has_sigma = sigma ? 1 : 0;
+    for (int c = 0; c < 32; c++) a.sig_v[c] = (sigma && c < nfc) ? sigma[c] : 0.0;
+    if (sigma && nfc > 32) {
         PLX_HIP(hipMalloc((void **)&d_sigma, sizeof(double) * nfc));
         if (hipMemcpyAsync(d_sigma, sigma, sizeof(double) * nfc, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
             hipFree(d_sigma);

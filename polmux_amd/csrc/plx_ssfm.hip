@@ -1253,6 +1253,9 @@ struct plx_ssfm {
     double *d_pub = nullptr;
     int fused = 0, fused_grid = 0, tiles_pf = 0;
     int row16 = 0;                // register-blocked row pass usable (N2 == 256, dual, no PMD)
+    double *h_brf[2] = {nullptr, nullptr}; // pinned staging of the waveplate tables
+    hipEvent_t brf_ev[2] = {nullptr, nullptr};
+    int brf_slot = 0;
     int pf_col = 0, pf_row = 0;   // > 0: persistent prefetching kernels usable (tile == PF x threads)
     int grid_col = 0, grid_row = 0;
     int64_t row_launches = 0, sample_steps = 0;
@@ -1274,6 +1277,10 @@ static void free_plan(plx_ssfm *P)
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
     hipFree(P->d_ndone); hipFree(P->d_sync); hipFree(P->d_pub);
     if (P->h_ndone) hipHostFree(P->h_ndone);
+    for (int k = 0; k < 2; k++) {
+        if (P->h_brf[k]) hipHostFree(P->h_brf[k]);
+        if (P->brf_ev[k]) hipEventDestroy(P->brf_ev[k]);
+    }
     delete P;
 }
 
@@ -1474,32 +1481,58 @@ extern "C" int plx_ssfm_destroy(plx_ssfm *P)
     return PLX_OK;
 }
 
-extern "C" int plx_ssfm_set_birefringence(plx_ssfm *P, const double *db0, const double *theta,
-                                          const double *epsilon, int nsets)
+// Waveplate tables.  Device storage is sized once for max_frames sets; uploads go through two pinned staging
+// slots and are stream-ordered (the copy lands after whatever propagate call is still reading the old table on
+// that stream and before the next one), so a Monte-Carlo loop can draw fresh birefringence for batch i+1 while
+// batch i is still in flight elsewhere on the GPU -- no device-wide synchronisation.
+static int set_brf(plx_ssfm *P, const double *db0, const double *theta, const double *epsilon, int nsets, hipStream_t st,
+                   bool wait)
 {
     if (!P || !db0 || !theta || !epsilon) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_set_birefringence: null argument");
-    if (nsets != 1 && nsets > P->d.max_frames) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_set_birefringence: more sets than frames");
+    if (nsets < 1 || (nsets != 1 && nsets > P->d.max_frames)) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_set_birefringence: more sets than frames");
     const int np = P->d.nplates;
-    std::vector<double> t((size_t)nsets * np * 9);
+    const size_t cap = (size_t)P->d.max_frames * np * 9, cnt = (size_t)nsets * np * 9;
+    if (!P->d_brf) PLX_HIP(hipMalloc((void **)&P->d_brf, cap * sizeof(double)));
+    const int slot = P->brf_slot;
+    P->brf_slot ^= 1;
+    if (!P->h_brf[slot]) {
+        PLX_HIP(hipHostMalloc((void **)&P->h_brf[slot], cap * sizeof(double), hipHostMallocDefault));
+        PLX_HIP(hipEventCreateWithFlags(&P->brf_ev[slot], hipEventDisableTiming));
+    } else {
+        PLX_HIP(hipEventSynchronize(P->brf_ev[slot]));   // the upload that last used this slot has executed
+    }
+    double *t = P->h_brf[slot];
     for (int sidx = 0; sidx < nsets; sidx++)
         for (int n = 0; n < np; n++) {
             const size_t i = (size_t)sidx * np + n;
             // matR = matRth*matRepsilon, fiber.m:910-912
-            const double ct = cos(theta[i]), st = sin(theta[i]), ce = cos(epsilon[i]), se = sin(epsilon[i]);
+            const double ct = cos(theta[i]), sn = sin(theta[i]), ce = cos(epsilon[i]), se = sin(epsilon[i]);
             double *m = &t[i * 9];
-            m[0] = ct * ce;  m[1] = -st * se; // R11
-            m[2] = -st * ce; m[3] = ct * se;  // R12
-            m[4] = st * ce;  m[5] = ct * se;  // R21
-            m[6] = ct * ce;  m[7] = st * se;  // R22
+            m[0] = ct * ce;  m[1] = -sn * se; // R11
+            m[2] = -sn * ce; m[3] = ct * se;  // R12
+            m[4] = sn * ce;  m[5] = ct * se;  // R21
+            m[6] = ct * ce;  m[7] = sn * se;  // R22
             m[8] = db0[i] * kInv2Pi; // turns, like betat_p / db1_p
         }
-    if (P->d_brf) { hipFree(P->d_brf); P->d_brf = nullptr; }
-    PLX_HIP(hipMalloc((void **)&P->d_brf, t.size() * sizeof(double)));
-    PLX_HIP(hipMemcpy(P->d_brf, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+    PLX_HIP(hipMemcpyAsync(P->d_brf, t, cnt * sizeof(double), hipMemcpyHostToDevice, st));
+    PLX_HIP(hipEventRecord(P->brf_ev[slot], st));
+    if (wait) PLX_HIP(hipStreamSynchronize(st));
     P->a.brf = P->d_brf;
     P->a.brf_per_frame = nsets > 1 ? 1 : 0;
     P->brf_sets = nsets;
     return PLX_OK;
+}
+
+extern "C" int plx_ssfm_set_birefringence(plx_ssfm *P, const double *db0, const double *theta,
+                                          const double *epsilon, int nsets)
+{
+    return set_brf(P, db0, theta, epsilon, nsets, nullptr, true);
+}
+
+extern "C" int plx_ssfm_set_birefringence_dev(plx_ssfm *P, const double *db0, const double *theta,
+                                              const double *epsilon, int nsets, void *stream)
+{
+    return set_brf(P, db0, theta, epsilon, nsets, (hipStream_t)stream, false);
 }
 
 extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, int nframes, void *stream)

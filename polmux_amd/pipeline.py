@@ -19,6 +19,16 @@ from .gstate import GSTATE
 from .rx import cde_transfer, dsp_params_struct
 
 
+def _u01(keys):
+    """splitmix64 finaliser of uint64 keys -> doubles in [0, 1) (53 bits)."""
+    with np.errstate(over="ignore"):
+        z = keys + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
 class HotPathConfig:
     """Run_my_PDM_QPSK-style parameters (BASELINE config C1 by default)."""
 
@@ -144,15 +154,22 @@ class HotPath:
         return ux, uy
 
     def set_random_pmd(self, seeds):
-        """brf draws of fiber.m:274-276, one independent set per frame, keyed by realisation seed."""
+        """brf draws of fiber.m:274-276, one independent set per frame, keyed by the realisation index alone (a
+        counter-based generator: splitmix64 of (master seed, realisation, plate, stream) -> U[0,1)), so any batching
+        or sharding of the indices gives the same waveplates.  Uploaded stream-ordered, without a device sync."""
         np_ = self.nplates
-        db0 = np.empty((len(seeds), np_)); th = np.empty_like(db0); ep = np.empty_like(db0)
-        for k, sd in enumerate(seeds):
-            r = np.random.default_rng([20260101, int(sd), 1])
-            db0[k] = r.random(np_) * 2 * math.pi - math.pi
-            th[k] = r.random(np_) * math.pi - 0.5 * math.pi
-            ep[k] = 0.5 * np.arcsin(r.random(np_) * 2 - 1)
-        self.lib.call("plx_ssfm_set_birefringence", self.ssfm, db0.ctypes.data, th.ctypes.data, ep.ctypes.data, len(seeds))
+        r = np.asarray(list(seeds), dtype=np.uint64).reshape(-1, 1, 1)
+        plate = np.arange(np_, dtype=np.uint64).reshape(1, -1, 1)
+        stream = np.arange(3, dtype=np.uint64).reshape(1, 1, 3)
+        with np.errstate(over="ignore"):       # uint64 arithmetic wraps by design
+            keys = (np.uint64(20260101) * np.uint64(0x9E3779B97F4A7C15) + r) * np.uint64(0xD1342543DE82EF95) \
+                + plate * np.uint64(3) + stream
+        u = _u01(keys)
+        db0 = np.ascontiguousarray(u[:, :, 0] * 2 * math.pi - math.pi)
+        th = np.ascontiguousarray(u[:, :, 1] * math.pi - 0.5 * math.pi)
+        ep = np.ascontiguousarray(0.5 * np.arcsin(u[:, :, 2] * 2 - 1))
+        self.lib.call("plx_ssfm_set_birefringence_dev", self.ssfm, db0.ctypes.data, th.ctypes.data, ep.ctypes.data, db0.shape[0],
+                      self.stream())
         return db0, th, ep
 
     # ------------------------------------------------------------------- stages ---
@@ -176,8 +193,11 @@ class HotPath:
                 self._rows += rows.value
                 self._steps += steps.value
 
-    def receive(self, ux, uy, noise_sigma=0.0, noise_seed=None, side_stream=None):
+    def receive(self, ux, uy, noise_sigma=0.0, noise_seed=None, side_stream=None, noise_keys=None):
         """Front end (2-sps pick, or receiver_cohmix + ADC + decimate), CDE, DSP, decisions.  Returns err [F,2] (device).
+        Receiver noise (sigma per quadrature on the 2-sps samples, an ASE stand-in) comes from the device Philox
+        generator of plx_ampliflat_dev keyed by (noise_seed, noise_keys[frame] or frame): with noise_keys = the
+        realisation indices the noise of a realisation does not depend on batching or sharding.
         With side_stream the whole receiver is enqueued on that stream behind the fibre of this batch, so
         the latency-bound CMA recurrence overlaps the HBM-bound fibre sweeps of the NEXT batch."""
         if side_stream is not None:
@@ -186,7 +206,7 @@ class HotPath:
             ready.record(torch.cuda.current_stream())
             side_stream.wait_event(ready)
             with torch.cuda.stream(side_stream):
-                return self.receive(ux, uy, noise_sigma, noise_seed)
+                return self.receive(ux, uy, noise_sigma, noise_seed, None, noise_keys)
         F = ux.shape[0]
         cfg = self.cfg
         half = cfg.nt // 2
@@ -199,10 +219,13 @@ class HotPath:
                 self.lib.call("plx_pick_dev", src.data_ptr(), rx.data_ptr() + pol * self.Lrx * 16, cfg.nfft, self.Lrx, 0,
                               half, self.rx_scale, F, 2 * self.Lrx, st)
         if noise_sigma:
-            g = self.torch.Generator(device=self.dev)
-            g.manual_seed(int(noise_seed or 0))
-            nz = self.torch.randn((F, 2, self.Lrx, 2), generator=g, device=self.dev, dtype=self.torch.float64)
-            rx += noise_sigma * self.torch.view_as_complex(nz)
+            sig = np.array([float(noise_sigma)])
+            kt = None
+            if noise_keys is not None:
+                kt = self.torch.as_tensor(np.asarray(list(noise_keys), dtype=np.int64), device=self.dev)
+            # one frame of rx = [X | Y] contiguous: a single-field, single-"polarisation" ampliflat with unit gain
+            self.lib.call("plx_ampliflat_dev", rx.data_ptr(), None, 2 * self.Lrx, 1, F, 1.0, sig.ctypes.data, None,
+                          int(noise_seed or 0) & (2 ** 64 - 1), kt.data_ptr() if kt is not None else None, 1, 0, st)
         self.lib.call("plx_cde_apply_dev", self.cde, rx.data_ptr(), self.eq.data_ptr(), self.Lrx, 2 * F, st)
         self.lib.call("plx_dsp_run_dev", self.dsp, self.eq.data_ptr(), self.sym.data_ptr(), F, st)
         self.lib.call("plx_decide_count_dev", self.sym.data_ptr(), cfg.nsymb, 2, F, self.pat.data_ptr(), None,
@@ -279,20 +302,7 @@ class McCampaign:
                 hp.set_random_pmd(idx)
             ux, uy = hp.make_batch(n)
             hp.fibre(ux, uy)
-            # receive() without its own noise; ASE keyed by realisation index is added here
-            cfg, st = hp.cfg, hp.stream()
-            rx = hp.rx[:n]
-            for pol, src in enumerate((ux, uy)):
-                hp.lib.call("plx_pick_dev", src.data_ptr(), rx.data_ptr() + pol * hp.Lrx * 16, cfg.nfft, hp.Lrx, 0,
-                            cfg.nt // 2, hp.rx_scale, n, 2 * hp.Lrx, st)
-            if self.sigma:
-                for k, r in enumerate(idx):
-                    g = torch.Generator(device=hp.dev)
-                    g.manual_seed(20260101 * 1000003 + int(r))
-                    nz = torch.randn((2, hp.Lrx, 2), generator=g, device=hp.dev, dtype=torch.float64)
-                    rx[k] += self.sigma * torch.view_as_complex(nz)
-            hp.lib.call("plx_cde_apply_dev", hp.cde, rx.data_ptr(), hp.eq.data_ptr(), hp.Lrx, 2 * n, st)
-            hp.lib.call("plx_dsp_run_dev", hp.dsp, hp.eq.data_ptr(), hp.sym.data_ptr(), n, st)
+            hp.receive(ux, uy, self.sigma, 20260101, None, idx)   # noise keyed by realisation index
             out.append(hp.errors_resolved(n).cpu().numpy())
         return np.concatenate(out) if out else np.zeros(0, np.int64)
 
