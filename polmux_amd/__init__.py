@@ -10,10 +10,10 @@ from .gstate import CONSTANTS, GSTATE, create_field, lasersource, reset_all  # n
 from .fiber import fiber  # noqa: F401
 from .ampliflat import ampliflat  # noqa: F401
 from .rx import (CDE_OFDE, DspPdmCohQpsk, cmaadaptivefilter, easiadaptivefilter, fastexp, samp2pat)  # noqa: F401
-from .rxfront import RxPdmCohQpsk, evaldelay, myfilter, receiver_cohmix  # noqa: F401
+from .rxfront import RxPdmCohQpsk, dsp4cohdec, evaldelay, myfilter, receiver_cohmix  # noqa: F401
 from .pmdinv import inverse_pmd  # noqa: F401
 from .mc import ber_estimate, mc_estimate  # noqa: F401
 
-__all__ = ["PolmuxError", "GSTATE", "CONSTANTS", "reset_all", "create_field", "lasersource", "fiber", "ampliflat", "CDE_OFDE", "receiver_cohmix", "RxPdmCohQpsk", "myfilter", "evaldelay",
+__all__ = ["PolmuxError", "GSTATE", "CONSTANTS", "reset_all", "create_field", "lasersource", "fiber", "ampliflat", "CDE_OFDE", "receiver_cohmix", "RxPdmCohQpsk", "dsp4cohdec", "myfilter", "evaldelay",
            "DspPdmCohQpsk", "cmaadaptivefilter", "easiadaptivefilter", "fastexp", "samp2pat", "ber_estimate",
            "mc_estimate", "inverse_pmd"]

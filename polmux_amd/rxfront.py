@@ -304,3 +304,22 @@ def RxPdmCohQpsk(chNum, symbolPattern, RxParams, rng=None):
     finally:
         fr.close()
     return out[0].transpose(0, 1).contiguous(), float("nan")
+
+
+def dsp4cohdec(ich, pat, x, p, rng=None):
+    """[Phases, Amplitudes, worsteyeop] = dsp4cohdec(ich, pat, x, p)  dsp4cohdec.m:100-282 -- Optilux's own coherent
+    receiver + DSP (ex19/ex20): receiver_cohmix with the receiver struct x, ADC / timing / decimation with the DSP
+    struct p (:121-160), then the DSP body that DspPdmCohQpsk shares with it (:212-282).  Phases/Amplitudes are torch
+    float64 [Nsymb, 1 or 2] on the GPU; worsteyeop is NaN (eye diagnostics are not evaluated on the device path)."""
+    import torch
+    from .rx import DspPdmCohQpsk
+    if p.get("applydcf"):
+        raise NotImplementedError("p.applydcf (DispCompFilter, dsp4cohdec.m:163-173) is not part of the accelerated path; "
+                                  "use CDE_OFDE between the front end and the DSP")
+    rxp = dict(x)
+    for k in ("sps", "workatbaudrate", "applyadc", "adcbits"):
+        if k in p:
+            rxp[k] = p[k]
+    samples, eye = RxPdmCohQpsk(ich, pat, rxp, rng)                    # dsp4cohdec.m:108-160 = RxPdmCohQpsk.m:18-72
+    sig = DspPdmCohQpsk(samples.transpose(0, 1), p, ich)               # [ncol, Nsymb]
+    return torch.angle(sig).transpose(0, 1).contiguous(), torch.abs(sig).transpose(0, 1).contiguous(), eye

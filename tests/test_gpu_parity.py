@@ -965,3 +965,44 @@ def test_inverse_pmd_batch_per_frame_draws(lib, oracle):
     for f in range(F):
         assert float((ux[f] / att - hp.tx[0]).abs().max()) < 1e-11 and float((uy[f] / att - hp.tx[1]).abs().max()) < 1e-11
     hp.close()
+
+
+def test_dsp4cohdec_ex19_single_pol_vs_oracle(lib, oracle):
+    """BASELINE config[0] (ex19_coherent_singlepol.m:112-139): single-polarisation QPSK, noiseless + noisy flat amplifier,
+    dsp4cohdec(1, pat, x, dspParameters), samp2pat -- against the oracle chain (front.py + dsp_pdm_coh_qpsk) fed with the
+    same noisy field: phases within 1e-7, decided pattern identical."""
+    import polmux_amd as px
+    from oracle import front
+    from polmux_amd import rxfront, synth
+    from polmux_amd.gstate import GSTATE, to_host_field
+    nsymb, nt = 256, 64
+    px.reset_all(nsymb, nt, 1)
+    GSTATE.SYMBOLRATE = 10.0
+    E = px.lasersource(1.0, 1550.0, 0.4)
+    pat, patmat = synth.pattern_debruijn(nsymb, 1, 4)
+    eopt = synth.qi_modulator(E[:, 0], synth.electricsource_qpsk(patmat[:, 0], nt, 1.0, 0.2),
+                              synth.electricsource_qpsk(patmat[:, 1], nt, 1.0, 0.2))
+    px.create_field("unique", eopt.reshape(-1, 1), None, dict(power="average"))
+    r = np.random.default_rng(19)
+    noise = r.standard_normal((nsymb * nt, 2)) + 1j * r.standard_normal((nsymb * nt, 2))   # [X | Y], ampliflat.m:123-129
+    px.ampliflat(-1.0, "gain")                                         # ex19:133-134
+    px.ampliflat(1.0, "gain", dict(f=18.0, noise=noise))
+    assert GSTATE.FIELDY is not None                                   # noise-only Y created by the amplifier, ampliflat.m:139-142
+    field = to_host_field(GSTATE.FIELDX)[:, 0]
+    x = dict(rec="coherent", ts=0, oftype="gauss", obw=1.9, eftype="bessel5", ebw=0.65, delay="theory", lopower=0)
+    p = dict(sps=nt, workatbaudrate=False, applyadc=False, adcbits=5, samplingrate=20.0, applydcf=False, applynlr=False,
+             applypol=False, modorder=2, freqavg=500, phasavg=3, poworder=2)
+    phase, amp, eye = px.dsp4cohdec(1, pat, x, p)
+    assert phase.shape == (nsymb, 1) and amp.shape == (nsymb, 1)
+    hopt, elo, hel, post_delay, _ = rxfront._front_tables(1, x)
+    cur = front.receiver_cohmix(field, None, hopt, elo, hel, True)
+    shift = rxfront._mround(-rxfront.theory_delay(1, x, False, post_delay) * nt)
+    rx = front.rx_front(cur, False, 0, [shift], nt // 2, rxfront.fir1_lowpass(16, 2.0 / nt))
+    op = oracle.dsp_params(power_mw=float(GSTATE.POWER[0]), applypol=False, freqavg=500, phasavg=3, poworder=2)
+    ref = oracle.dsp_pdm_coh_qpsk(rx, op)
+    got = amp.cpu().numpy() * np.exp(1j * phase.cpu().numpy())
+    np.testing.assert_allclose(got, ref, atol=1e-7)
+    pat_hat = px.samp2pat(x, None, phase.cpu().numpy())
+    np.testing.assert_array_equal(pat_hat, oracle.samp2pat_coherent(np.angle(ref)))
+    with pytest.raises(NotImplementedError, match="applydcf"):
+        px.dsp4cohdec(1, pat, x, dict(p, applydcf=True))
