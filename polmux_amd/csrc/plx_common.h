@@ -81,9 +81,13 @@ __device__ __forceinline__ cplx cexp_neg_turns(double x)
 #ifdef PLX_EMU
 __device__ __forceinline__ void pin(cplx &) {}
 __device__ __forceinline__ void pin(double &) {}
+__device__ __forceinline__ void pin(int &) {}
 #else
 __device__ __forceinline__ void pin(cplx &v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
 __device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
+// an index made opaque at this point: loads addressed through it cannot be hoisted above (keeps the live ranges of
+// a later phase's operands out of an earlier, register-hungry phase)
+__device__ __forceinline__ void pin(int &v) { asm volatile("" : "+v"(v)); }
 #endif
 
 // ---- DPP lane exchange inside a 16-lane row (no LDS crossbar on the critical path) ----

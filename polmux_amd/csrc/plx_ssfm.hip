@@ -533,10 +533,14 @@ __global__ __launch_bounds__(256) void k_row(SsfmArgs a)
 // j + 16k of transform t (t = pol*R + r), loads them straight from HBM (16 lanes = 256 contiguous bytes),
 // runs lvl2_dif256, exchanges ONCE through LDS (padded: lane stride 17 slots), finishes with r16_dif,
 // applies exp(-i beta dz) at the 16 bit-reversed bins it holds, and goes back the same way: 4 LDS
-// passes and 2 barriers instead of 16 passes and ~10 barriers of the general kernel.  Dual-polarisation
-// plans without PMD (the waveplate loop needs both polarisations of a bin in one thread: k_row).
-// Opt-in (PLX_SSFM_ROW16=1): on MI355X it times the same as k_row -- the row pass is not LDS-bound.
-__global__ __launch_bounds__(256) void k_row16(SsfmArgs a)
+// passes instead of 16.  One workgroup = ONE wave (2 rows x 2 polarisations x 16 lanes), so its barriers are
+// free; the two polarisations take turns in the exchange buffer (10.7 KiB of LDS).  Opt-in (PLX_SSFM_ROW16=1):
+// the 16 complex128 points + twiddles + butterfly temporaries need ~200 VGPRs per lane, i.e. 2 waves per SIMD;
+// at that occupancy it only matches k_row (41.7 vs 40.4 ms per 256-frame pass), and capping the registers for 3
+// or 4 waves per SIMD spills (57 ms) -- profiles/r01_notes.md.  Dual-polarisation plans without PMD (the
+// waveplate loop needs both polarisations of a bin in one thread: k_row).
+#define ROW16_R 2
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_row16(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
     if (*a.ndone >= a.nframes) return;
@@ -544,48 +548,69 @@ __global__ __launch_bounds__(256) void k_row16(SsfmArgs a)
     const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
     const FrameCtl *ctl = a.ctl + f;
     if (ctl->done) return;
-    const int R = a.R, pol = t >= R ? 1 : 0, r = t - pol * R;
-    cplx *s = (cplx *)lds;                 // [2R][272]
-    cplx *tw = s + (size_t)2 * R * 272;    // W_256^k, k < 128
-    lds_load_twiddles(tw, a.tw2, 128, tid, blockDim.x);
+    const int pol = t >> 1, r = t & 1;
+    cplx *s = (cplx *)lds;                       // [ROW16_R][272], used by polarisation 0 then 1
+    cplx *tw = s + (size_t)ROW16_R * 272;        // W_256^k, k < 128
+    lds_load_twiddles(tw, a.tw2, 128, tid, 64);
     const size_t N = (size_t)1 << (a.p1 + a.p2);
-    const size_t rowoff = ((size_t)blockIdx.x * R + r) << 8;   // row start inside the frame
+    const size_t rowoff = ((size_t)blockIdx.x * ROW16_R + r) << 8;   // row start inside the frame
     cplx *const u = (pol ? a.uy : a.ux) + (size_t)fc * N + rowoff;
     const cplx *const tp = a.tpass + rowoff;
     cplx x[16];
-    {
-        cplx tv[16];
 #pragma unroll
-        for (int k = 0; k < 16; k++) { x[k] = u[j + 16 * k]; tv[k] = tp[j + 16 * k]; }
+    for (int h = 0; h < 2; h++) {                // two batches of 8 + 8 loads keep the register file at 128
+        cplx xv[8], tv[8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) { pin(x[k]); pin(tv[k]); }
+        for (int k = 0; k < 8; k++) { xv[k] = u[j + 16 * (8 * h + k)]; tv[k] = tp[j + 16 * (8 * h + k)]; }
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = cmul(x[k], tv[k]);
+        for (int k = 0; k < 8; k++) { pin(xv[k]); pin(tv[k]); }
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[8 * h + k] = cmul(xv[k], tv[k]);
     }
-    __syncthreads();                        // twiddles staged
+    __syncthreads();                             // twiddles staged
     lvl2_dif256(x, j, tw);
-    cplx *const st = s + t * 272;
+    cplx *const st = s + r * 272;
 #pragma unroll
-    for (int k = 0; k < 16; k++) st[j + 17 * k] = x[k];          // row_phys(j + 16k)
-    __syncthreads();
+    for (int p = 0; p < 2; p++) {                // exchange: write points j+16k, read block j
+        if (pol == p) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = st[17 * j + k];          // block j: points 16j .. 16j+15
+            for (int k = 0; k < 16; k++) st[j + 17 * k] = x[k];      // row_phys(j + 16k)
+        }
+        __syncthreads();
+        if (pol == p) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = st[17 * j + k];      // block j: points 16j .. 16j+15
+        }
+        __syncthreads();
+    }
     r16_dif(x);
     {
         const double cur = a.force ? a.f_cur : ctl->cur;
-        const double *bt = a.betat_p + (size_t)c * N + rowoff + 16 * j;
+        int o16 = 16 * j;
+        pin(o16);
+        const double *bt = a.betat_p + (size_t)c * N + rowoff + o16;
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = cmul(cexp_neg_turns(bt[k] * cur), x[k]);   // :927-928 with matR = I
     }
     r16_dit(x);
 #pragma unroll
-    for (int k = 0; k < 16; k++) st[17 * j + k] = x[k];
-    __syncthreads();
+    for (int p = 0; p < 2; p++) {
+        if (pol == p) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = st[j + 17 * k];
+            for (int k = 0; k < 16; k++) st[17 * j + k] = x[k];
+        }
+        __syncthreads();
+        if (pol == p) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = st[j + 17 * k];
+        }
+        __syncthreads();
+    }
     lvl2_dit256(x, j, tw);
+    int jo = j;
+    pin(jo);
 #pragma unroll
-    for (int k = 0; k < 16; k++) u[j + 16 * k] = cmulc(x[k], tp[j + 16 * k]);
+    for (int k = 0; k < 16; k++) u[jo + 16 * k] = cmulc(x[k], tp[jo + 16 * k]);
 }
 
 // ------------------------------------------------------ pass 3: inverse columns ---
@@ -1429,7 +1454,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         if (const char *e = getenv("PLX_SSFM_GRID_COL")) P->grid_col = atoi(e);
         if (const char *e = getenv("PLX_SSFM_GRID_ROW")) P->grid_row = atoi(e);
     }
-    P->row16 = (a.dual && !a.pmd && a.p2 == 8 && a.R <= 8 && getenv("PLX_SSFM_ROW16")) ? 1 : 0;   // opt-in: measured equal to k_row (profiles/r01_notes.md)
+    P->row16 = (a.dual && !a.pmd && a.p2 == 8 && N1 % ROW16_R == 0 && getenv("PLX_SSFM_ROW16")) ? 1 : 0;   // opt-in (profiles/r01_notes.md)
     // fused column sweep (opt-in, PLX_SSFM_FUSE=1): needs the tile to be PF x 256 and all tiles of a frame
     // co-resident.  Measured on MI355X it moves 1/3 less HBM traffic but is latency-bound at 2 workgroups
     // per CU and ends up level with the plain three-sweep step (profiles/r01_notes.md), so the default
@@ -1592,7 +1617,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
 #endif
-                if (P->row16) PLX_LAUNCH(k_row16, grow, dim3((unsigned)(32 * a.R)), P->lds_row, st, a);
+                if (P->row16) PLX_LAUNCH(k_row16, dim3((unsigned)(N1 / ROW16_R), FC), dim3(64), (size_t)(ROW16_R * 272 + 128) * sizeof(cplx), st, a);
                 else PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
                 P->row_launches++;
                 continue;
@@ -1610,7 +1635,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
             else PLX_LAUNCH(k_col_fwd, gcol, bcol, P->lds_col, st, a);
             if (P->pf_row == 4) PLX_LAUNCH(k_row_p<4>, pgr, dim3(ROW_THREADS), P->lds_row, st, a, trx, trt);
             else if (P->pf_row == 8) PLX_LAUNCH(k_row_p<8>, pgr, dim3(ROW_THREADS), P->lds_row, st, a, trx, trt);
-            else if (P->row16) PLX_LAUNCH(k_row16, grow, dim3((unsigned)(32 * a.R)), P->lds_row, st, a);
+            else if (P->row16) PLX_LAUNCH(k_row16, dim3((unsigned)(N1 / ROW16_R), FC), dim3(64), (size_t)(ROW16_R * 272 + 128) * sizeof(cplx), st, a);
             else PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
             if (P->pf_col == 8) PLX_LAUNCH(k_col_inv_p<8>, pgc, blk, P->lds_col, st, a, tcx, tct);
             else if (P->pf_col == 4) PLX_LAUNCH(k_col_inv_p<4>, pgc, blk, P->lds_col, st, a, tcx, tct);
