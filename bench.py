@@ -110,9 +110,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal of the N > 1 path on a one-GPU box (dev only): every rank on cuda:0, collectives over gloo
+    rehearsal = os.environ.get("PLX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from polmux_amd import _abi, pipeline
     _abi.get().call("plx_set_device", local)
 
@@ -178,9 +185,11 @@ def main():
     for r_ in resolved:
         res_total += r_
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        cdev = "cpu" if rehearsal else "cuda"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        err_total, res_total = err_total.to(cdev), res_total.to(cdev)
         dist.all_reduce(err_total, op=dist.ReduceOp.SUM)       # the one exchange step (RCCL over xGMI)
         dist.all_reduce(res_total, op=dist.ReduceOp.SUM)
     fib = sum(ev.elapsed_ms(x, y) for x, y in fib_ms)
