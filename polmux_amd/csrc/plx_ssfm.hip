@@ -325,7 +325,7 @@ __global__ __launch_bounds__(256) void k_rowsum(SsfmArgs a)
 // batches of COL_CH per thread before any arithmetic, to keep >= 64 KiB in flight
 // per CU.
 #define COL_CH 4
-#define COL_THREADS_MAX 512
+#define COL_THREADS_MAX 1024
 __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_fwd(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_fwd(SsfmArgs a)
 // transform, all on one LDS-resident row set (padded layout, see plx_fft.h).
 #define ROW_THREADS 128
 #define ROW_CH 4
-__global__ __launch_bounds__(256) void k_row(SsfmArgs a)
+__global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
     if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
@@ -1278,6 +1278,9 @@ struct plx_ssfm {
     double *d_pub = nullptr;
     int fused = 0, fused_grid = 0, tiles_pf = 0;
     int row16 = 0;                // register-blocked row pass usable (N2 == 256, dual, no PMD)
+    int row_threads = ROW_THREADS; // workgroup size of k_row, chosen at plan creation
+    int row_split = 0, rs_threads = 0; // long rows without PMD: one polarisation per workgroup (scalar row pass twice)
+    size_t rs_lds = 0;
     double *h_brf[2] = {nullptr, nullptr}; // pinned staging of the waveplate tables
     hipEvent_t brf_ev[2] = {nullptr, nullptr};
     int brf_slot = 0;
@@ -1380,6 +1383,21 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         while (R * npol * (N2 / 16) < ROW_THREADS / 2 && R * 2 <= N1) R *= 2;   // measured: 2 rows x 2 pols at N2 = 256
         if (const char *e = getenv("PLX_SSFM_ROWS")) { int v = atoi(e); if (v >= 1 && v <= N1 && (v & (v - 1)) == 0) R = v; }
         a.R = R; a.logR = ilog2(R);
+        // row pass: ~8 points per thread (128 threads for 2 rows x 2 polarisations x 256 points); long rows leave room
+        // for only one or two workgroups per CU, so those get proportionally more waves (up to 1024 threads)
+        int rowthr = ROW_THREADS;
+        const int64_t pts = (int64_t)npol * R * N2;
+        while (rowthr < 1024 && (int64_t)rowthr * 8 < pts) rowthr *= 2;
+        if (const char *e = getenv("PLX_SSFM_ROW_THREADS")) { int v = atoi(e); if (v >= 64 && v <= 1024 && (v & (v - 1)) == 0) rowthr = v; }
+        P->row_threads = rowthr;
+    }
+    // Long rows leave room for a single dual-polarisation workgroup per CU.  Without PMD the two polarisations only
+    // share the multiplier, so each gets its own workgroup (the scalar form of the row pass, R = 1): half the LDS,
+    // 2-3 workgroups per CU.
+    if (a.dual && N2 >= 2048 && !getenv("PLX_SSFM_NO_ROW_SPLIT")) {   // measured: 2^20 frames 74 -> 66 ms; at N2 = 1024 it loses (47 -> 52)
+        P->row_split = 1;
+        P->rs_threads = N2 / 8 < ROW_THREADS ? ROW_THREADS : (N2 / 8 > 1024 ? 1024 : N2 / 8);
+        P->rs_lds = ((size_t)(N2 + N2 / 16) + N2 / 2) * sizeof(cplx);
     }
     a.spm = desc->fls[2]; a.xpm = desc->fls[3]; a.manakov = desc->manakov ? 1 : 0; a.pmd = desc->fls[1] ? 1 : 0;
     a.nplates = desc->nplates;
@@ -1589,10 +1607,10 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     const dim3 gcol((unsigned)(N2 / a.W), FC), grow((unsigned)(N1 / a.R), FC), blk(256);
     const dim3 gctl((unsigned)((nframes + 63) / 64)), bctl(64);
     int colthr = 512; // measured: 512-thread column workgroups (2 per CU, 16 waves) beat 256 by 3-12 %
-    if (const char *e = getenv("PLX_SSFM_COL_THREADS")) { int v = atoi(e); if (v == 128 || v == 256 || v == 512) colthr = v; }
+    if (P->lds_col > 80 * 1024) colthr = 1024;   // tall tiles of large frames: one workgroup per CU, give it 16 waves
+    if (const char *e = getenv("PLX_SSFM_COL_THREADS")) { int v = atoi(e); if (v == 128 || v == 256 || v == 512 || v == 1024) colthr = v; }
     const dim3 bcol((unsigned)colthr);
-    int rowthr = ROW_THREADS;
-    if (const char *e = getenv("PLX_SSFM_ROW_THREADS")) { int v = atoi(e); if (v == 64 || v == 128 || v == 256) rowthr = v; }
+    const int rowthr = P->row_threads;
     P->row_launches = 0;
     // Data-dependent trip count (fiber.m:518): steps are enqueued in chunks; the
     // completed-frame counter of chunk k is read back while chunk k+1 executes.
@@ -1636,6 +1654,14 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
             if (P->pf_row == 4) PLX_LAUNCH(k_row_p<4>, pgr, dim3(ROW_THREADS), P->lds_row, st, a, trx, trt);
             else if (P->pf_row == 8) PLX_LAUNCH(k_row_p<8>, pgr, dim3(ROW_THREADS), P->lds_row, st, a, trx, trt);
             else if (P->row16) PLX_LAUNCH(k_row16, dim3((unsigned)(N1 / ROW16_R), FC), dim3(64), (size_t)(ROW16_R * 272 + 128) * sizeof(cplx), st, a);
+            else if (P->row_split && !a.pmd) {
+                SsfmArgs b = a;
+                b.dual = 0; b.R = 1; b.logR = 0;
+                const dim3 gs((unsigned)N1, FC), bs((unsigned)P->rs_threads);
+                PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
+                b.ux = a.uy;
+                PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
+            }
             else PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
             if (P->pf_col == 8) PLX_LAUNCH(k_col_inv_p<8>, pgc, blk, P->lds_col, st, a, tcx, tct);
             else if (P->pf_col == 4) PLX_LAUNCH(k_col_inv_p<4>, pgc, blk, P->lds_col, st, a, tcx, tct);
@@ -1709,7 +1735,7 @@ int plx_ssfm_filter_dev(plx_ssfm *P, cplx *d_ux, cplx *d_uy, const cplx *d_hmul,
     PLX_HIP(hipMemsetAsync(P->d_ndone, 0, 64, st));
     const dim3 gcol((unsigned)(N2 / b.W), FC), grow((unsigned)(N1 / b.R), FC);
     PLX_LAUNCH(k_col_fwd, gcol, dim3(512), P->lds_col, st, b);
-    PLX_LAUNCH(k_row, grow, dim3(ROW_THREADS), P->lds_row, st, b);
+    PLX_LAUNCH(k_row, grow, dim3((unsigned)P->row_threads), P->lds_row, st, b);
     PLX_LAUNCH(k_col_inv, gcol, dim3(512), P->lds_col, st, b);
     PLX_HIP(hipGetLastError());
     return PLX_OK;
@@ -1818,7 +1844,7 @@ struct Adaptive {
         const int N1 = 1 << b.p1, N2 = 1 << b.p2;
         const dim3 gcol((unsigned)(N2 / b.W), (unsigned)b.nfc), grow((unsigned)(N1 / b.R), (unsigned)b.nfc);
         PLX_LAUNCH(k_col_fwd, gcol, dim3(256), P->lds_col, st, b);
-        PLX_LAUNCH(k_row, grow, dim3(ROW_THREADS), P->lds_row, st, b);
+        PLX_LAUNCH(k_row, grow, dim3((unsigned)P->row_threads), P->lds_row, st, b);
         PLX_LAUNCH(k_col_inv, gcol, dim3(256), P->lds_col, st, b);
     }
     void nl_att(cplx *x, double dz)
