@@ -18,14 +18,17 @@ receiver_cohmix itself is pinned by the reference's analytic identities only (ba
 import numpy as np
 
 
-def receiver_cohmix(sigx, sigy, hf_opt, elo, hf_el, balanced=True):
-    """Iric [n x 2] or [n x 4] = receiver_cohmix data path.  sigy None -> X only.  elo: scalar or [n]."""
+def receiver_cohmix(sigx, sigy, hf_opt, elo, hf_el, balanced=True, ndfn=0):
+    """Iric [n x 2] or [n x 4] = receiver_cohmix data path.  sigy None -> X only.  elo: scalar or [n].
+    ndfn: channel offset in bins when the field is 'unique' (nind = nmod(npoints-ndfn, Nfft), :104-107)."""
     sigx = np.asarray(sigx, dtype=np.complex128)
-    elo = np.asarray(elo, dtype=np.complex128) * np.ones(sigx.shape[0])
-    sx = np.fft.fft(sigx) * hf_opt                                  # :183-189
+    n = sigx.shape[0]
+    elo = np.asarray(elo, dtype=np.complex128) * np.ones(n)
+    nind = (np.arange(n) - ndfn) % n                                # 0-based nmod(npoints-ndfn, Nfft)
+    sx = np.fft.fft(sigx)[nind] * hf_opt                            # :183-189
     isy = sigy is not None
     if isy:
-        sy = np.fft.fft(np.asarray(sigy, dtype=np.complex128)) * hf_opt   # :238-242
+        sy = np.fft.fft(np.asarray(sigy, dtype=np.complex128))[nind] * hf_opt   # :238-242
         sy = np.fft.ifft(sy)                                        # :246
     sx = np.fft.ifft(sx)                                            # :247 / :252
 

@@ -89,11 +89,10 @@ def to_host_field(t):
     return t.detach().cpu().numpy().T.copy()
 
 
-def create_field(ftype, sigx, sigy=None, options=None):
-    """create_field('sepfields'|'unique', sigx, sigy, struct('power','average')) -- the part of
-    create_field.m:100-199 the hot path needs: average-power normalisation (:113-124) and the
-    'sepfields' assignment (:156-163).  'unique' (frequency-shifted sum, :165-199) is Tx-side and
-    stays on the host."""
+def create_field(ftype, sigx, sigy=None, options=None, rng=None):
+    """create_field('sepfields'|'unique', sigx, sigy, options) -- create_field.m:100-199: average-power
+    normalisation (:113-124), options.delay (:127-146), 'sepfields' (:156-163) and 'unique' (one field with the
+    channels at their carrier offsets, :165-199; Tx-side host work).  The fields end up in HBM."""
     sigx = np.asarray(sigx, dtype=np.complex128)
     if sigx.ndim == 1:
         sigx = sigx.reshape(-1, 1)
@@ -111,17 +110,64 @@ def create_field(ftype, sigx, sigy=None, options=None):
             sigy = sigy * k
         GSTATE.POWER = np.asarray(GSTATE.POWER, dtype=float) ** 2 / avge
     npol = 2 if isy else 1
-    GSTATE.DELAY = np.zeros((npol, GSTATE.NCH))
+    if options and options.get("delay") is not None:                                  # create_field.m:127-146
+        if isinstance(options["delay"], str):
+            if options["delay"] != "rand":
+                raise ValueError("options.delay must be 'rand' or numeric")
+            tau = np.round((rng or np.random.default_rng()).random((npol, GSTATE.NCH)) * GSTATE.NT)
+        else:
+            d = np.atleast_2d(np.asarray(options["delay"], dtype=float))
+            if d.shape != (npol, GSTATE.NCH):
+                raise ValueError("the delay must be of size [number of polarizations,number of channels]")
+            tau = np.sign(d) * np.floor(np.abs(d * GSTATE.NT) + 0.5)                   # MATLAB round
+        sigx = sigx.copy()
+        sigy = sigy.copy() if isy else sigy
+        for k in range(GSTATE.NCH):
+            sigx[:, k] = np.roll(sigx[:, k], int(tau[0, k]))                          # fastshift(x, n): y(i) = x(i-n)
+            if isy:
+                sigy[:, k] = np.roll(sigy[:, k], int(tau[1, k]))
+        GSTATE.DELAY = tau
+    else:
+        GSTATE.DELAY = np.zeros((npol, GSTATE.NCH))
     GSTATE.DISP = np.zeros((npol, GSTATE.NCH))
-    if ftype.lower() == "sepfields" or GSTATE.NCH == 1:
+    if ftype.lower() == "sepfields":
         GSTATE.FIELDX = to_device_field(sigx)
         GSTATE.FIELDX_TX = GSTATE.FIELDX.clone()
         if isy:
             GSTATE.FIELDY = to_device_field(sigy)
             GSTATE.FIELDY_TX = GSTATE.FIELDY.clone()
+    elif ftype.lower() == "unique":
+        # one field carrying every channel at its own carrier: spectra shifted by ndfn bins and summed
+        # (create_field.m:165-199; Tx-side, O(Nch N log N) once, on the host)
+        ndfn = unique_field_shifts()
+        zx = np.zeros(sigx.shape[0], dtype=np.complex128)
+        zy = np.zeros_like(zx)
+        for k in range(GSTATE.NCH):
+            zx = zx + np.roll(np.fft.fft(sigx[:, k]), -int(ndfn[k]))                   # fastshift(z, -ndfn(kch))
+            if isy:
+                zy = zy + np.roll(np.fft.fft(sigy[:, k]), -int(ndfn[k]))
+        GSTATE.FIELDX = to_device_field(np.fft.ifft(zx))
+        GSTATE.FIELDX_TX = GSTATE.FIELDX.clone()
+        if isy:
+            GSTATE.FIELDY = to_device_field(np.fft.ifft(zy))
+            GSTATE.FIELDY_TX = GSTATE.FIELDY.clone()
     else:
-        raise NotImplementedError("create_field('unique') with several channels is Tx-side host code outside the "
-                                  "accelerated path (create_field.m:165-199)")
+        raise ValueError("the field type must be 'unique' or 'sepfields'")
+
+
+def unique_field_shifts():
+    """ndfn of create_field.m:181-184 / receiver_cohmix.m:104-107: carrier offsets of the channels from the central
+    wavelength, in frequency bins of GSTATE.FN."""
+    lamt = np.atleast_1d(np.asarray(GSTATE.LAMBDA, dtype=float))
+    maxl, minl = lamt.max(), lamt.min()
+    fnyqmin = (CONSTANTS.CLIGHT / minl - CONSTANTS.CLIGHT / maxl) / GSTATE.SYMBOLRATE
+    if GSTATE.NT < fnyqmin and fnyqmin != 0:
+        raise ValueError("number of samples per symbol is too small")               # :170-179 (the prompt is not asked)
+    lamc = 2 * maxl * minl / (maxl + minl)
+    deltafn = CONSTANTS.CLIGHT * (1 / lamc - 1.0 / lamt)
+    minfreq = GSTATE.FN[1] - GSTATE.FN[0]
+    v = deltafn / GSTATE.SYMBOLRATE / minfreq
+    return (np.sign(v) * np.floor(np.abs(v) + 0.5)).astype(np.int64)                # MATLAB round
 
 
 def lasersource(Ptx, lam, spac=None):

@@ -107,9 +107,10 @@ def _front_tables(ich, x, rng=None, nfc=None):
     nfft = fn.size
     if nfc is None:
         nfc = GSTATE.FIELDX.shape[0]
-    if nfc != GSTATE.NCH:
-        raise NotImplementedError("receiver_cohmix on a 'unique' multi-channel field (spectral channel selection, "
-                                  "receiver_cohmix.m:104-125) is outside the accelerated path; use 'sepfields'")
+    ndfn = 0
+    if nfc != GSTATE.NCH:                                             # a 'unique' field: select channel ich, :104-125
+        from .gstate import unique_field_shifts
+        ndfn = int(unique_field_shifts()[ich - 1])
     b2b = False
     if "b2b" in x:                                                    # :132-141
         if x["b2b"] != "b2b":
@@ -160,6 +161,14 @@ def _front_tables(ich, x, rng=None, nfc=None):
         ph = (0 if det is None else det) + (0 if pn is None else pn)
         elo = ecw * (np.cos(ph) + 1j * np.sin(ph))                    # :227
     hel = myfilter(x["eftype"], fn, x["ebw"], x.get("eord"))          # :296
+    if ndfn:
+        # sigx = fft(sigx); sigx = sigx(nind) moves the spectrum by ndfn bins before the optical filter (:104-107, :184).
+        # The device path gets the same currents without touching the field: filter with the table moved back by
+        # ndfn bins, and give the (unit-modulus) time-domain phasor of the shift to the local oscillator instead --
+        # |j s p + j Elo|^2 = |j s + j Elo conj(p)|^2 for each of the four mixer outputs (:254-291).
+        hopt = np.roll(hopt, -ndfn)
+        p = np.exp(2j * math.pi * ndfn * np.arange(nfft) / nfft)
+        elo = (elo * np.ones(nfft)) * np.conj(p)
     return hopt, elo, hel, post_delay, b2b
 
 
@@ -218,10 +227,11 @@ def _channel_fields(ich, b2b):
     fy = GSTATE.FIELDY_TX if b2b else GSTATE.FIELDY
     if fx is None:
         raise ValueError("GSTATE.FIELDX is empty")
-    ux = fx[ich - 1:ich].clone()
+    row = ich - 1 if fx.shape[0] == GSTATE.NCH else 0                   # nch = ich / nch = 1 for a unique field, :108,:123
+    ux = fx[row:row + 1].clone()
     if GSTATE.FIELDY is None:
         return ux, None
-    uy = fy[ich - 1:ich].clone() if fy is not None else ux * 0          # :230-236
+    uy = fy[row:row + 1].clone() if fy is not None else ux * 0          # :230-236
     return ux, uy
 
 

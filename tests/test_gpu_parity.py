@@ -1006,3 +1006,43 @@ def test_dsp4cohdec_ex19_single_pol_vs_oracle(lib, oracle):
     np.testing.assert_array_equal(pat_hat, oracle.samp2pat_coherent(np.angle(ref)))
     with pytest.raises(NotImplementedError, match="applydcf"):
         px.dsp4cohdec(1, pat, x, dict(p, applydcf=True))
+
+
+def test_unique_wdm_field_create_and_receive(lib, oracle):
+    """create_field('unique') (create_field.m:165-199) -> scalar fiber on the one wide field -> RxPdmCohQpsk of each
+    channel (receiver_cohmix.m:104-125 channel selection, folded into the filter / LO tables): device vs the literal
+    oracle form; options.delay; the aliasing check."""
+    import polmux_amd as px
+    from oracle import front
+    from polmux_amd import rxfront, synth
+    from polmux_amd.gstate import GSTATE, to_host_field, unique_field_shifts
+    nsymb, nt, nch = 256, 32, 3
+    px.reset_all(nsymb, nt, nch)
+    GSTATE.SYMBOLRATE = 10.0
+    px.lasersource(1.0, 1550.0, 0.4)
+    cols = np.stack([synth.pdm_qpsk_field(nsymb, nt, 1.0, 2 + k, 5 + k)[0] for k in range(nch)], 1)
+    px.create_field("unique", cols, None, dict(power="average", delay=np.array([[0.25, 0.0, -0.5]])))
+    assert GSTATE.FIELDX.shape == (1, nsymb * nt) and GSTATE.DELAY.tolist() == [[8.0, 0.0, -16.0]]
+    nd = unique_field_shifts()
+    k = np.sqrt(1.0 / np.mean(np.abs(cols) ** 2, axis=0))
+    z = sum(np.roll(np.fft.fft(np.roll(cols[:, c] * k[c], int(GSTATE.DELAY[0, c]))), -int(nd[c])) for c in range(nch))
+    np.testing.assert_allclose(to_host_field(GSTATE.FIELDX)[:, 0], np.fft.ifft(z), atol=1e-13)
+    fib = dict(length=2e4, alphadB=0.2, aeff=80.0, n2=2.7e-20, disp=4.0, slope=0.0, dphimax=5e-3, dzmax=2e4)
+    fib["lambda"] = 1550.0
+    px.fiber(fib, "g-s-")
+    field = to_host_field(GSTATE.FIELDX)[:, 0]
+    rp = _rx_params(nt, applyadc=False, baudrate=10.0, samplingrate=20.0)
+    for ich in (1, 3):
+        rs, _ = px.RxPdmCohQpsk(ich, np.zeros(nsymb), rp)
+        hopt0 = rxfront.myfilter("gauss", GSTATE.FN, 0.95)
+        hel = rxfront.myfilter("bessel5", GSTATE.FN, 0.65)
+        cur = front.receiver_cohmix(field, None, hopt0, 1.0, hel, True, ndfn=int(nd[ich - 1]))
+        _, _, _, post_delay, _ = rxfront._front_tables(ich, rp)
+        shift = rxfront._mround(-rxfront.theory_delay(ich, rp, False, post_delay) * nt)
+        want = front.rx_front(cur, False, 0, [shift], nt // 2, rxfront.fir1_lowpass(16, 2.0 / nt))
+        assert np.abs(rs.cpu().numpy() - want).max() <= 1e-10 * np.abs(want).max()
+    GSTATE.LAMBDA = np.array([1540.0, 1550.0, 1560.0])
+    with pytest.raises(ValueError, match="too small"):
+        px.create_field("unique", cols)
+    with pytest.raises(ValueError, match="'unique' or 'sepfields'"):
+        px.create_field("both", cols)

@@ -174,3 +174,39 @@ def test_front_tables_follow_receiver_cohmix():
     assert rxfront.theory_delay(1, x, False, 0.0) == pytest.approx(0.25 + 0.3863 / 0.65)
     assert rxfront.theory_delay(1, dict(x, b2b="b2b"), True, 0.0) == pytest.approx(0.3863 / 0.65)
     assert rxfront._mround(2.5) == 3 and rxfront._mround(-2.5) == -3 and rxfront._mround(-0.4) == 0
+
+
+def test_unique_field_channel_selection_folds_into_the_tables():
+    """receiver_cohmix.m:104-107,184: sigx = sigx(nind) on a 'unique' WDM field.  The device path leaves the field alone
+    and moves the optical filter table and the LO instead (rxfront._front_tables): same currents as the literal form."""
+    import polmux_amd as px
+    from polmux_amd.gstate import GSTATE, unique_field_shifts
+    nsymb, nt, nch = 64, 32, 3
+    px.reset_all(nsymb, nt, nch)
+    GSTATE.SYMBOLRATE = 10.0
+    px.lasersource(1.0, 1550.0, 0.4)
+    nd = unique_field_shifts()
+    assert nd[1] == 0 and nd[0] == -nd[2] and nd[0] < 0              # 0.4 nm = ~50 GHz = 5 symbol rates = ~320 bins; ch 1 = shortest lambda
+    assert abs(-nd[0] - round(299792458.0 * (1 / 1549.6 - 1 / 1550.0) / 10.0 * nsymb)) <= 1
+    cols = [synth.pdm_qpsk_field(nsymb, nt, 1.0, 2 + k, 5 + k)[0] for k in range(nch)]
+    z = sum(np.roll(np.fft.fft(c), -int(nd[k])) for k, c in enumerate(cols))           # create_field.m:186-189
+    field = np.fft.ifft(z)
+    GSTATE.FIELDX = np.zeros((1, nsymb * nt), dtype=complex)                          # unique: one row, NCH = 3
+    x = dict(oftype="gauss", obw=1.9, eftype="bessel5", ebw=0.65, lopower=0.0)
+    for ich in (1, 2, 3):
+        hopt, elo, hel, pd, _ = rxfront._front_tables(ich, x)
+        got = front.receiver_cohmix(field, None, hopt, elo, hel, True)                 # what the device computes
+        fn = GSTATE.FN
+        lit = front.receiver_cohmix(field, None, rxfront.myfilter("gauss", fn, 0.95), 1.0, hel, True, ndfn=int(nd[ich - 1]))
+        np.testing.assert_allclose(got, lit, atol=1e-11 * np.abs(lit).max())
+        # and the selected channel is the transmitted one, up to the in-band sidelobes of its neighbours 5 symbol rates
+        # away (almost square pulses: about -20 dB)
+        clean = front.receiver_cohmix(cols[ich - 1], None, rxfront.myfilter("gauss", fn, 0.95), 1.0, hel, True)
+        assert np.abs(got - clean).max() < 0.2 * np.abs(clean).max()
+    # a single channel in the unique field comes back exactly
+    GSTATE.FIELDX = np.zeros((1, nsymb * nt), dtype=complex)
+    alone = np.fft.ifft(np.roll(np.fft.fft(cols[0]), -int(nd[0])))
+    hopt, elo, hel, pd, _ = rxfront._front_tables(1, x)
+    got = front.receiver_cohmix(alone, None, hopt, elo, hel, True)
+    clean = front.receiver_cohmix(cols[0], None, rxfront.myfilter("gauss", GSTATE.FN, 0.95), 1.0, hel, True)
+    np.testing.assert_allclose(got, clean, atol=1e-11 * np.abs(clean).max())
