@@ -7,6 +7,9 @@ import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "tests", "emu", "_build", "libpolmux_emu.so")
+# PLX_EMU_SAN=1 (with LD_PRELOAD=$(gcc -print-file-name=libasan.so)): the ASan + UBSan build, tests/emu/build.sh SAN=1
+if os.environ.get("PLX_EMU_SAN") == "1":
+    LIB = os.path.join(ROOT, "tests", "emu", "_build", "libpolmux_emu_san.so")
 
 
 def build():
@@ -14,7 +17,8 @@ def build():
         + [os.path.join(ROOT, "include", "polmux_hip.h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
         return LIB
-    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build.sh")], stdout=subprocess.DEVNULL)
+    env = dict(os.environ, SAN="1") if LIB.endswith("_san.so") else None
+    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build.sh")], stdout=subprocess.DEVNULL, env=env)
     return LIB
 
 
