@@ -49,7 +49,7 @@ def parse():
                          "and per step (Monte-Carlo PMD realisations), receiver noise as ASE stand-in")
     ap.add_argument("--no-overlap", action="store_true", help="run the receiver on the fibre stream (no stream overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-frames", type=int, default=32, help="frames of the batch the CPU baseline processes (~0.4 s each)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the batch the one-core CPU baseline processes (~0.5 s each)")
     return ap.parse_args()
 
 
@@ -75,32 +75,60 @@ class HipEvents:
         return ms.value
 
 
-def cpu_baseline(cfg, hp, nframes):
-    """The reference algorithm restated on the CPU (oracle/, kind 'port'), one core, on a bounded
-    sample of the SAME workload: `nframes` frames of the batch."""
-    from oracle import plxo
-    import torch
+def host_cores():
+    """CPU cores this process may actually use: the smaller of the affinity mask and the cgroup CPU quota (a GPU box
+    hands each GPU a share of the host, e.g. 16 of 256 logical CPUs), PLX_BENCH_CORES overrides."""
+    if os.environ.get("PLX_BENCH_CORES"):
+        return max(1, int(os.environ["PLX_BENCH_CORES"]))
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                   # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        cores = min(cores, max(1, int(quota)))
+    return max(1, min(cores, 64))
+
+
+def cpu_params(cfg, hp, noise):
     gam, betat, db1 = hp._keep
-    t0 = time.perf_counter()
-    for _ in range(nframes):
-        rc, fd, nc, ox, oy = plxo.matrix_ssfm(hp.tx_host[0], hp.tx_host[1], betat, db1, min(cfg.dzmax, cfg.length),
-                                              cfg.dphimax, gam, hp.alphalin, cfg.length, 1, 0, hp.fls, [0.0], [0.0], [0.0])
-        if hp.front is not None:
-            from oracle import front
-            t = hp.front_tables
-            cur = front.receiver_cohmix(ox[:, 0], oy[:, 0], t["hopt"], t["elo"], t["hel"], True)
-            rx = front.rx_front(cur, True, cfg.adcbits, hp.front_shifts, t["decim"], t["fir"])
-        else:
-            half = cfg.nt // 2
-            rx = np.stack([ox[::half, 0], oy[::half, 0]], 1) * hp.rx_scale
-        ex, ey, _ = plxo.cde_ofde(rx[:, 0], rx[:, 1], 2 * cfg.symbolrate * 1e9, cfg.lam * 1e-9, cfg.length, cfg.disp * 1e-6,
-                                  cfg.slope * 1e-6, cfg.fft_length, cfg.cde_L)
-        op = plxo.dsp_params(power_mw=hp.power_mw, applypol=True, polmethod="cma", cma_mu=cfg.cma_mu, cma_taps=cfg.cma_taps,
-                             freqavg=cfg.freqavg, phasavg=cfg.phasavg, poworder=cfg.poworder)
-        sym = plxo.dsp_pdm_coh_qpsk(np.stack([ex, ey], 1), op)
-        plxo.samp2pat_coherent(np.angle(sym))
-    dt = time.perf_counter() - t0
-    return nframes * cfg.nfft / dt / 1e9, dt, nc
+    p = dict(tx_x=hp.tx_host[0], tx_y=hp.tx_host[1], betat=betat, db1=db1, dzmax=min(cfg.dzmax, cfg.length), dphimax=cfg.dphimax,
+             gam=gam, alphalin=hp.alphalin, length=cfg.length, fls=list(hp.fls), nt=cfg.nt, rx_scale=hp.rx_scale, noise=noise,
+             symbolrate=cfg.symbolrate, lam=cfg.lam, disp=cfg.disp, slope=cfg.slope, fft_length=cfg.fft_length, cde_L=cfg.cde_L,
+             power_mw=hp.power_mw, cma_mu=cfg.cma_mu, cma_taps=cfg.cma_taps, freqavg=cfg.freqavg, phasavg=cfg.phasavg,
+             poworder=cfg.poworder, adcbits=cfg.adcbits, front=None)
+    if hp.front is not None:
+        p["front"] = hp.front_tables
+        p["front_shifts"] = hp.front_shifts
+    return p
+
+
+def cpu_baseline(cfg, hp, nframes, noise):
+    """The reference algorithm restated on the CPU (oracle/, kind 'port') on a bounded sample of the SAME workload
+    (frames of the batch, same receiver noise level): one core, then one frame stream per host core."""
+    from oracle import cpu_chain
+    p = cpu_params(cfg, hp, noise)
+    dt, nc = cpu_chain.run_frames(p, nframes, 999)
+    one = (nframes * cfg.nfft / dt / 1e9, dt, nc)
+    cores = host_cores()
+    per = max(1, nframes // 4)
+    res = cpu_chain.run_parallel(p, per, cores)
+    allc = None if res is None else (cores * per * cfg.nfft / res[1] / 1e9, res[1], res[0], cores, per)
+    return one, allc
 
 
 def main():
@@ -252,10 +280,16 @@ def main():
                          "launches": row_launches},
         }
         if not a.no_cpu_baseline:
-            v, cdt, nc = cpu_baseline(cfg, hp, a.cpu_frames)
+            (v, cdt, nc), allc = cpu_baseline(cfg, hp, a.cpu_frames, a.noise)
             out["cpu_baseline"] = {"value": v, "unit": "Gsample/s", "cores": 1, "kind": "port",
-                                   "sample": "%d frame(s) of the same batch through oracle/ (fibre %d steps + CDE + CMA + CPE), "
-                                             "%.1f s" % (a.cpu_frames, nc, cdt)}
+                                   "sample": "%d frame(s) of the same batch through oracle/ (fibre %d steps + front end + noise + "
+                                             "CDE + CMA + CPE), %.1f s" % (a.cpu_frames, nc, cdt)}
+            if allc is not None:
+                va, busiest, wall, cores, per = allc
+                out["cpu_baseline_all_cores"] = {"value": va, "unit": "Gsample/s", "cores": cores, "kind": "port",
+                                                 "realisations_per_s": cores * per / busiest,
+                                                 "sample": "%d processes x %d frame(s) each, busiest process %.1f s (%.1f s "
+                                                           "wall incl. process start)" % (cores, per, busiest, wall)}
         print(json.dumps(out))
     hp.close()
     if world > 1:

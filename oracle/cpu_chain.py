@@ -1,0 +1,78 @@
+"""TEST INFRASTRUCTURE ONLY -- the whole hot path of one frame on the CPU oracle, for bench.py's cpu_baseline leg.
+
+fibre (plxo.matrix_ssfm, fiber.m:459-554) -> front end (2-sps pick, or oracle/front.py) -> receiver noise ->
+CDE_OFDE -> DspPdmCohQpsk (CMA + carrier recovery) -> samp2pat.  Importable without torch so that worker processes
+(one frame per host core) start quickly.
+"""
+import time
+
+import numpy as np
+
+
+def run_frames(p, nframes, seed):
+    """p: dict of plain numpy arrays / scalars (picklable).  Returns (seconds, ncycle of the last frame)."""
+    from oracle import plxo
+    r = np.random.default_rng(seed)
+    nc = 0
+    t0 = time.perf_counter()
+    for _ in range(nframes):
+        rc, fd, nc, ox, oy = plxo.matrix_ssfm(p["tx_x"], p["tx_y"], p["betat"], p["db1"], p["dzmax"], p["dphimax"], p["gam"],
+                                              p["alphalin"], p["length"], 1, 0, p["fls"], [0.0], [0.0], [0.0])
+        if p.get("front") is not None:
+            from oracle import front
+            t = p["front"]
+            cur = front.receiver_cohmix(ox[:, 0], oy[:, 0], t["hopt"], t["elo"], t["hel"], True)
+            rx = front.rx_front(cur, True, p["adcbits"], p["front_shifts"], t["decim"], t["fir"])
+        else:
+            half = p["nt"] // 2
+            rx = np.stack([ox[::half, 0], oy[::half, 0]], 1) * p["rx_scale"]
+        if p["noise"]:
+            rx = rx + p["noise"] * (r.standard_normal(rx.shape) + 1j * r.standard_normal(rx.shape))
+        ex, ey, _ = plxo.cde_ofde(rx[:, 0], rx[:, 1], 2 * p["symbolrate"] * 1e9, p["lam"] * 1e-9, p["length"], p["disp"] * 1e-6,
+                                  p["slope"] * 1e-6, p["fft_length"], p["cde_L"])
+        op = plxo.dsp_params(power_mw=p["power_mw"], applypol=True, polmethod="cma", cma_mu=p["cma_mu"], cma_taps=p["cma_taps"],
+                             freqavg=p["freqavg"], phasavg=p["phasavg"], poworder=p["poworder"])
+        sym = plxo.dsp_pdm_coh_qpsk(np.stack([ex, ey], 1), op)
+        plxo.samp2pat_coherent(np.angle(sym))
+    return time.perf_counter() - t0, nc
+
+
+def run_parallel(p, frames_per_core, cores, timeout_s=180.0):
+    """One child process per core (`python -m oracle.cpu_chain params.npz n seed`: fresh interpreters that never see the
+    parent's GPU state), each running frames_per_core frames.  Returns (wall seconds, busiest child's compute seconds)
+    or None if a child fails or the time limit passes (children are then terminated)."""
+    import os
+    import pickle
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        pf = os.path.join(d, "params.pkl")
+        with open(pf, "wb") as f:
+            pickle.dump(p, f)
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, "-m", "oracle.cpu_chain", pf, str(frames_per_core), str(1000 + k)], cwd=root,
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for k in range(cores)]
+        secs, ok = [], True
+        for pr in procs:
+            try:
+                out, _ = pr.communicate(timeout=max(1.0, timeout_s - (time.perf_counter() - t0)))
+                secs.append(float(out.strip().split()[-1]))
+            except Exception:
+                ok = False
+        if not ok or len(secs) != cores:
+            for pr in procs:
+                if pr.poll() is None:
+                    pr.kill()
+            return None
+        return time.perf_counter() - t0, max(secs)
+
+
+if __name__ == "__main__":
+    import pickle
+    import sys
+    with open(sys.argv[1], "rb") as f:
+        params = pickle.load(f)
+    dt, _ = run_frames(params, int(sys.argv[2]), int(sys.argv[3]))
+    print(dt)
