@@ -949,7 +949,7 @@ template <int PF> __global__ __launch_bounds__(ROW_THREADS) void k_row_p(SsfmArg
 // ticket counter -> the last arriver runs ctrl_step and publishes (Leff, done) -> the others poll one
 // word.  All shared words use agent-scope atomics (CDNA guide G16); the next tile's loads are already
 // in flight while a workgroup waits.  Spins are bounded; a timeout raises an error on the host.
-template <int PF> __global__ __launch_bounds__(256) void k_colx(SsfmArgs a, int tiles_x, int tiles_pf, int total)
+template <int PF, int NT> __global__ __launch_bounds__(NT) void k_colx(SsfmArgs a, int tiles_x, int tiles_pf, int total)
 {
     PLX_DYN_LDS(lds);
     if (*a.ndone >= a.nframes) return;
@@ -958,7 +958,7 @@ template <int PF> __global__ __launch_bounds__(256) void k_colx(SsfmArgs a, int 
     cplx *s = (cplx *)lds;
     cplx *tw = s + ((size_t)N1 << a.logT);
     double *red = (double *)(tw + (N1 >> 1)); // [16] + broadcast slots [16..19]
-    lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, 256);
+    lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, NT);
     cplx xv[PF], yv[PF];
     int tl = blockIdx.x;
     bool have = false;
@@ -970,7 +970,7 @@ template <int PF> __global__ __launch_bounds__(256) void k_colx(SsfmArgs a, int 
         if (have) {
 #pragma unroll
             for (int k = 0; k < PF; k++) {
-                const int e = tid + k * 256;
+                const int e = tid + k * NT;
                 const size_t g = gbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
                 xv[k] = a.ux[g]; yv[k] = a.uy[g];
             }
@@ -986,7 +986,7 @@ template <int PF> __global__ __launch_bounds__(256) void k_colx(SsfmArgs a, int 
             for (int k = 0; k < PF; k++) { pin(xv[k]); pin(yv[k]); }
 #pragma unroll
             for (int k = 0; k < PF; k++) {
-                const int e = tid + k * 256;
+                const int e = tid + k * NT;
                 const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
                 s[o] = xv[k];
                 s[o + W] = yv[k];
@@ -999,13 +999,13 @@ template <int PF> __global__ __launch_bounds__(256) void k_colx(SsfmArgs a, int 
             const bool started = a.ctl[f].started != 0;
             double sc = 1.0;
             if (started) { // finish step s: ifft (1/N) and attenuation (:531-532)
-                if (!(a.dbg & 1)) lds_fft_dit(s, a.p1, T, 1, a.logT, tw, tid, 256, true);
+                if (!(a.dbg & 1)) lds_fft_dit(s, a.p1, T, 1, a.logT, tw, tid, NT, true);
                 sc = a.ctl[f].att * a.invN;
             }
             double m = 0;
 #pragma unroll
             for (int k = 0; k < PF; k++) {
-                const int e = tid + k * 256;
+                const int e = tid + k * NT;
                 const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
                 const cplx x = cscale(s[o], sc), y = cscale(s[o + W], sc);
                 double p = x.x * x.x + x.y * x.y;
@@ -1020,7 +1020,7 @@ template <int PF> __global__ __launch_bounds__(256) void k_colx(SsfmArgs a, int 
             __syncthreads();
             if (tid == 0) {
                 double mm = red[0];
-                for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
+                for (int w = 1; w < NT / 64; w++) mm = red[w] > mm ? red[w] : mm;
                 const unsigned long long prev = atomicMax(a.umax + fc, (unsigned long long)__double_as_longlong(mm));
                 unsigned ticket = 0;
                 if (prev != ~0ull) ticket = atomicAdd(a.arrive + f, 1u); // (prev used: the max has completed first)
@@ -1048,7 +1048,7 @@ template <int PF> __global__ __launch_bounds__(256) void k_colx(SsfmArgs a, int 
                 const double gamleff = a.gam[c] * leff;
 #pragma unroll
                 for (int k = 0; k < PF; k++) {
-                    const int e = tid + k * 256;
+                    const int e = tid + k * NT;
                     const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
                     cplx x = s[o], y = s[o + W];
                     const double P = x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y;
@@ -1070,10 +1070,10 @@ template <int PF> __global__ __launch_bounds__(256) void k_colx(SsfmArgs a, int 
                 }
             }
             __syncthreads();
-            if (!finished && !(a.dbg & 1)) lds_fft_dif(s, a.p1, T, 1, a.logT, tw, tid, 256, true);
+            if (!finished && !(a.dbg & 1)) lds_fft_dif(s, a.p1, T, 1, a.logT, tw, tid, NT, true);
 #pragma unroll
             for (int k = 0; k < PF; k++) {
-                const int e = tid + k * 256;
+                const int e = tid + k * NT;
                 const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
                 const size_t g = cbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
                 a.ux[g] = s[o];
@@ -1473,14 +1473,22 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         if (const char *e = getenv("PLX_SSFM_GRID_ROW")) P->grid_row = atoi(e);
     }
     P->row16 = (a.dual && !a.pmd && a.p2 == 8 && N1 % ROW16_R == 0 && getenv("PLX_SSFM_ROW16")) ? 1 : 0;   // opt-in (profiles/r01_notes.md)
-    // fused column sweep (opt-in, PLX_SSFM_FUSE=1): needs the tile to be PF x 256 and all tiles of a frame
-    // co-resident.  Measured on MI355X it moves 1/3 less HBM traffic but is latency-bound at 2 workgroups
-    // per CU and ends up level with the plain three-sweep step (profiles/r01_notes.md), so the default
-    // stays the barrier-free form.
-    if (a.dual && getenv("PLX_SSFM_FUSE")) {
+    // Fused column sweep: the inverse column pass of step s, the step controller and the forward column pass of
+    // step s+1 in ONE launch on an LDS/register-resident tile (2 sweeps over HBM per step instead of 3).  Needs
+    // the tile to be PF x 256 and every tile of a frame co-resident (per-frame ticket barrier).  Default for the
+    // 256 x (8+8) tile, where the register-blocked k_colx16 applies: measured 139.5 vs 148.8 ms per 1024-frame
+    // pass (profiles/r01_notes.md); opt-in (PLX_SSFM_FUSE=1) elsewhere, PLX_SSFM_NO_FUSE=1 switches it off.
+    int ncu = 256;
+    {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            ncu = v;
+    }
+    const bool fuse_default = a.p1 == 8 && a.W == 8;
+    if (a.dual && !getenv("PLX_SSFM_NO_FUSE") && (fuse_default || getenv("PLX_SSFM_FUSE"))) {
         const int nel_col = N1 << a.logW, tiles_pf = nfc * (N2 / a.W);
         int wg = (int)(160 * 1024 / (P->lds_col + 1024)); if (wg < 1) wg = 1; if (wg > 2) wg = 2;
-        const int cap = 256 * wg;
+        const int cap = ncu * wg;
         if ((nel_col == 8 * 256 || nel_col == 4 * 256 || nel_col == 16 * 256) && tiles_pf <= cap) {
             P->fused = nel_col / 256;
             P->tiles_pf = tiles_pf;
@@ -1495,8 +1503,9 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         }
     }
     if (allow_lds(k_row16, P->lds_row) != hipSuccess) { free_plan(P); PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS"); }
-    if (allow_lds(k_colx16, P->lds_col) != hipSuccess || allow_lds(k_colx<8>, P->lds_col) != hipSuccess || allow_lds(k_colx<4>, P->lds_col) != hipSuccess ||
-        allow_lds(k_colx<16>, P->lds_col) != hipSuccess) {
+    if (allow_lds(k_colx16, P->lds_col) != hipSuccess || allow_lds(k_colx<8, 256>, P->lds_col) != hipSuccess ||
+        allow_lds(k_colx<4, 256>, P->lds_col) != hipSuccess || allow_lds(k_colx<16, 256>, P->lds_col) != hipSuccess ||
+        allow_lds(k_colx<8, 512>, P->lds_col) != hipSuccess || allow_lds(k_colx<4, 512>, P->lds_col) != hipSuccess) {
         free_plan(P);
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
     }
@@ -1629,9 +1638,11 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
 #endif
                 if (P->fused == 8 && a.p1 == 8 && a.W == 8 && !getenv("PLX_SSFM_NO_R16"))
                     PLX_LAUNCH(k_colx16, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
-                else if (P->fused == 8) PLX_LAUNCH(k_colx<8>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
-                else if (P->fused == 4) PLX_LAUNCH(k_colx<4>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
-                else PLX_LAUNCH(k_colx<16>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
+                else if (P->fused == 8 && getenv("PLX_SSFM_FUSE_512")) PLX_LAUNCH((k_colx<4, 512>), gx, dim3(512), P->lds_col, st, a, tcx, P->tiles_pf, tct);
+                else if (P->fused == 8) PLX_LAUNCH((k_colx<8, 256>), gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
+                else if (P->fused == 4) PLX_LAUNCH((k_colx<4, 256>), gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
+                else if (getenv("PLX_SSFM_FUSE_256")) PLX_LAUNCH((k_colx<16, 256>), gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
+                else PLX_LAUNCH((k_colx<8, 512>), gx, dim3(512), P->lds_col, st, a, tcx, P->tiles_pf, tct);
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
 #endif

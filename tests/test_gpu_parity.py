@@ -524,17 +524,20 @@ def test_fiber_function_surface(lib, oracle):
         px.fiber(x)
 
 
-@pytest.mark.parametrize("var", ["PLX_SSFM_FUSE", "PLX_SSFM_PERSIST"])
-def test_optin_sweep_variants_match_oracle(lib, oracle, monkeypatch, var):
-    """The opt-in SSFM sweeps (fused col_inv+control+col_fwd behind a per-frame barrier; persistent
-    register-prefetching sweeps) reproduce the oracle like the default path, frames with different step counts."""
+@pytest.mark.parametrize("env", [{"PLX_SSFM_FUSE": "1"}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_PERSIST": "1", "PLX_SSFM_NO_FUSE": "1"}])
+def test_optin_sweep_variants_match_oracle(lib, oracle, monkeypatch, env):
+    """The selectable SSFM sweeps (fused col_inv+control+col_fwd behind a per-frame barrier -- the default at this
+    geometry --, the plain three-sweep step, persistent register-prefetching sweeps) all reproduce the oracle, frames
+    with different step counts."""
     import torch
     F = 20                                           # > 16 frames: the fused grid walks more than one round
     c = _fibre_case(1024, 64, "g-s-", 2.0, length=2e4)
-    monkeypatch.setenv(var, "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     plan = C.c_void_p()
     lib.call("plx_ssfm_create", C.byref(plan), C.byref(_desc(c, frames=F)))
-    monkeypatch.delenv(var)
+    for k in env:
+        monkeypatch.delenv(k)
     scale = np.sqrt(np.linspace(0.5, 6.0, F))
     ux = _dev(np.stack([c["ux"][:, 0] * s for s in scale]))
     uy = _dev(np.stack([c["uy"][:, 0] * s for s in scale]))
