@@ -9,7 +9,7 @@ from polmux_amd.fiber import parse_flag, fiber_tables
 from polmux_amd.gstate import GSTATE
 import polmux_amd as px
 emu=_abi.get()
-nsymb,nt,nch,nplates=64,int(sys.argv[6]) if len(sys.argv)>6 else 16,int(sys.argv[1]),int(sys.argv[2])
+nsymb,nt,nch,nplates=int(os.environ.get("NSYMB","64")),int(sys.argv[6]) if len(sys.argv)>6 else 16,int(sys.argv[1]),int(sys.argv[2])
 flag=sys.argv[3]
 n=nsymb*nt
 px.reset_all(nsymb,nt,nch); GSTATE.SYMBOLRATE=28.0
@@ -23,6 +23,7 @@ cols=[synth.pdm_qpsk_field(nsymb,nt,3.0*(1+0.1*(k%5)),2+2*k,3+2*k) for k in rang
 sx=np.stack([c[0] for c in cols],1); sy=np.stack([c[1] for c in cols],1)
 r=np.random.default_rng(100)
 db0=r.random(nplates)*2*np.pi-np.pi; th=r.random(nplates)*np.pi-np.pi/2; ep=0.5*np.arcsin(r.random(nplates)*2-1)
+if fls[1]==0: db0=th=ep=np.zeros(1)   # fiber.m:291-297: without PMD the wrapper passes zero birefringence
 d=SsfmDesc(); d.nfft,d.nfc,d.dual_pol,d.max_frames=n,nch,1,1
 for i in range(4): d.fls[i]=fls[i]
 d.dzmaxt,d.dphimaxt,d.alphalin,d.length,d.nplates,d.manakov=dzm,dph,t["alphalin"],LL,nplates,0

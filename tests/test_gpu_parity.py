@@ -99,9 +99,12 @@ def _brf(nplates, seed):
     (256, 64, "gps-", dict(pavg=8.0, nplates=20, dgd=0.3, manakov="yes")),
     (1024, 64, "gp--", dict(nplates=100, dgd=0.1)),         # ex24-style linear PMD, single step over 100 plates
     (1024, 64, "g-s-", dict(pavg=2.0)),                     # BASELINE config[1] frame
+    (1024, 64, "g-s-", dict(pavg=2.0, nfc=4)),              # 'sepfields' WDM, dual-pol: shared dz, per-channel walk-off
+    (1024, 64, "gps-", dict(pavg=0.8, nfc=16, nplates=10, dgd=0.2)),   # BASELINE config[2] frame: 16 channels
 ])
 def test_matrix_ssfm_gateway_vs_oracle(lib, oracle, nsymb, nt, flag, kw):
-    c = _fibre_case(nsymb, nt, flag, kw.get("pavg", 2.0), kw.get("nplates", 1), kw.get("dgd", 0.0), kw.get("manakov", "no"))
+    c = _fibre_case(nsymb, nt, flag, kw.get("pavg", 2.0), kw.get("nplates", 1), kw.get("dgd", 0.0), kw.get("manakov", "no"),
+                    nfc=kw.get("nfc", 1))
     db0, th, ep = _brf(c["nplates"], 11) if c["fls"][1] else (np.zeros(1), np.zeros(1), np.zeros(1))
     d = _desc(c)
     planes = [np.asfortranarray(v.copy()) for v in (c["ux"].real, c["ux"].imag, c["uy"].real, c["uy"].imag)]
