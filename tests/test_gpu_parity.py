@@ -1052,3 +1052,19 @@ def test_unique_wdm_field_create_and_receive(lib, oracle):
         px.create_field("unique", cols)
     with pytest.raises(ValueError, match="'unique' or 'sepfields'"):
         px.create_field("both", cols)
+
+
+def test_ex19_monte_carlo_script(lib):
+    """examples/ex19_coherent_singlepol.py = ex19_coherent_singlepol.m:104-154: the reference's one-realisation-per-
+    iteration Monte-Carlo loop on the device path.  BER falls with OSNR and sits near the differential-QPSK theory."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("ex19", os.path.join(os.path.dirname(__file__), "..", "examples",
+                                                                         "ex19_coherent_singlepol.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.main(osnr=(3.0, 6.0), stop=(0.2, 68), max_runs=120, quiet=True)
+    (o1, b1, s1, n1), (o2, b2, s2, n2) = res
+    assert n1 >= 10 and n2 >= 10
+    assert 1e-3 < b2 < b1 < 0.2                                        # ex19's published curve: ~4e-2 at 3 dB, ~4e-3 at 6 dB
+    assert s1 / b1 < 0.5

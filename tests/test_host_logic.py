@@ -255,3 +255,24 @@ def test_samp2pat_host():
     np.testing.assert_array_equal(px.samp2pat(dict(rec="coherent"), None, ph), [[1, 1, 1, 0], [0, 1, 0, 0]])
     with pytest.raises(ValueError, match="Wrong modulation format"):
         px.samp2pat(dict(rec="ook"), None, ph)
+
+
+def test_pat_decoder_host_logic_matches_reference_text():
+    """pat_decoder.m:66-79 / pat2stars.m / stars2pat.m: differential QPSK decoding, quaternary and binary routes."""
+    from polmux_amd import patterns, synth
+    pat, _ = synth.pattern_debruijn(64, 1, 4)
+    p, pm = patterns.pat_decoder(pat, "dqpsk")
+    st = patterns.pat2stars(pat, "dqpsk")
+    np.testing.assert_array_equal(st, np.array([1, 1j, -1j, -1])[pat])
+    d = np.conj(st) * np.roll(st, 1)                                  # conj(stars_t).*fastshift(stars_t,1)
+    q, qm = patterns.stars2pat(d, "dqpsk")
+    np.testing.assert_array_equal(p, 3 - q)
+    np.testing.assert_array_equal(pm, 1 - qm)
+    _, bm = patterns.stars2pat(st, "dqpsk")
+    p2, pm2 = patterns.pat_decoder(bm, "dqpsk", dict(binary=True))
+    np.testing.assert_array_equal(p2, p)
+    np.testing.assert_array_equal(pm2, pm)
+    # dpsk: stars +-1, conj(s).*fastshift(s,1) = [1,-1,1,-1] -> stars2pat [0,1,0,1] -> inverted
+    np.testing.assert_array_equal(patterns.pat_decoder(np.array([0, 1, 1, 0]), "dpsk"), [1, 0, 1, 0])
+    with pytest.raises(ValueError, match="wrong modulation format"):
+        patterns.pat_decoder(pat, "nope")
