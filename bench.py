@@ -282,7 +282,9 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_launch": SSFM_BYTES_PER_SAMPLE_STEP * F * n,
                          "traffic": traffic, "sample_steps_per_s": sample_steps / (fib * 1e-3),
-                         "launches": row_launches},
+                         "launches": row_launches, "ms_per_step_launch": fib / max(1, row_launches),
+                         "note": "one step-launch = the kernels of one SSFM step over the whole batch; 'launches' also counts "
+                                 "the few no-op launches of the chunked step loop after every frame has finished"},
         }
         if not a.no_cpu_baseline:
             (v, cdt, nc), allc = cpu_baseline(cfg, hp, a.cpu_frames, a.noise)
