@@ -1068,3 +1068,31 @@ def test_ex19_monte_carlo_script(lib):
     assert n1 >= 10 and n2 >= 10
     assert 1e-3 < b2 < b1 < 0.2                                        # ex19's published curve: ~4e-2 at 3 dB, ~4e-3 at 6 dB
     assert s1 / b1 < 0.5
+
+
+@pytest.mark.parametrize("nplates", [1, 20])
+def test_ex24_pmf_splits_the_field_by_half_a_symbol(lib, nplates):
+    """ex24_pmd.m:84-107 (SURVEY 8c vi): fiber(tx,'gp--') with tx.db0 = 0, tx.theta = tx.epsilon = pi/4, tx.dgd = 0.5 and no
+    GVD on an x-polarised field: the two principal states leave the PMF a quarter symbol late / early -- exact sample
+    shifts at Nt = 64 -- whether the PMF is one trunk (scalar theta, as in the script) or twenty equal ones."""
+    import polmux_amd as px
+    from polmux_amd import synth
+    from polmux_amd.gstate import GSTATE, to_host_field
+    from test_oracle_fiber import _pmf_expected
+    nsymb, nt = 64, 64
+    px.reset_all(nsymb, nt, 1)
+    GSTATE.SYMBOLRATE = 10.0
+    px.lasersource(1.0, 1550.0)
+    sx = synth.pdm_qpsk_field(nsymb, nt, 1.0)[0]
+    px.create_field("unique", sx.reshape(-1, 1), np.zeros((nsymb * nt, 1)))
+    tx = dict(length=1e5, alphadB=0.2, aeff=63.0, n2=2.7e-20, disp=0.0, slope=0.0, dphimax=5e-3, dzmax=2e4, dgd=0.5,
+              db0=np.zeros(nplates), theta=np.full(nplates, np.pi / 4), epsilon=np.full(nplates, np.pi / 4))
+    tx["lambda"] = 1550.0
+    brf = px.fiber(tx, "gp--")
+    assert brf["ncycle"] == 1 and brf["lcorr"] == 1e5 / nplates
+    want = _pmf_expected(sx, nt, 0.5, np.exp(-0.5 * np.log(10) * 1e-4 * 0.2 * 1e5))
+    np.testing.assert_allclose(to_host_field(GSTATE.FIELDX)[:, 0], want[0], atol=1e-12)
+    np.testing.assert_allclose(to_host_field(GSTATE.FIELDY)[:, 0], want[1], atol=1e-12)
+    g = px.ampliflat(20.0, "gain")                                       # ex24:91 restores the launch power
+    p = (GSTATE.FIELDX.abs() ** 2 + GSTATE.FIELDY.abs() ** 2).mean().item()
+    assert g == 100.0 and p == pytest.approx(np.mean(np.abs(sx) ** 2), rel=1e-12)

@@ -166,3 +166,41 @@ def test_adaptive_ssfm_converges_to_fine_constant_step(oracle):
     f2, nc2, uf = oracle.scalar_ssfm(u, betat, 50.0, 1e-5, gam, alpha, L, [1, 0, 1, 0])
     assert nc > 2 and nc2 > 100
     np.testing.assert_allclose(ua, uf, rtol=0, atol=2e-4 * np.abs(uf).max())
+
+
+def _pmf_expected(sx, nt, dgd, att):
+    """ex24_pmd.m:90-107: a PMF (every waveplate theta = epsilon = pi/4, db0 = 0) of total DGD `dgd` symbols splits an
+    x-polarised field into its two principal states, one delayed and one advanced by dgd/2 symbols (fiber.m:910-932
+    with all R equal: R D^n R^H)."""
+    th = ep = np.pi / 4
+    Rth = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]])
+    Rep = np.array([[np.cos(ep), 1j * np.sin(ep)], [1j * np.sin(ep), np.cos(ep)]])
+    R = Rth @ Rep
+    uu = R.conj().T @ np.stack([sx, np.zeros_like(sx)])
+    k = int(round(0.5 * dgd * nt))
+    uu = np.stack([np.roll(uu[0], k), np.roll(uu[1], -k)])
+    return (R @ uu) * att
+
+
+def test_pmf_splits_the_pulse_by_the_dgd():
+    """PMF with theta = epsilon = pi/4, dgd = 0.5 symbols -> two replicas 0.5 symbols apart, exactly
+    (the delays are whole samples at Nt = 64 and there is no GVD)."""
+    from oracle import plxo as oracle
+    from polmux_amd import synth
+    nsymb, nt, nplates, dgd, L, alphalin = 64, 64, 20, 0.5, 1e5, np.log(10) * 1e-4 * 0.2
+    sx = synth.pdm_qpsk_field(nsymb, nt, 1.0)[0]
+    fn = synth.fn_grid(nsymb, nt)
+    omega = 2 * np.pi * 10.0 * fn
+    betat = np.zeros((nsymb * nt, 1))
+    db1 = ((dgd / nplates) / 10.0 * omega).reshape(-1, 1)               # dgdrms/symbolrate*omega, fiber.m:269,284
+    z = np.zeros(nplates)
+    rc, fd, nc, ox, oy = oracle.matrix_ssfm(sx, np.zeros_like(sx), betat, db1, L, 5e-3, [0.0], alphalin, L, nplates, False,
+                                            [1, 1, 0, 0], z, z + np.pi / 4, z + np.pi / 4)
+    assert rc == 0 and nc == 1
+    want = _pmf_expected(sx, nt, dgd, np.exp(-0.5 * alphalin * L))
+    np.testing.assert_allclose(ox[:, 0], want[0], atol=1e-12)
+    np.testing.assert_allclose(oy[:, 0], want[1], atol=1e-12)
+    # and the two principal states carry half the power each: total power = half-and-half of the shifted copies
+    p = np.abs(ox[:, 0]) ** 2 + np.abs(oy[:, 0]) ** 2
+    k = int(0.25 * nt)
+    np.testing.assert_allclose(p, 0.5 * (np.roll(np.abs(sx) ** 2, k) + np.roll(np.abs(sx) ** 2, -k)) * np.exp(-alphalin * L), atol=1e-12)
