@@ -225,6 +225,14 @@ int64_t plx_front_out_len(const plx_front *plan);   /* ceil(nfft / decim) */
 int plx_front_run_dev(plx_front *plan, double *d_ux, double *d_uy, int nframes, const int64_t *shift,
                       double *d_out, void *stream);
 
+/* y = ifft(fft(x) .* H), in place, on [nsignals][nfft] complex128 rows sharing one frequency response H (fft
+ * order): the dispersion-compensating filter of RxPdmCohQpsk.m:74-84 / dsp4cohdec.m:163-173 (Hfilt built by
+ * DispCompFilter on the host) or any other fixed response.  nfft: power of two in [256, 2^20].             */
+typedef struct plx_filter plx_filter;
+int plx_filter_create(plx_filter **plan, int64_t nfft, int max_signals, const double *h_re, const double *h_im);
+int plx_filter_destroy(plx_filter *plan);
+int plx_filter_apply_dev(plx_filter *plan, double *d_x, int nsignals, void *stream);
+
 /* ------------------------------------------------------------------ inverse PMD --- */
 /* inverse_pmd(brf, options)  inverse_pmd.m:91-145: the per-frequency PMD matrix U of a link of `nfibers` fibres
  * (brf{n} as returned by fiber), Uinv = U^H, and its application to a unique dual-polarisation field.

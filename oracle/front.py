@@ -102,3 +102,23 @@ def rx_front(irxt, isy, adcbits, shifts, r, b):
     if dec.shape[1] == 4:
         cols.append(dec[:, 2] + 1j * dec[:, 3])                      # :69 (COS_POL2=3, SIN_POL2=4)
     return np.stack(cols, 1)
+
+
+def disp_comp_filter(beta2l, B, N, filter_length):
+    """RxPdmCohQpsk.m:90-98 DispCompFilter, statement by statement."""
+    freq = -B / 2 + B / N * np.arange(N)
+    freq = np.fft.ifftshift(freq)
+    delay = 2 * np.pi * freq / B * (filter_length / 2)
+    argum = (2 * np.pi * freq) ** 2 * beta2l / 2 - delay
+    H = np.cos(argum) + 1j * np.sin(argum)
+    b = np.fft.ifft(H)
+    b = b[: int(filter_length) + 1]
+    return np.fft.fft(b, N) * (np.cos(delay) + 1j * np.sin(delay))
+
+
+def apply_dcf(rx, dispersion, lam, baudrate, ndispsym, workatbaudrate, clight=299792458.0):
+    """RxPdmCohQpsk.m:74-84"""
+    beta2l = -dispersion * lam ** 2 / 2 / np.pi / clight * 1e-21
+    sps = 1 + (0 if workatbaudrate else 1)
+    H = disp_comp_filter(beta2l, sps * baudrate, rx.shape[0], ndispsym * sps)
+    return np.fft.ifft(np.fft.fft(rx, axis=0) * H[:, None], axis=0)

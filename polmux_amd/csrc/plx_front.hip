@@ -249,3 +249,53 @@ extern "C" int plx_front_run_dev(plx_front *P, double *d_ux, double *d_uy, int n
     PLX_HIP(hipGetLastError());
     return PLX_OK;
 }
+
+// ---------------------------------------------------------------- generic spectral filter ---
+// y = ifft(fft(x) .* H) on [nsig][nfft] complex128 signals (every row filtered by the same H): the DSP-side
+// dispersion-compensating FIR of RxPdmCohQpsk.m:74-84 / dsp4cohdec.m:163-173 (H from DispCompFilter, host) and any
+// other fixed frequency response a caller wants applied on the device.
+struct plx_filter {
+    plx_ssfm *fft = nullptr;
+    cplx *d_h = nullptr;
+    int max_sig = 0;
+};
+
+extern "C" int plx_filter_create(plx_filter **out, int64_t nfft, int max_signals, const double *h_re, const double *h_im)
+{
+    if (!out || !h_re) PLX_FAIL(PLX_ERR_ARG, "plx_filter_create: null argument");
+    *out = nullptr;
+    if (max_signals < 1) PLX_FAIL(PLX_ERR_ARG, "plx_filter_create: max_signals must be >= 1");
+    plx_filter *P = new plx_filter();
+    P->max_sig = max_signals;
+    std::vector<double> zeros((size_t)(nfft > 0 ? nfft : 1), 0.0);
+    double gam0 = 0.0;
+    plx_ssfm_desc sd;
+    std::memset(&sd, 0, sizeof(sd));
+    sd.nfft = nfft; sd.nfc = 1; sd.dual_pol = 0; sd.max_frames = max_signals;
+    sd.dzmaxt = 1; sd.dphimaxt = 1; sd.length = 1; sd.nplates = 1; sd.gam = &gam0; sd.betat = zeros.data();
+    int rc = plx_ssfm_create(&P->fft, &sd);
+    if (rc == PLX_OK) rc = plx_ssfm_filter_table(P->fft, h_re, h_im, &P->d_h);
+    if (rc != PLX_OK) {
+        if (P->fft) plx_ssfm_destroy(P->fft);
+        delete P;
+        return rc;
+    }
+    *out = P;
+    return PLX_OK;
+}
+
+extern "C" int plx_filter_destroy(plx_filter *P)
+{
+    if (!P) return PLX_OK;
+    if (P->fft) plx_ssfm_destroy(P->fft);
+    if (P->d_h) (void)hipFree(P->d_h);
+    delete P;
+    return PLX_OK;
+}
+
+extern "C" int plx_filter_apply_dev(plx_filter *P, double *d_x, int nsignals, void *stream)
+{
+    if (!P || !d_x) PLX_FAIL(PLX_ERR_ARG, "plx_filter_apply_dev: null argument");
+    if (nsignals < 1 || nsignals > P->max_sig) PLX_FAIL(PLX_ERR_ARG, "plx_filter_apply_dev: nsignals outside [1, max_signals]");
+    return plx_ssfm_filter_dev(P->fft, (cplx *)d_x, nullptr, P->d_h, nsignals, stream);
+}

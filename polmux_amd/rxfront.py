@@ -293,6 +293,39 @@ def rx_plan(chNum, RxParams, isy, max_frames=1, rng=None):
     return fr, shifts, dict(post_delay=post_delay, delay=delay, decim=r, fir=fir, hopt=hopt, elo=elo, hel=hel, b2b=b2b)
 
 
+def DispCompFilter(Beta2L, B, N, FilterLength):
+    """Hfilt = DispCompFilter(Beta2L, B, N, FilterLength)  RxPdmCohQpsk.m:90-98: frequency response of a
+    FilterLength+1-tap FIR approximating the inverse of the accumulated dispersion (host table)."""
+    k = np.arange(N)
+    freq = -B / 2 + B / N * k                                        # (-B/2 : B/N : B/2*(N-2)/N)
+    freq = np.fft.ifftshift(freq)
+    delay = 2 * math.pi * freq / B * (FilterLength / 2)
+    argum = (2 * math.pi * freq) ** 2 * Beta2L / 2 - delay
+    H = np.cos(argum) + 1j * np.sin(argum)                           # fastexp
+    b = np.fft.ifft(H)[: int(FilterLength) + 1]
+    return np.fft.fft(b, N) * (np.cos(delay) + 1j * np.sin(delay))
+
+
+def _apply_dcf(samples, p):
+    """RxSamples = ifft(fft(RxSamples).*Hfilt) column-wise (RxPdmCohQpsk.m:74-84): samples torch [L, ncol] -> same."""
+    import torch
+    L, ncol = samples.shape
+    Beta2L = -p["dispersion"] * p["lambda"] ** 2 / 2 / math.pi / CONSTANTS.CLIGHT * 1e-21
+    sps = 1 + (0 if p.get("workatbaudrate") else 1)
+    H = DispCompFilter(Beta2L, sps * p["baudrate"], L, p["ndispsym"] * sps)
+    lib = _abi.get()
+    hr, hi = np.ascontiguousarray(H.real), np.ascontiguousarray(H.imag)
+    plan = C.c_void_p()
+    lib.call("plx_filter_create", C.byref(plan), L, ncol, hr.ctypes.data, hi.ctypes.data)
+    try:
+        rows = samples.transpose(0, 1).contiguous()                  # [ncol, L]
+        lib.call("plx_filter_apply_dev", plan, rows.data_ptr(), ncol, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.current_stream().synchronize()
+    finally:
+        lib.call("plx_filter_destroy", plan)
+    return rows.transpose(0, 1).contiguous()
+
+
 def _mround(v):
     """MATLAB round (half away from zero)."""
     return math.floor(abs(v) + 0.5) * (1 if v >= 0 else -1)
@@ -301,10 +334,8 @@ def _mround(v):
 def RxPdmCohQpsk(chNum, symbolPattern, RxParams, rng=None):
     """[RxSamples, worsteyeop] = RxPdmCohQpsk(chNum, symbolPattern, RxParams)  RxPdmCohQpsk.m:3-87.
     RxSamples: torch complex128 [nout, 1 or 2] on the GPU.  worsteyeop (the eye-opening diagnostic of
-    mygeteyeinfo, :139-166) is not evaluated on the device path and is returned as NaN; RxParams.applydcf
-    (DispCompFilter, :74-84) is served by CDE_OFDE in this chain and raises if requested."""
-    if RxParams.get("applydcf"):
-        raise NotImplementedError("RxParams.applydcf (DispCompFilter) is not part of the accelerated path; use CDE_OFDE")
+    mygeteyeinfo, :139-166) is not evaluated on the device path and is returned as NaN.  RxParams.applydcf runs the
+    DispCompFilter response (:74-98) through the device FFT engine (sample counts that are powers of two >= 256)."""
     sp = np.asarray(symbolPattern)
     isy = GSTATE.FIELDY is not None and sp.ndim == 2 and sp.shape[1] != 1      # :27-33
     fr, shifts, info = rx_plan(chNum, RxParams, isy, 1, rng)
@@ -313,7 +344,10 @@ def RxPdmCohQpsk(chNum, symbolPattern, RxParams, rng=None):
         out = fr.run(ux, uy if fr.dual else None, shifts)
     finally:
         fr.close()
-    return out[0].transpose(0, 1).contiguous(), float("nan")
+    samples = out[0].transpose(0, 1).contiguous()
+    if RxParams.get("applydcf"):
+        samples = _apply_dcf(samples, RxParams)                       # :74-84
+    return samples, float("nan")
 
 
 def dsp4cohdec(ich, pat, x, p, rng=None):
@@ -323,11 +357,8 @@ def dsp4cohdec(ich, pat, x, p, rng=None):
     float64 [Nsymb, 1 or 2] on the GPU; worsteyeop is NaN (eye diagnostics are not evaluated on the device path)."""
     import torch
     from .rx import DspPdmCohQpsk
-    if p.get("applydcf"):
-        raise NotImplementedError("p.applydcf (DispCompFilter, dsp4cohdec.m:163-173) is not part of the accelerated path; "
-                                  "use CDE_OFDE between the front end and the DSP")
     rxp = dict(x)
-    for k in ("sps", "workatbaudrate", "applyadc", "adcbits"):
+    for k in ("sps", "workatbaudrate", "applyadc", "adcbits", "applydcf", "dispersion", "ndispsym", "baudrate", "lambda"):
         if k in p:
             rxp[k] = p[k]
     samples, eye = RxPdmCohQpsk(ich, pat, rxp, rng)                    # dsp4cohdec.m:108-160 = RxPdmCohQpsk.m:18-72

@@ -1010,8 +1010,6 @@ def test_dsp4cohdec_ex19_single_pol_vs_oracle(lib, oracle):
     np.testing.assert_allclose(got, ref, atol=1e-7)
     pat_hat = px.samp2pat(x, None, phase.cpu().numpy())
     np.testing.assert_array_equal(pat_hat, oracle.samp2pat_coherent(np.angle(ref)))
-    with pytest.raises(NotImplementedError, match="applydcf"):
-        px.dsp4cohdec(1, pat, x, dict(p, applydcf=True))
 
 
 def test_unique_wdm_field_create_and_receive(lib, oracle):
@@ -1096,3 +1094,34 @@ def test_ex24_pmf_splits_the_field_by_half_a_symbol(lib, nplates):
     g = px.ampliflat(20.0, "gain")                                       # ex24:91 restores the launch power
     p = (GSTATE.FIELDX.abs() ** 2 + GSTATE.FIELDY.abs() ** 2).mean().item()
     assert g == 100.0 and p == pytest.approx(np.mean(np.abs(sx) ** 2), rel=1e-12)
+
+
+def test_rx_dispersion_compensating_filter_applydcf(lib):
+    """RxParams.applydcf: DispCompFilter (RxPdmCohQpsk.m:90-98) built on the host, applied by the device FFT engine
+    (plx_filter_*): equals the oracle's fft/ifft form on the same RxSamples; dsp4cohdec takes the same branch."""
+    import polmux_amd as px
+    from oracle import front
+    from polmux_amd import rxfront, synth
+    from polmux_amd.gstate import GSTATE
+    nsymb, nt = 1024, 16
+    px.reset_all(nsymb, nt, 1)
+    GSTATE.SYMBOLRATE = 10.0
+    px.lasersource(1.0, 1550.0)
+    sx, sy, _, _ = synth.pdm_qpsk_field(nsymb, nt, 1.0)
+    px.create_field("sepfields", sx, sy)
+    rp = _rx_params(nt, applyadc=False, baudrate=10e9, samplingrate=20.0, dispersion=1700.0, ndispsym=16)
+    plain, _ = px.RxPdmCohQpsk(1, np.zeros((nsymb, 2)), rp)
+    got, _ = px.RxPdmCohQpsk(1, np.zeros((nsymb, 2)), dict(rp, applydcf=True))
+    want = front.apply_dcf(plain.cpu().numpy(), 1700.0, 1550.0, 10e9, 16, False)
+    assert np.abs(want - plain.cpu().numpy()).max() > 0.1 * np.abs(want).max()      # the filter does something
+    assert np.abs(got.cpu().numpy() - want).max() <= 1e-12 * np.abs(want).max()
+    H = rxfront.DispCompFilter(-1700.0 * 1550.0 ** 2 / 2 / np.pi / 299792458.0 * 1e-21, 2 * 10e9, 2 * nsymb, 32)
+    np.testing.assert_allclose(H, front.disp_comp_filter(-1700.0 * 1550.0 ** 2 / 2 / np.pi / 299792458.0 * 1e-21, 2 * 10e9, 2 * nsymb, 32),
+                               atol=1e-14)
+    p = dict(sps=nt, workatbaudrate=False, applyadc=False, adcbits=5, applydcf=True, dispersion=1700.0, ndispsym=16, baudrate=10e9,
+             applynlr=False, applypol=False, modorder=2, freqavg=0, phasavg=3, poworder=2)
+    p["lambda"] = 1550.0
+    x = {k: rp[k] for k in ("rec", "ts", "oftype", "obw", "oord", "eftype", "ebw", "eord", "delay", "lopower")}
+    ph1, am1, _ = px.dsp4cohdec(1, np.zeros((nsymb, 2)), x, p)
+    sig = px.DspPdmCohQpsk(got.transpose(0, 1), p, 1)
+    np.testing.assert_allclose(am1.cpu().numpy(), sig.abs().cpu().numpy().T, atol=1e-12)
