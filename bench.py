@@ -17,6 +17,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -47,6 +48,8 @@ def parse():
     ap.add_argument("--mc", action="store_true",
                     help="BASELINE config[3] style step: fiber('gps-') with a fresh random-birefringence draw per frame "
                          "and per step (Monte-Carlo PMD realisations), receiver noise as ASE stand-in")
+    ap.add_argument("--spans", type=int, default=1, help="spans per step, with in-line amplifiers between them (config[4]: 40)")
+    ap.add_argument("--nf", type=float, default=None, help="noise figure [dB] of the in-line amplifiers (default: noiseless)")
     ap.add_argument("--no-overlap", action="store_true", help="run the receiver on the fibre stream (no stream overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the batch the one-core CPU baseline processes (~0.5 s each)")
@@ -110,7 +113,10 @@ def cpu_params(cfg, hp, noise):
              gam=gam, alphalin=hp.alphalin, length=cfg.length, fls=list(hp.fls), nt=cfg.nt, rx_scale=hp.rx_scale, noise=noise,
              symbolrate=cfg.symbolrate, lam=cfg.lam, disp=cfg.disp, slope=cfg.slope, fft_length=cfg.fft_length, cde_L=cfg.cde_L,
              power_mw=hp.power_mw, cma_mu=cfg.cma_mu, cma_taps=cfg.cma_taps, freqavg=cfg.freqavg, phasavg=cfg.phasavg,
-             poworder=cfg.poworder, adcbits=cfg.adcbits, front=None)
+             poworder=cfg.poworder, adcbits=cfg.adcbits, front=None, nspans=cfg.nspans, span_sigma=None)
+    if cfg.span_nf_db is not None and cfg.nspans > 1:
+        from polmux_amd.ampliflat import ase_sigma
+        p["span_sigma"] = float(ase_sigma(cfg.span_nf_db, math.exp(hp.alphalin * cfg.length), 1)[0])
     if hp.front is not None:
         p["front"] = hp.front_tables
         p["front_shifts"] = hp.front_shifts
@@ -154,7 +160,8 @@ def main():
 
     if a.mc:
         a.flag = "gps-"
-    cfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag=a.flag, frontend=a.frontend)
+    cfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag=a.flag, frontend=a.frontend, nspans=a.spans,
+                                 span_nf_db=a.nf)
     F = a.frames
     hp = pipeline.HotPath(cfg, max_frames=F)
     n = cfg.nfft
@@ -268,8 +275,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Run_my_PDM_QPSK-style (BASELINE config[1]): 28 Gbaud PDM-QPSK, 2^%d-sample "
-                                   "dual-pol frame, 1x80 km SSMF span fiber('%s'), CDE_OFDE 256/128, CMA 7 taps + "
-                                   "V&V carrier recovery; front end: %s" % (int(np.log2(n)), a.flag, a.frontend),
+                                   "dual-pol frame, %dx80 km SSMF span fiber('%s'), CDE_OFDE 256/128, CMA 7 taps + "
+                                   "V&V carrier recovery; front end: %s" % (int(np.log2(n)), a.spans, a.flag, a.frontend),
                        "frames_per_gpu_per_step": F, "nsymb": a.nsymb, "nt": a.nt, "pavg_mw": a.pavg,
                        "ssfm_steps_per_frame": sample_steps / (a.steps * F * n), "rx_noise_sigma": a.noise,
                        "fibre_ms_per_step": fib / a.steps, "rxdsp_ms_per_step": rxm / a.steps,

@@ -16,8 +16,19 @@ def run_frames(p, nframes, seed):
     nc = 0
     t0 = time.perf_counter()
     for _ in range(nframes):
-        rc, fd, nc, ox, oy = plxo.matrix_ssfm(p["tx_x"], p["tx_y"], p["betat"], p["db1"], p["dzmax"], p["dphimax"], p["gam"],
-                                              p["alphalin"], p["length"], 1, 0, p["fls"], [0.0], [0.0], [0.0])
+        nc = 0
+        ox, oy = p["tx_x"], p["tx_y"]
+        nspans = int(p.get("nspans", 1))
+        for span in range(nspans):
+            rc, fd, k, ox, oy = plxo.matrix_ssfm(ox, oy, p["betat"], p["db1"], p["dzmax"], p["dphimax"], p["gam"],
+                                                 p["alphalin"], p["length"], 1, 0, p["fls"], [0.0], [0.0], [0.0])
+            nc += k
+            if span + 1 < nspans:                                      # in-line amplifier, ampliflat.m:123-143
+                g = np.exp(p["alphalin"] * p["length"])
+                ox, oy = np.sqrt(g) * ox, np.sqrt(g) * oy
+                if p.get("span_sigma"):
+                    ox = ox + p["span_sigma"] * (r.standard_normal(ox.shape) + 1j * r.standard_normal(ox.shape))
+                    oy = oy + p["span_sigma"] * (r.standard_normal(oy.shape) + 1j * r.standard_normal(oy.shape))
         if p.get("front") is not None:
             from oracle import front
             t = p["front"]
@@ -28,7 +39,7 @@ def run_frames(p, nframes, seed):
             rx = np.stack([ox[::half, 0], oy[::half, 0]], 1) * p["rx_scale"]
         if p["noise"]:
             rx = rx + p["noise"] * (r.standard_normal(rx.shape) + 1j * r.standard_normal(rx.shape))
-        ex, ey, _ = plxo.cde_ofde(rx[:, 0], rx[:, 1], 2 * p["symbolrate"] * 1e9, p["lam"] * 1e-9, p["length"], p["disp"] * 1e-6,
+        ex, ey, _ = plxo.cde_ofde(rx[:, 0], rx[:, 1], 2 * p["symbolrate"] * 1e9, p["lam"] * 1e-9, p["length"] * int(p.get("nspans", 1)), p["disp"] * 1e-6,
                                   p["slope"] * 1e-6, p["fft_length"], p["cde_L"])
         op = plxo.dsp_params(power_mw=p["power_mw"], applypol=True, polmethod="cma", cma_mu=p["cma_mu"], cma_taps=p["cma_taps"],
                              freqavg=p["freqavg"], phasavg=p["phasavg"], poworder=p["poworder"])

@@ -37,9 +37,12 @@ class HotPathConfig:
                  dgd=0.1, nplates=100, manakov="no", nspans=1, fft_length=256, cde_L=128, applypol=True,
                  polmethod="cma", cma_taps=7, cma_mu=1 / 6000, freqavg=500, phasavg=3, poworder=2,
                  frontend="pick", oftype="gauss", obw=1.9, oord=3, eftype="bessel5", ebw=0.65, eord=4, lopower=0.0,
-                 adcbits=5):
+                 adcbits=5, span_nf_db=None):
         """frontend: 'pick' = 2-sps sampling supplied by the harness; 'cohmix' = the reference's own
-        receiver_cohmix + ADC + decimate chain (RxPdmCohQpsk.m, Run_my_PDM_QPSK.m:52-73 defaults) on the device."""
+        receiver_cohmix + ADC + decimate chain (RxPdmCohQpsk.m, Run_my_PDM_QPSK.m:52-73 defaults) on the device.
+        nspans > 1: every span but the last is followed by an in-line flat amplifier restoring its loss
+        (ampliflat(G,'gain'), noiseless or with noise figure span_nf_db and ASE keyed per frame); the last span's loss is
+        undone in the receiver scale, as for one span."""
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -110,7 +113,7 @@ class HotPath:
         self.lib.call("plx_dsp_create", C.byref(self.dsp), self.Lrx, 2, self.F, C.byref(self.dsp_p))
         # receive scale: undo the span loss and bring symbols to the 4*sqrt(P) full scale that
         # DspPdmCohQpsk divides by (DspPdmCohQpsk.m:22-23, "2* -> see receiver_cohmix")
-        self.rx_scale = 4.0 * math.sqrt(power) / math.sqrt(power / 2.0) * math.exp(0.5 * self.alphalin * cfg.length * cfg.nspans)
+        self.rx_scale = 4.0 * math.sqrt(power) / math.sqrt(power / 2.0) * math.exp(0.5 * self.alphalin * cfg.length)
         self.front = None
         if cfg.frontend == "cohmix":
             from . import rxfront
@@ -118,7 +121,7 @@ class HotPath:
                       lopower=cfg.lopower)
             hopt, elo, hel, post_delay, _ = rxfront._front_tables(1, rp, nfc=1)
             # in-line amplifier restoring the span loss, folded into the optical filter table (no extra sweep)
-            hopt = hopt * math.exp(0.5 * self.alphalin * cfg.length * cfg.nspans)
+            hopt = hopt * math.exp(0.5 * self.alphalin * cfg.length)
             r = cfg.nt // 2                                                    # RxPdmCohQpsk.m:49-53, 2 samples/symbol
             delay = rxfront.evaldelay(cfg.oftype, cfg.obw * 0.5) + rxfront.evaldelay(cfg.eftype, cfg.ebw) + post_delay
             self.front_shifts = [rxfront._mround(-delay * cfg.nt)] * 2         # 'theory' delay, RxPdmCohQpsk.m:124-137
@@ -176,12 +179,13 @@ class HotPath:
     def stream(self):
         return self.torch.cuda.current_stream().cuda_stream
 
-    def fibre(self, ux, uy):
+    def fibre(self, ux, uy, span_keys=None):
         """ux, uy: [F, n] complex128 device tensors ([frame][channel=1][nfft]), propagated in place."""
         F = ux.shape[0]
         g = self.group or F
         self._rows = self._steps = 0
-        for _ in range(self.cfg.nspans):
+        cfg = self.cfg
+        for span in range(cfg.nspans):
             # frames are independent: propagating them in groups whose fields fit the 256 MiB Infinity
             # Cache keeps the three sweeps of every step on-die instead of streaming HBM
             for f0 in range(0, F, g):
@@ -192,6 +196,18 @@ class HotPath:
                 self.lib.call("plx_ssfm_stats", self.ssfm, C.byref(rows), C.byref(steps))
                 self._rows += rows.value
                 self._steps += steps.value
+            if span + 1 < cfg.nspans:              # in-line amplifier (ampliflat.m), stays on the device
+                gain = math.exp(self.alphalin * cfg.length)
+                sig = None
+                if cfg.span_nf_db is not None:
+                    from .ampliflat import ase_sigma
+                    sig = np.ascontiguousarray(ase_sigma(cfg.span_nf_db, gain, 1), dtype=float)
+                kt = None
+                if span_keys is not None:
+                    kt = self.torch.as_tensor(np.asarray(list(span_keys), dtype=np.int64), device=self.dev)
+                self.lib.call("plx_ampliflat_dev", ux.data_ptr(), uy.data_ptr(), cfg.nfft, 1, F, gain,
+                              sig.ctypes.data if sig is not None else None, None, (20260101 + 7919 * span) & (2 ** 64 - 1),
+                              kt.data_ptr() if kt is not None else None, 1, 1, self.stream())
 
     def receive(self, ux, uy, noise_sigma=0.0, noise_seed=None, side_stream=None, noise_keys=None):
         """Front end (2-sps pick, or receiver_cohmix + ADC + decimate), CDE, DSP, decisions.  Returns err [F,2] (device).

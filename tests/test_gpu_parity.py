@@ -1125,3 +1125,38 @@ def test_rx_dispersion_compensating_filter_applydcf(lib):
     ph1, am1, _ = px.dsp4cohdec(1, np.zeros((nsymb, 2)), x, p)
     sig = px.DspPdmCohQpsk(got.transpose(0, 1), p, 1)
     np.testing.assert_allclose(am1.cpu().numpy(), sig.abs().cpu().numpy().T, atol=1e-12)
+
+
+def test_hot_path_multi_span_with_inline_amplifiers(lib, oracle):
+    """HotPath with nspans = 3 (BASELINE config[4] is this chain, 40 spans long): fibre, noiseless in-line amplifier,
+    fibre, ... against the oracle loop; then ASE-loaded amplifiers keyed per frame give batch-independent noise."""
+    import torch
+    from polmux_amd import pipeline
+    cfg = pipeline.HotPathConfig(nsymb=256, nt=32, nspans=3, pavg_mw=1.0)
+    hp = pipeline.HotPath(cfg, max_frames=3)
+    ux, uy = hp.make_batch(3)
+    hp.fibre(ux, uy)
+    _sync()
+    gam, betat, db1 = hp._keep
+    hx, hy = hp.tx_host
+    tot = 0
+    for s in range(3):
+        rc, fd, nc, hx, hy = oracle.matrix_ssfm(hx, hy, betat, db1, cfg.dzmax, cfg.dphimax, gam, hp.alphalin, cfg.length, 1, 0, hp.fls,
+                                                [0.0], [0.0], [0.0])
+        hx, hy = hx[:, 0], hy[:, 0]
+        tot += nc
+        if s < 2:
+            g = math.exp(hp.alphalin * cfg.length)
+            hx, hy = math.sqrt(g) * hx, math.sqrt(g) * hy
+    assert hp.ssfm_stats()[1] == 3 * tot * cfg.nfft
+    assert np.abs(ux[2].cpu().numpy() - hx).max() <= FIELD_RTOL * np.abs(hx).max()
+    assert np.abs(uy[0].cpu().numpy() - hy).max() <= FIELD_RTOL * np.abs(hy).max()
+    hp.close()
+    cfg = pipeline.HotPathConfig(nsymb=256, nt=32, nspans=2, pavg_mw=1.0, span_nf_db=5.0)
+    hp = pipeline.HotPath(cfg, max_frames=4)
+    a = hp.make_batch(4); hp.fibre(*a, span_keys=[10, 11, 12, 13])
+    b = hp.make_batch(2); hp.fibre(*b, span_keys=[12, 10])
+    _sync()
+    assert torch.equal(a[0][2], b[0][0]) and torch.equal(a[1][0], b[1][1])           # noise keyed by realisation, not position
+    assert float((a[0][0] - a[0][1]).abs().max()) > 1e-3
+    hp.close()
