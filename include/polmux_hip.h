@@ -86,7 +86,13 @@ int plx_ssfm_set_birefringence_dev(plx_ssfm *plan, const double *db0, const doub
                                    const double *epsilon, int nsets, void *stream);
 /* Propagate nframes frames in place.  d_ux/d_uy: device, interleaved complex128,
  * layout [frame][channel][nfft]; d_uy NULL for a scalar plan.  Asynchronous on
- * `stream` except for the bounded polling of the data-dependent step loop.         */
+ * `stream` except for the bounded polling of the data-dependent step loop: the call
+ * returns when every frame has reached the fibre end.  Dual-polarisation plans with
+ * 256-row column tiles use a fused sweep whose workgroups of one frame meet at a
+ * barrier and must be co-resident: do not overlap two propagate calls (two host
+ * threads, two plans) on one device -- batch the frames into one call instead; a
+ * barrier that cannot complete is reported as PLX_ERR_HIP, and PLX_SSFM_NO_FUSE=1
+ * selects the barrier-free sweeps.                                                  */
 int plx_ssfm_propagate_dev(plx_ssfm *plan, double *d_ux, double *d_uy, int nframes, void *stream);
 /* per-frame results of the last propagate: firstdz, ncycle (fiber.m:431)           */
 int plx_ssfm_results(plx_ssfm *plan, int nframes, double *firstdz, int32_t *ncycle);

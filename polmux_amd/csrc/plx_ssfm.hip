@@ -1397,6 +1397,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     if (a.dual && N2 >= 2048 && !getenv("PLX_SSFM_NO_ROW_SPLIT")) {   // measured: 2^20 frames 74 -> 66 ms; at N2 = 1024 it loses (47 -> 52)
         P->row_split = 1;
         P->rs_threads = N2 / 8 < ROW_THREADS ? ROW_THREADS : (N2 / 8 > 1024 ? 1024 : N2 / 8);
+        if (const char *e = getenv("PLX_SSFM_RS_THREADS")) { int v = atoi(e); if (v >= 64 && v <= 1024 && (v & (v - 1)) == 0) P->rs_threads = v; }
         P->rs_lds = ((size_t)(N2 + N2 / 16) + N2 / 2) * sizeof(cplx);
     }
     a.spm = desc->fls[2]; a.xpm = desc->fls[3]; a.manakov = desc->manakov ? 1 : 0; a.pmd = desc->fls[1] ? 1 : 0;

@@ -6,6 +6,7 @@ from polmux_amd import pipeline
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 cfg = pipeline.HotPathConfig()
+os.environ.setdefault("PLX_SSFM_NO_FUSE", "1")   # concurrent propagate calls: the fused sweep assumes it owns the chip
 def run(nstreams):
     hps = [pipeline.HotPath(cfg, F // nstreams) for _ in range(nstreams)]
     streams = [torch.cuda.Stream() for _ in range(nstreams)]
