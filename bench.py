@@ -255,6 +255,19 @@ def main():
     fib = sum(ev.elapsed_ms(x, y) for x, y in fib_ms)
     rxm = sum(ev.elapsed_ms(x, y) for x, y in rx_ms)
 
+    # SURVEY 8d's M1 read literally -- ONE frame through fibre + receiver, nothing else on the GPU (outside the timed region)
+    single = None
+    if rank == 0 and not a.mc:
+        sx, sy = hp.make_batch(1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        hp.fibre(sx, sy)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        hp.receive(sx, sy, noise_sigma=a.noise, noise_seed=4242)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        single = {"fibre_ms": (t2 - t1) * 1e3, "rx_ms": (t3 - t2) * 1e3, "gsample_per_s": n / (t3 - t1) / 1e9}
     if rank == 0:
         samples = float(world) * a.steps * F * n
         value = samples / dt / 1e9
@@ -283,7 +296,8 @@ def main():
                        "mc_realisations_per_s": float(world) * a.steps * F / dt, "fresh_pmd_per_realisation": bool(a.mc),
                        "bit_errors_xy": err_total.cpu().tolist(),
                        "bit_errors_resolved": int(res_total.item()) if a.mc else None,
-                       "bits": int(world) * a.steps * F * 4 * a.nsymb, "restaged_batches": restaged},
+                       "bits": int(world) * a.steps * F * 4 * a.nsymb, "restaged_batches": restaged,
+                       "single_frame": single},
             "roofline": {"bound": "hbm", "kernel": "SSFM step (k_colx16 [inverse + forward column pass, fused] + k_row)"
                          if not os.environ.get("PLX_SSFM_NO_FUSE") and a.nsymb * a.nt == 65536 else "SSFM step (k_col_fwd + k_row + k_col_inv)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
