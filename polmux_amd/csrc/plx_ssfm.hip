@@ -420,6 +420,36 @@ __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_fwd(SsfmArgs a)
     }
 }
 
+// The waveplate loop of matrix_step (fiber.m:907-933) at one frequency.  Per trunk the reference applies
+//   u <- R diag(e^{-i(a+b)}, e^{-i(a-b)}) R^H u,   a = betat*dzb(k),  b = (db1 + db0(n))/2 * dzb(k)/lcorr.
+// With diag(e^{-ib}, e^{ib}) = cos b I - i sin b sigma3 this is  e^{-ia} (cos b u - i sin b S u),  S = R sigma3 R^H
+// (Hermitian, traceless, frequency independent: S11 real, S12 complex -- formed on the host per waveplate), and the
+// scalar factors e^{-ia} of all trunks multiply to e^{-i betat * dz}: one exponential per trunk instead of two, 20
+// multiply-adds instead of 40.  BRF_STRIDE doubles per plate: S11, Re S12, Im S12, db0 (turns).
+#define BRF_STRIDE 4
+__device__ __forceinline__ void pmd_trunks(cplx &x, cplx &y, double btf, double d1f, const double *brf, int nplates, int n0, int ntrunk,
+                                           double dzb_first, double dzb_last, double lcorr, double dz_total)
+{
+    for (int k = 1; k <= ntrunk; k++) {
+        int plate = n0 + k - 1; // the reference indexes brf.theta(n) unchecked; stay in bounds
+        plate = plate < 0 ? 0 : (plate >= nplates ? nplates - 1 : plate);
+        const double *m = brf + (size_t)plate * BRF_STRIDE;
+        const double s11 = m[0];
+        const cplx s12 = make_double2(m[1], m[2]);
+        const double dzk = (k == 1) ? dzb_first : (k == ntrunk ? dzb_last : lcorr);
+        const double deltabeta = 0.5 * (d1f + m[3]) * dzk / lcorr;              // :925 (turns)
+        const cplx e = cexp_neg_turns(deltabeta);                               // (cos b, -sin b)
+        const cplx sx = cadd(cscale(x, s11), cmul(s12, y));                     // S u
+        const cplx sy = csub(cmulc(x, s12), cscale(y, s11));
+        // cos b u - i sin b S u, with e.y = -sin b:  -i sin b (p + i q) = e.y (-q) ... written out per component
+        x = make_double2(e.x * x.x - e.y * sx.y, e.x * x.y + e.y * sx.x);
+        y = make_double2(e.x * y.x - e.y * sy.y, e.x * y.y + e.y * sy.x);
+    }
+    const cplx h = cexp_neg_turns(btf * dz_total);                              // prod_k e^{-i betat dzb(k)}, :924,:927-928
+    x = cmul(h, x);
+    y = cmul(h, y);
+}
+
 // --------------------------------------------------------------- pass 2: rows ---
 // Second half of the forward transform, the linear operator of the step
 // (lin_step :771-773 / matrix_step :907-933) and the first half of the inverse
@@ -491,29 +521,13 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         }
     } else {
         const double *d1 = a.db1_p + (size_t)c * N + rowbase;
-        const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * 9 : 0);
+        const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * BRF_STRIDE : 0);
         const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem; // plate of piece k: n0+k (1-based) :908
         const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last, lcorr = a.lcorr;
         for (int e = tid; e < nel; e += nthr) {
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-            const double btf = bt[e], d1f = d1[e];
             cplx x = s[o], y = s[o + R * TSp];
-            for (int k = 1; k <= ntrunk; k++) {
-                int plate = n0 + k - 1; // the reference indexes brf.theta(n) unchecked; stay in bounds
-                plate = plate < 0 ? 0 : (plate >= a.nplates ? a.nplates - 1 : plate);
-                const double *m = brf + (size_t)plate * 9;
-                const cplx R11 = make_double2(m[0], m[1]), R12 = make_double2(m[2], m[3]);
-                const cplx R21 = make_double2(m[4], m[5]), R22 = make_double2(m[6], m[7]);
-                const double dzk = (k == 1) ? dzb_first : (k == ntrunk ? dzb_last : lcorr);
-                cplx uux = cadd(cmulc(x, R11), cmulc(y, R21));                 // :920
-                cplx uuy = cadd(cmulc(x, R12), cmulc(y, R22));                 // :921
-                const double combeta = btf * dzk;                              // :924
-                const double deltabeta = 0.5 * (d1f + m[8]) * dzk / lcorr;     // :925
-                uux = cmul(cexp_neg_turns(combeta + deltabeta), uux);          // :927 (phases in turns)
-                uuy = cmul(cexp_neg_turns(combeta - deltabeta), uuy);          // :928
-                x = cadd(cmul(R11, uux), cmul(R12, uuy));                      // :931
-                y = cadd(cmul(R21, uux), cmul(R22, uuy));                      // :932
-            }
+            pmd_trunks(x, y, bt[e], d1[e], brf, a.nplates, n0, ntrunk, dzb_first, dzb_last, lcorr, cur);
             s[o] = x;
             s[o + R * TSp] = y;
         }
@@ -895,30 +909,14 @@ template <int PF> __global__ __launch_bounds__(ROW_THREADS) void k_row_p(SsfmArg
                 }
             } else {
                 const double *d1 = a.db1_p + (size_t)c * N + cr;
-                const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * 9 : 0);
+                const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * BRF_STRIDE : 0);
                 const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem;
                 const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last, lcorr = a.lcorr;
                 for (int k = 0; k < PF; k++) {
                     const int e = tid + k * ROW_THREADS;
                     const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-                    const double btf = bt[e], d1f = d1[e];
                     cplx x = s[o], y = s[o + R * TSp];
-                    for (int q = 1; q <= ntrunk; q++) {
-                        int plate = n0 + q - 1;
-                        plate = plate < 0 ? 0 : (plate >= a.nplates ? a.nplates - 1 : plate);
-                        const double *m = brf + (size_t)plate * 9;
-                        const cplx R11 = make_double2(m[0], m[1]), R12 = make_double2(m[2], m[3]);
-                        const cplx R21 = make_double2(m[4], m[5]), R22 = make_double2(m[6], m[7]);
-                        const double dzk = (q == 1) ? dzb_first : (q == ntrunk ? dzb_last : lcorr);
-                        cplx uux = cadd(cmulc(x, R11), cmulc(y, R21));                 // :920
-                        cplx uuy = cadd(cmulc(x, R12), cmulc(y, R22));                 // :921
-                        const double combeta = btf * dzk;                              // :924
-                        const double deltabeta = 0.5 * (d1f + m[8]) * dzk / lcorr;     // :925
-                        uux = cmul(cexp_neg_turns(combeta + deltabeta), uux);          // :927 (phases in turns)
-                        uuy = cmul(cexp_neg_turns(combeta - deltabeta), uuy);          // :928
-                        x = cadd(cmul(R11, uux), cmul(R12, uuy));                      // :931
-                        y = cadd(cmul(R21, uux), cmul(R22, uuy));                      // :932
-                    }
+                    pmd_trunks(x, y, bt[e], d1[e], brf, a.nplates, n0, ntrunk, dzb_first, dzb_last, lcorr, curdz);
                     s[o] = x;
                     s[o + R * TSp] = y;
                 }
@@ -1544,7 +1542,7 @@ static int set_brf(plx_ssfm *P, const double *db0, const double *theta, const do
     if (!P || !db0 || !theta || !epsilon) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_set_birefringence: null argument");
     if (nsets < 1 || (nsets != 1 && nsets > P->d.max_frames)) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_set_birefringence: more sets than frames");
     const int np = P->d.nplates;
-    const size_t cap = (size_t)P->d.max_frames * np * 9, cnt = (size_t)nsets * np * 9;
+    const size_t cap = (size_t)P->d.max_frames * np * BRF_STRIDE, cnt = (size_t)nsets * np * BRF_STRIDE;
     if (!P->d_brf) PLX_HIP(hipMalloc((void **)&P->d_brf, cap * sizeof(double)));
     const int slot = P->brf_slot;
     P->brf_slot ^= 1;
@@ -1558,14 +1556,15 @@ static int set_brf(plx_ssfm *P, const double *db0, const double *theta, const do
     for (int sidx = 0; sidx < nsets; sidx++)
         for (int n = 0; n < np; n++) {
             const size_t i = (size_t)sidx * np + n;
-            // matR = matRth*matRepsilon, fiber.m:910-912
+            // matR = matRth*matRepsilon, fiber.m:910-912; the kernel needs S = matR * sigma3 * matR' (see pmd_trunks)
             const double ct = cos(theta[i]), sn = sin(theta[i]), ce = cos(epsilon[i]), se = sin(epsilon[i]);
-            double *m = &t[i * 9];
-            m[0] = ct * ce;  m[1] = -sn * se; // R11
-            m[2] = -sn * ce; m[3] = ct * se;  // R12
-            m[4] = sn * ce;  m[5] = ct * se;  // R21
-            m[6] = ct * ce;  m[7] = sn * se;  // R22
-            m[8] = db0[i] * kInv2Pi; // turns, like betat_p / db1_p
+            const double r11x = ct * ce, r11y = -sn * se, r12x = -sn * ce, r12y = ct * se;
+            const double r21x = sn * ce, r21y = ct * se, r22x = ct * ce, r22y = sn * se;
+            double *m = &t[i * BRF_STRIDE];
+            m[0] = (r11x * r11x + r11y * r11y) - (r12x * r12x + r12y * r12y);                       // S11 = |R11|^2 - |R12|^2
+            m[1] = (r11x * r21x + r11y * r21y) - (r12x * r22x + r12y * r22y);                       // S12 = R11 conj(R21) - R12 conj(R22)
+            m[2] = (r11y * r21x - r11x * r21y) - (r12y * r22x - r12x * r22y);
+            m[3] = db0[i] * kInv2Pi; // turns, like betat_p / db1_p
         }
     PLX_HIP(hipMemcpyAsync(P->d_brf, t, cnt * sizeof(double), hipMemcpyHostToDevice, st));
     PLX_HIP(hipEventRecord(P->brf_ev[slot], st));
