@@ -35,6 +35,19 @@ __global__ __launch_bounds__(512) void k_tile(cplx *a0, cplx *a1, int rows, int 
         if (NARR == 2) { cplx y = lds[e * NARR + 1]; y.y += 1.0; a1[g] = y; }
     }
 }
+__global__ __launch_bounds__(256) void k_stream(cplx *a, size_t n)
+{   // plain grid-stride in-place read-modify-write, no LDS: the streaming ceiling of the part for this traffic mix
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { cplx v = a[i]; v.x += 1.0; a[i] = v; }
+}
+__global__ __launch_bounds__(256) void k_stream4(cplx *a, size_t n)
+{   // the same with 4 independent loads in flight per thread
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i + 3 * stride < n; i += 4 * stride) {
+        cplx v0 = a[i], v1 = a[i + stride], v2 = a[i + 2 * stride], v3 = a[i + 3 * stride];
+        v0.x += 1.0; v1.x += 1.0; v2.x += 1.0; v3.x += 1.0;
+        a[i] = v0; a[i + stride] = v1; a[i + 2 * stride] = v2; a[i + 3 * stride] = v3;
+    }
+}
 int main()
 {
     const int F = 256, N1 = 256, N2 = 256;          // frames of N1 x N2 dual-pol samples
@@ -64,6 +77,16 @@ int main()
         }
         const double bytes = 2.0 * F * NS * 2 * sizeof(cplx);
         printf("%-70s %7.1f us  %.2f TB/s (LDS %zu KiB)\n", c.name, best * 1e3, bytes / (best * 1e-3) / 1e12, ldsb >> 10);
+    }
+    for (int v = 0; v < 2; v++) for (int g : {2048, 8192, 32768}) {
+        float best = 1e9; const size_t n = (size_t)F * NS * 2;
+        for (int it = 0; it < 6; it++) {
+            hipEventRecord(e0, 0);
+            if (v == 0) hipLaunchKernelGGL(k_stream, dim3(g), dim3(256), 0, 0, x, n); else hipLaunchKernelGGL(k_stream4, dim3(g), dim3(256), 0, 0, x, n);
+            hipEventRecord(e1, 0); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); if (it && ms < best) best = ms;
+        }
+        printf("streaming in-place RMW (%s, grid %d): %7.1f us  %.2f TB/s\n", v ? "4 loads in flight" : "1 load", g, best * 1e3, 2.0 * n * sizeof(cplx) / (best * 1e-3) / 1e12);
     }
     return 0;
 }
