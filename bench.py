@@ -304,6 +304,7 @@ def main():
                          "algorithmic_bytes_per_launch": SSFM_BYTES_PER_SAMPLE_STEP * F * n,
                          "traffic": traffic, "sample_steps_per_s": sample_steps / (fib * 1e-3),
                          "launches": row_launches, "ms_per_step_launch": fib / max(1, row_launches),
+                         "measured_inplace_rw_stream_GBs": 5100.0,   # scripts/micro/seg_copy.hip, profiles/r01_notes.md
                          "note": "one step-launch = the kernels of one SSFM step over the whole batch; 'launches' also counts "
                                  "the few no-op launches of the chunked step loop after every frame has finished"},
         }
