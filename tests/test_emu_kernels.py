@@ -503,3 +503,47 @@ def test_emu_inverse_pmd(emu, oracle):
     with pytest.raises(Exception, match="set_link has not been called"):
         emu.call("plx_pmdinv_apply_dev", plan, _vp(_il(fx)), _vp(_il(fy)), 1, None)
     emu.call("plx_pmdinv_destroy", plan)
+
+
+def test_emu_new_plan_argument_errors(emu):
+    """plx_front_*, plx_pmdinv_*, plx_filter_*: bad arguments are refused with PLX_ERR_ARG / PLX_ERR_UNSUPPORTED and a message."""
+    from polmux_amd._abi import PLX_ERR_ARG, PLX_ERR_UNSUPPORTED, PolmuxError
+    n = 1024
+    one = np.ones(n)
+    plan = C.c_void_p()
+
+    def code(fn, *args):
+        with pytest.raises(PolmuxError) as ei:
+            emu.call(fn, *args)
+        assert emu.last_error()
+        return ei.value.code
+
+    d = _front_desc(n, 1, 1, one + 0j, one + 0j, 1.0, 1, 5, 16, np.ones(16) / 16)       # even tap count
+    assert code("plx_front_create", C.byref(plan), C.byref(d)) == PLX_ERR_ARG
+    d = _front_desc(n, 1, 1, one + 0j, one + 0j, 1.0, 1, 40, 1, None)                   # adcbits out of range
+    assert code("plx_front_create", C.byref(plan), C.byref(d)) == PLX_ERR_ARG
+    d = _front_desc(1000, 1, 1, np.ones(1000) + 0j, np.ones(1000) + 0j, 1.0, 1, 0, 1, None)   # not a power of two
+    assert code("plx_front_create", C.byref(plan), C.byref(d)) == PLX_ERR_UNSUPPORTED
+    d = _front_desc(n, 1, 2, one + 0j, one + 0j, 1.0, 1, 0, 1, None)
+    emu.call("plx_front_create", C.byref(plan), C.byref(d))
+    x = np.zeros(2 * 2 * n)
+    out = np.zeros(2 * 2 * 2 * n)
+    assert code("plx_front_run_dev", plan, _vp(x), None, 1, None, _vp(out), None) == PLX_ERR_ARG      # dual plan needs uy
+    assert code("plx_front_run_dev", plan, _vp(x), _vp(x), 3, None, _vp(out), None) == PLX_ERR_ARG    # more than max_frames
+    emu.call("plx_front_destroy", plan)
+    assert code("plx_filter_create", C.byref(plan), n, 0, _vp(one), None) == PLX_ERR_ARG
+    assert code("plx_filter_create", C.byref(plan), 100, 1, _vp(one), None) == PLX_ERR_UNSUPPORTED
+    emu.call("plx_filter_create", C.byref(plan), n, 2, _vp(one), None)
+    assert code("plx_filter_apply_dev", plan, _vp(x), 3, None) == PLX_ERR_ARG
+    y = _il(np.arange(2 * n) + 1j)
+    emu.call("plx_filter_apply_dev", plan, _vp(y), 2, None)                                # H = 1: identity
+    np.testing.assert_allclose(y.view(np.complex128), np.arange(2 * n) + 1j, atol=1e-9)
+    emu.call("plx_filter_destroy", plan)
+    assert code("plx_pmdinv_create", C.byref(plan), n, 0) == PLX_ERR_ARG
+    emu.call("plx_pmdinv_create", C.byref(plan), n, 1)
+    nt0 = np.array([0], dtype=np.int32)
+    z = np.zeros(4)
+    assert code("plx_pmdinv_set_link", plan, 1, _vp(nt0), _vp(z), _vp(z), _vp(z), _vp(z), _vp(one), _vp(one), None, 1, 1) == PLX_ERR_ARG
+    nt1 = np.array([2], dtype=np.int32)
+    assert code("plx_pmdinv_set_link", plan, 1, _vp(nt1), _vp(z), _vp(z), _vp(z), _vp(z), _vp(one), _vp(one), None, 1, 2) == PLX_ERR_ARG
+    emu.call("plx_pmdinv_destroy", plan)
