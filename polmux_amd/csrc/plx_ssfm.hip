@@ -474,6 +474,10 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     const int nel = R << a.p2;
     const cplx *uyp = a.dual ? a.uy : a.ux;
     const size_t rowbase = (size_t)j0 * N2;      // the R rows of this workgroup are contiguous
+    // the inter-pass twiddles of a thread's points: with exactly ROW_CH points per thread (the usual shape) they stay
+    // in registers for the conjugate multiply on the way out
+    const bool keep_tw = nel == nthr * ROW_CH;
+    cplx tkeep[ROW_CH];
     for (int e0 = tid; e0 < nel; e0 += nthr * ROW_CH) {
         cplx tv[ROW_CH], xv[ROW_CH], yv[ROW_CH];
 #pragma unroll
@@ -488,6 +492,7 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 #pragma unroll
         for (int k = 0; k < ROW_CH; k++) {
             const int e = e0 + k * nthr;
+            tkeep[k] = tv[k];
             if (e < nel) {
                 const int r = e >> a.p2, i = e & (N2 - 1);
                 s[r * TSp + row_phys(i)] = cmul(xv[k], tv[k]);
@@ -534,6 +539,16 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     }
     __syncthreads();
     if (!(a.dbg & 2)) row_fft_dit(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
+    if (keep_tw) {
+#pragma unroll
+        for (int k = 0; k < ROW_CH; k++) {
+            const int e = tid + k * nthr;
+            const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+            a.ux[base + rowbase + e] = cmulc(s[o], tkeep[k]);
+            if (a.dual) a.uy[base + rowbase + e] = cmulc(s[o + R * TSp], tkeep[k]);
+        }
+        return;
+    }
     for (int e = tid; e < nel; e += nthr) {
         const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
         const cplx t = a.tpass[rowbase + e];
