@@ -1,0 +1,148 @@
+"""The MEX shims of INTEGRATION.md (integration/mex/*.c) compiled and driven without MATLAB through a test double of
+mex.h (tests/mexstub): the calling convention of the reference's gateways -- separate real/imaginary planes, missing
+imaginary planes allocated on the inputs, h1/h2 updated in the caller's arrays with 0, 0 returned, mexErrMsgTxt on bad
+arguments (cmaadaptivefilter.c:93-174, easiadaptivefilter.c:95-169, fastexp.c:46-67)."""
+import ctypes as C
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIMS = sorted(glob.glob(os.path.join(ROOT, "integration", "mex", "*.c")))
+STUB = os.path.join(ROOT, "tests", "mexstub")
+BUILD = os.path.join(STUB, "_build")
+
+
+class MxArray(C.Structure):
+    _fields_ = [("m", C.c_size_t), ("n", C.c_size_t), ("pr", C.POINTER(C.c_double)), ("pi", C.POINTER(C.c_double))]
+
+
+def test_every_shim_compiles_against_the_abi_header():
+    assert len(SHIMS) >= 5
+    for f in SHIMS:
+        subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + STUB,
+                               "-I" + os.path.join(ROOT, "include"), f])
+
+
+def _load(shim):
+    """shim + stub runtime -> one shared object linked against libpolmux_hip.so"""
+    import torch  # noqa: F401  (the HIP runtime of torch must be loaded first, see polmux_amd/_abi.py)
+    os.makedirs(BUILD, exist_ok=True)
+    so = os.path.join(BUILD, "lib%s.so" % shim)
+    libdir = os.path.join(ROOT, "polmux_amd", "lib")
+    subprocess.check_call(["gcc", "-std=gnu99", "-O1", "-shared", "-fPIC", "-I" + STUB, "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "integration", "mex", shim + ".c"), os.path.join(STUB, "mexstub.c"),
+                           "-L" + libdir, "-lpolmux_hip", "-Wl,-rpath," + libdir, "-o", so])
+    from polmux_amd import _abi
+    _abi.get()
+    lib = C.CDLL(so)
+    lib.mxCreateDoubleMatrix.restype = C.POINTER(MxArray)
+    lib.mxCreateDoubleMatrix.argtypes = [C.c_size_t, C.c_size_t, C.c_int]
+    lib.mexstub_call.argtypes = [C.c_int, C.POINTER(C.POINTER(MxArray)), C.c_int, C.POINTER(C.POINTER(MxArray))]
+    lib.mexstub_last_error.restype = C.c_char_p
+    return lib
+
+
+def _mx(lib, a, force_complex=False):
+    """numpy [m x n] -> mxArray with separate planes; a real array gets NO imaginary plane (like MATLAB)"""
+    a = np.atleast_2d(np.asarray(a))
+    cplx = np.iscomplexobj(a) or force_complex
+    a = a.astype(np.complex128 if cplx else np.float64)
+    p = lib.mxCreateDoubleMatrix(a.shape[0], a.shape[1], 1 if cplx else 0)
+    flat = np.asfortranarray(a)
+    re = np.ascontiguousarray(flat.real.T, dtype=np.float64)          # column-major order = C order of the transpose
+    C.memmove(p.contents.pr, re.ctypes.data, a.size * 8)
+    if cplx:
+        im = np.ascontiguousarray(flat.imag.T, dtype=np.float64)
+        C.memmove(p.contents.pi, im.ctypes.data, a.size * 8)
+    return p
+
+
+def _np(p):
+    m, n = p.contents.m, p.contents.n
+    re = np.ctypeslib.as_array(p.contents.pr, shape=(n, m)).T.copy() if m * n else np.zeros((m, n))
+    if p.contents.pi:
+        return re + 1j * np.ctypeslib.as_array(p.contents.pi, shape=(n, m)).T
+    return re
+
+
+def _call(lib, nlhs, *args):
+    prhs = (C.POINTER(MxArray) * len(args))(*args)
+    plhs = (C.POINTER(MxArray) * max(nlhs, 1))()
+    rc = lib.mexstub_call(nlhs, plhs, len(args), prhs)
+    return rc, [plhs[i] for i in range(nlhs)], lib.mexstub_last_error().decode()
+
+
+@pytest.mark.gpu
+def test_fastexp_shim():
+    lib = _load("plx_fastexp_mex")
+    x = np.linspace(-40, 40, 35).reshape(7, 5)
+    rc, out, err = _call(lib, 1, _mx(lib, x))
+    assert rc == 0, err
+    np.testing.assert_allclose(_np(out[0]), np.cos(x) + 1j * np.sin(x), atol=1e-15)
+
+
+@pytest.mark.gpu
+def test_cma_shim_updates_taps_in_place_and_returns_zeros():
+    from oracle import plxo as oracle
+    lib = _load("plx_cmaadaptivefilter_mex")
+    r = np.random.default_rng(5)
+    taps, L = 7, 200
+    a = np.exp(1j * (np.pi / 4 + np.pi / 2 * r.integers(0, 4, (L + taps - 1, 2))))
+    c, s = np.cos(0.3), np.sin(0.3)
+    xx = a @ np.array([[c, s], [-s, c]])
+    h1 = np.zeros((taps, 2)); h1[3, 0] = 1.0                     # REAL arrays: no imaginary plane until the gateway adds one
+    h2 = np.zeros((taps, 2)); h2[3, 1] = 1.0
+    mh1, mh2 = _mx(lib, h1), _mx(lib, h2)
+    assert not mh1.contents.pi
+    rc, out, err = _call(lib, 3, _mx(lib, xx), mh1, mh2, _mx(lib, [[taps]]), _mx(lib, [[1e-2]]), _mx(lib, [[1.0, 1.0]]), _mx(lib, [[1]]))
+    assert rc == 0, err
+    y, oh1, oh2 = oracle.cmaadaptivefilter(xx, h1.astype(complex), h2.astype(complex), taps, 1e-2, [1.0, 1.0], 1)
+    np.testing.assert_allclose(_np(out[0]), y, atol=1e-10)
+    assert bool(mh1.contents.pi)                                  # imaginary plane allocated ON THE INPUT (:141-155)
+    np.testing.assert_allclose(_np(mh1), oh1, atol=1e-10)         # taps updated in the caller's arrays
+    np.testing.assert_allclose(_np(mh2), oh2, atol=1e-10)
+    assert _np(out[1]).tolist() == [[0.0]] and _np(out[2]).tolist() == [[0.0]]   # returns 0, 0 (:166-171)
+    rc, _, err = _call(lib, 3, _mx(lib, xx), _mx(lib, h1), _mx(lib, h2), _mx(lib, [[4]]), _mx(lib, [[1e-2]]), _mx(lib, [[1.0, 1.0]]),
+                       _mx(lib, [[1]]))
+    assert rc == 1 and err == "Ntaps should be an ODD INTEGER."   # mexErrMsgTxt, :118-119
+    rc, _, err = _call(lib, 3, _mx(lib, xx), _mx(lib, h1), _mx(lib, h2), _mx(lib, [[taps]]), _mx(lib, [[1e-2]]), _mx(lib, [[1.0, 1.0]]),
+                       _mx(lib, [[3]]))
+    assert rc == 1 and err == "Samples x symbol should be either 1 or 2."          # :132
+
+
+@pytest.mark.gpu
+def test_matrix_ssfm_and_cde_shims():
+    from oracle import plxo as oracle
+    from polmux_amd import synth
+    lib = _load("plx_matrix_ssfm_mex")
+    nsymb, nt = 64, 16
+    ux, uy, _, _ = synth.pdm_qpsk_field(nsymb, nt, 6.0)
+    omega = 2 * np.pi * 28 * synth.fn_grid(nsymb, nt)
+    betat = (0.5 * omega ** 2 * -2.17e-8).reshape(-1, 1)
+    db1 = np.zeros_like(betat)
+    args = [_mx(lib, ux.reshape(-1, 1)), _mx(lib, uy.reshape(-1, 1)), _mx(lib, betat), _mx(lib, db1), _mx(lib, [[2e4]]), _mx(lib, [[5e-3]]),
+            _mx(lib, [[1.3e-6]]), _mx(lib, [[4.6e-5]]), _mx(lib, [[1]]), _mx(lib, [[2e4]]), _mx(lib, [[1]]), _mx(lib, [[0]]),
+            _mx(lib, [[1, 0, 1, 0]]), _mx(lib, [[0.0]]), _mx(lib, [[0.0]]), _mx(lib, [[0.0]])]
+    rc, out, err = _call(lib, 4, *args)
+    assert rc == 0, err
+    orc, ofd, onc, ox, oy = oracle.matrix_ssfm(ux, uy, betat, db1, 2e4, 5e-3, [1.3e-6], 4.6e-5, 2e4, 1, False, [1, 0, 1, 0], [0.0], [0.0], [0.0])
+    assert _np(out[1])[0, 0] == onc and _np(out[0])[0, 0] == pytest.approx(ofd, rel=1e-12)
+    assert np.abs(_np(out[2]) - ox).max() <= 1e-9 * np.abs(ox).max()
+    assert np.abs(_np(out[3]) - oy).max() <= 1e-9 * np.abs(oy).max()
+    lib2 = _load("plx_cde_ofde_mex")
+    r = np.random.default_rng(2)
+    x = r.standard_normal(700) + 1j * r.standard_normal(700)
+    y = r.standard_normal(700) + 1j * r.standard_normal(700)
+    sc = [_mx(lib2, [[v]]) for v in (56e9, 1550e-9, 8e4, 17e-6, 0.0, 256, 128)]
+    rc, out, err = _call(lib2, 2, _mx(lib2, x.reshape(-1, 1)), _mx(lib2, y.reshape(-1, 1)), *sc)
+    assert rc == 0, err
+    ex, ey, _ = oracle.cde_ofde(x, y, 56e9, 1550e-9, 8e4, 17e-6, 0.0, 256, 128)
+    np.testing.assert_allclose(_np(out[0])[:, 0], ex, atol=1e-11)
+    np.testing.assert_allclose(_np(out[1])[:, 0], ey, atol=1e-11)
+    sc[6] = _mx(lib2, [[300]])                                    # L > N: OverlapBothTrans display()s and returns [] (CDE_OFDE.m:63-85)
+    rc, out, err = _call(lib2, 2, _mx(lib2, x.reshape(-1, 1)), _mx(lib2, y.reshape(-1, 1)), *sc)
+    assert rc == 0 and out[0].contents.m == 0
