@@ -230,6 +230,11 @@ int64_t plx_front_out_len(const plx_front *plan);   /* ceil(nfft / decim) */
  * d_out: [nframes][1 + dual_pol][out_len] complex128 RxSamples (RxPdmCohQpsk.m:63-72).                     */
 int plx_front_run_dev(plx_front *plan, double *d_ux, double *d_uy, int nframes, const int64_t *shift,
                       double *d_out, void *stream);
+/* gateway tier (one frame, host arrays, MATLAB's separate planes; xi/yi may be NULL, yr NULL when !dual_pol):
+ * out [out_len x (1 + dual_pol)] column-major = RxSamples; optional cur_r/cur_i [nfft x 2(1 + dual_pol)] = the
+ * photocurrent columns [IricX IricY] of receiver_cohmix.m:300-307 (cur_i is filled with zeros).            */
+int plx_rx_front(const double *xr, const double *xi, const double *yr, const double *yi, const plx_front_desc *desc,
+                 const int64_t *shift, double *outr, double *outi, double *cur_r, double *cur_i);
 
 /* y = ifft(fft(x) .* H), in place, on [nsignals][nfft] complex128 rows sharing one frequency response H (fft
  * order): the dispersion-compensating filter of RxPdmCohQpsk.m:74-84 / dsp4cohdec.m:163-173 (Hfilt built by

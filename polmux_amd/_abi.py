@@ -86,6 +86,7 @@ SIGNATURES = {
     "plx_front_destroy": [_vp],
     "plx_front_out_len": [_vp],
     "plx_front_run_dev": [_vp, _vp, _vp, C.c_int, _vp, _vp, _vp],
+    "plx_rx_front": [_vp, _vp, _vp, _vp, C.POINTER(FrontDesc), _vp, _vp, _vp, _vp, _vp],
     "plx_filter_create": [C.POINTER(_vp), _i64, C.c_int, _vp, _vp],
     "plx_filter_destroy": [_vp],
     "plx_filter_apply_dev": [_vp, _vp, C.c_int, _vp],

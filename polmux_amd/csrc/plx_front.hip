@@ -299,3 +299,47 @@ extern "C" int plx_filter_apply_dev(plx_filter *P, double *d_x, int nsignals, vo
     if (nsignals < 1 || nsignals > P->max_sig) PLX_FAIL(PLX_ERR_ARG, "plx_filter_apply_dev: nsignals outside [1, max_signals]");
     return plx_ssfm_filter_dev(P->fft, (cplx *)d_x, nullptr, P->d_h, nsignals, stream);
 }
+
+// gateway tier: one RxPdmCohQpsk front end on host arrays with MATLAB's separate planes (one frame)
+extern "C" int plx_rx_front(const double *xr, const double *xi, const double *yr, const double *yi, const plx_front_desc *desc,
+                            const int64_t *shift, double *outr, double *outi, double *cur_r, double *cur_i)
+{
+    if (!xr || !desc || !outr || !outi) PLX_FAIL(PLX_ERR_ARG, "plx_rx_front: null argument");
+    plx_front_desc d = *desc;
+    d.max_frames = 1;
+    const int dual = d.dual_pol ? 1 : 0;
+    if (dual && !yr) PLX_FAIL(PLX_ERR_ARG, "plx_rx_front: dual-polarisation descriptor needs the y field");
+    plx_front *P = nullptr;
+    int rc = plx_front_create(&P, &d);
+    if (rc != PLX_OK) return rc;
+    const size_t N = (size_t)d.nfft, nout = (size_t)plx_front_out_len(P);
+    std::vector<cplx> h(N * (dual + 1));
+    for (size_t i = 0; i < N; i++) {
+        h[i] = make_double2(xr[i], xi ? xi[i] : 0.0);
+        if (dual) h[N + i] = make_double2(yr[i], yi ? yi[i] : 0.0);
+    }
+    cplx *d_u = nullptr, *d_o = nullptr;
+    std::vector<cplx> o(nout * (dual + 1));
+    bool ok = hipMalloc((void **)&d_u, h.size() * sizeof(cplx)) == hipSuccess &&
+              hipMalloc((void **)&d_o, o.size() * sizeof(cplx)) == hipSuccess &&
+              hipMemcpy(d_u, h.data(), h.size() * sizeof(cplx), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        rc = plx_front_run_dev(P, (double *)d_u, dual ? (double *)(d_u + N) : nullptr, 1, shift, (double *)d_o, nullptr);
+        ok = rc == PLX_OK && hipDeviceSynchronize() == hipSuccess &&
+             hipMemcpy(o.data(), d_o, o.size() * sizeof(cplx), hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(h.data(), d_u, h.size() * sizeof(cplx), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    if (d_u) (void)hipFree(d_u);
+    if (d_o) (void)hipFree(d_o);
+    plx_front_destroy(P);
+    if (rc != PLX_OK) return rc;
+    if (!ok) PLX_FAIL(PLX_ERR_HIP, "plx_rx_front: HIP allocation or transfer failed");
+    for (size_t i = 0; i < o.size(); i++) { outr[i] = o[i].x; outi[i] = o[i].y; }          // [nout x (1 + dual)] column-major
+    if (cur_r && cur_i)                                                                      // photocurrents [nfft x 2(1 + dual)]: I, Q per pol
+        for (int p = 0; p <= dual; p++)
+            for (size_t i = 0; i < N; i++) {
+                cur_r[(2 * p) * N + i] = h[p * N + i].x; cur_i[(2 * p) * N + i] = 0.0;
+                cur_r[(2 * p + 1) * N + i] = h[p * N + i].y; cur_i[(2 * p + 1) * N + i] = 0.0;
+            }
+    return PLX_OK;
+}

@@ -146,3 +146,31 @@ def test_matrix_ssfm_and_cde_shims():
     sc[6] = _mx(lib2, [[300]])                                    # L > N: OverlapBothTrans display()s and returns [] (CDE_OFDE.m:63-85)
     rc, out, err = _call(lib2, 2, _mx(lib2, x.reshape(-1, 1)), _mx(lib2, y.reshape(-1, 1)), *sc)
     assert rc == 0 and out[0].contents.m == 0
+
+
+@pytest.mark.gpu
+def test_rx_front_shim_matches_the_resident_tier_and_oracle():
+    """plx_rx_front_mex: the front end called the MATLAB way (host arrays, tables from the .m side) equals oracle/front.py."""
+    from oracle import front
+    from polmux_amd import rxfront, synth
+    lib = _load("plx_rx_front_mex")
+    nsymb, nt = 256, 16
+    n = nsymb * nt
+    ux, uy, _, _ = synth.pdm_qpsk_field(nsymb, nt, 2.0)
+    fn = synth.fn_grid(nsymb, nt)
+    hopt = rxfront.myfilter("gauss", fn, 0.95)                     # real table: no imaginary plane
+    hel = rxfront.myfilter("bessel5", fn, 0.65)
+    b = rxfront.fir1_lowpass(16, 2.0 / nt)
+    rc, out, err = _call(lib, 1, _mx(lib, ux.reshape(-1, 1)), _mx(lib, uy.reshape(-1, 1)), _mx(lib, hopt.reshape(-1, 1)),
+                         _mx(lib, hel.reshape(-1, 1)), _mx(lib, [[1.0]]), _mx(lib, [[1]]), _mx(lib, [[5]]), _mx(lib, [[nt // 2]]),
+                         _mx(lib, b.reshape(1, -1)), _mx(lib, [[-9, -9]]))
+    assert rc == 0, err
+    got = _np(out[0])
+    assert got.shape == (2 * nsymb, 2)
+    cur = front.receiver_cohmix(ux, uy, hopt, 1.0, hel, True)
+    want = front.rx_front(cur, True, 5, [-9, -9], nt // 2, b)
+    assert np.mean(np.abs(got - want) > 1e-9 * np.abs(want).max()) < 2e-3
+    rc, _, err = _call(lib, 1, _mx(lib, ux.reshape(-1, 1)), _mx(lib, uy.reshape(-1, 1)), _mx(lib, hopt.reshape(-1, 1)),
+                       _mx(lib, hel.reshape(-1, 1)), _mx(lib, [[1.0]]), _mx(lib, [[1]]), _mx(lib, [[5]]), _mx(lib, [[nt // 2]]),
+                       _mx(lib, np.ones((1, 16)) / 16), _mx(lib, [[0, 0]]))
+    assert rc == 1 and "odd number of taps" in err
