@@ -174,3 +174,22 @@ def test_rx_front_shim_matches_the_resident_tier_and_oracle():
                        _mx(lib, hel.reshape(-1, 1)), _mx(lib, [[1.0]]), _mx(lib, [[1]]), _mx(lib, [[5]]), _mx(lib, [[nt // 2]]),
                        _mx(lib, np.ones((1, 16)) / 16), _mx(lib, [[0, 0]]))
     assert rc == 1 and "odd number of taps" in err
+
+
+@pytest.mark.gpu
+def test_scalar_ssfm_shim_with_xpm():
+    from oracle import plxo as oracle
+    from polmux_amd import synth
+    lib = _load("plx_scalar_ssfm_mex")
+    nsymb, nt, nfc = 64, 16, 3
+    n = nsymb * nt
+    u = np.stack([synth.pdm_qpsk_field(nsymb, nt, 4.0 + k, 2 + k, 7 + k)[0] for k in range(nfc)], 1)
+    omega = 2 * np.pi * 28 * synth.fn_grid(nsymb, nt)
+    betat = np.stack([0.5 * omega ** 2 * -2.17e-8 + 6.8e-9 * k * omega for k in range(nfc)], 1)
+    gam = np.array([[1.2e-6, 1.3e-6, 1.25e-6]])
+    rc, out, err = _call(lib, 3, _mx(lib, u), _mx(lib, betat), _mx(lib, [[1e4]]), _mx(lib, [[5e-3]]), _mx(lib, gam), _mx(lib, [[4.6e-5]]),
+                         _mx(lib, [[nfc]]), _mx(lib, [[1e4]]), _mx(lib, [[1, 0, 1, 1]]))
+    assert rc == 0, err
+    ofd, onc, ou = oracle.scalar_ssfm(u, betat, 1e4, 5e-3, gam[0], 4.6e-5, 1e4, [1, 0, 1, 1])
+    assert _np(out[1])[0, 0] == onc and _np(out[0])[0, 0] == pytest.approx(ofd, rel=1e-12)
+    assert np.abs(_np(out[2]) - ou).max() <= 1e-9 * np.abs(ou).max()
