@@ -308,7 +308,7 @@ def main():
                          "note": "one step-launch = the kernels of one SSFM step over the whole batch; 'launches' also counts "
                                  "the few no-op launches of the chunked step loop after every frame has finished"},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # a reported baseline, timed at N = 1 only
             (v, cdt, nc), allc = cpu_baseline(cfg, hp, a.cpu_frames, a.noise)
             out["cpu_baseline"] = {"value": v, "unit": "Gsample/s", "cores": 1, "kind": "port",
                                    "sample": "%d frame(s) of the same batch through oracle/ (fibre %d steps + front end + noise + "
