@@ -940,7 +940,7 @@ extern "C" int plx_dsp_create(plx_dsp **out, int64_t Lin, int32_t ncol, int32_t 
     if (Lin < 2 || (ncol != 1 && ncol != 2) || max_frames < 1) PLX_FAIL(PLX_ERR_ARG, "plx_dsp_create: bad size");
     if (p->applypol && ncol == 2 && (p->polmethod < 0 || p->polmethod > 3))
         PLX_FAIL(PLX_ERR_ARG, "Unknown Polar Rotation method."); // DspPdmCohQpsk.m:40
-    if (p->modorder < 1 || p->modorder > 4 || p->poworder < 1 || p->freqavg < 0 || p->phasavg < 0)
+    if (p->modorder < 1 || p->modorder > 4 || p->poworder < 0 || p->freqavg < 0 || p->phasavg < 0)
         PLX_FAIL(PLX_ERR_ARG, "plx_dsp_create: bad carrier-recovery parameters");
     plx_dsp *P = new plx_dsp();
     P->p = *p; P->Lin = Lin; P->ncol = ncol; P->max_frames = max_frames;
