@@ -193,3 +193,27 @@ def test_scalar_ssfm_shim_with_xpm():
     ofd, onc, ou = oracle.scalar_ssfm(u, betat, 1e4, 5e-3, gam[0], 4.6e-5, 1e4, [1, 0, 1, 1])
     assert _np(out[1])[0, 0] == onc and _np(out[0])[0, 0] == pytest.approx(ofd, rel=1e-12)
     assert np.abs(_np(out[2]) - ou).max() <= 1e-9 * np.abs(ou).max()
+
+
+@pytest.mark.gpu
+def test_easi_shim_six_inputs_in_place_real_parts():
+    """easiadaptivefilter.c:95-169 calling convention: six inputs (sps is prhs[5]), in-place taps, 0, 0 returned; only the
+    real parts of tap 0 move (:81-90)."""
+    from oracle import plxo as oracle
+    lib = _load("plx_easiadaptivefilter_mex")
+    r = np.random.default_rng(9)
+    L = 150
+    a = np.exp(1j * (np.pi / 4 + np.pi / 2 * r.integers(0, 4, (L, 2))))
+    xx = a @ np.array([[np.cos(0.2), np.sin(0.2)], [-np.sin(0.2), np.cos(0.2)]]) + 0.05 * (r.standard_normal((L, 2)) + 1j * r.standard_normal((L, 2)))
+    h1 = np.array([[0.9 + 0.1j, 0.2 - 0.3j]]); h2 = np.array([[-0.2 + 0.05j, 1.1 + 0.2j]])
+    mh1, mh2 = _mx(lib, h1), _mx(lib, h2)
+    rc, out, err = _call(lib, 3, _mx(lib, xx), mh1, mh2, _mx(lib, [[1]]), _mx(lib, [[1e-2]]), _mx(lib, [[1]]))
+    assert rc == 0, err
+    y, g1, g2 = oracle.easiadaptivefilter(xx, h1, h2, 1, 1e-2, 1)
+    np.testing.assert_allclose(_np(out[0]), y, atol=1e-11)
+    np.testing.assert_allclose(_np(mh1), g1, atol=1e-11)
+    np.testing.assert_allclose(_np(mh2), g2, atol=1e-11)
+    np.testing.assert_array_equal(_np(mh1).imag, h1.imag)
+    assert _np(out[1]).tolist() == [[0.0]] and _np(out[2]).tolist() == [[0.0]]
+    rc, _, err = _call(lib, 3, _mx(lib, xx), mh1, mh2, _mx(lib, [[1]]), _mx(lib, [[1e-2]]))
+    assert rc == 1 and err == "Six inputs required."
