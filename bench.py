@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--nf", type=float, default=None, help="noise figure [dB] of the in-line amplifiers (default: noiseless)")
     ap.add_argument("--no-overlap", action="store_true", help="run the receiver on the fibre stream (no stream overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame latency measurement after the timed region")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the batch the one-core CPU baseline processes (~0.5 s each)")
     return ap.parse_args()
 
@@ -257,7 +258,7 @@ def main():
 
     # SURVEY 8d's M1 read literally -- ONE frame through fibre + receiver, nothing else on the GPU (outside the timed region)
     single = None
-    if rank == 0 and not a.mc:
+    if rank == 0 and not a.mc and not a.no_single_frame:
         sx, sy = hp.make_batch(1)
         torch.cuda.synchronize()
         t1 = time.perf_counter()

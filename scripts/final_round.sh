@@ -11,7 +11,7 @@ timeout -k 10 600 python bench.py > gpurun_out/final/bench_default.json 2> gpuru
 tail -c 600 gpurun_out/final/bench_default.json; echo
 timeout -k 10 600 python bench.py --frontend cohmix --no-cpu-baseline > gpurun_out/final/bench_cohmix.json 2>/dev/null || exit 1
 timeout -k 10 600 python bench.py --mc --no-cpu-baseline > gpurun_out/final/bench_mc.json 2>/dev/null || exit 1
-timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2>&1 || exit 1
+timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-frame > /dev/null 2>&1 || exit 1
 f=$(find gpurun_out/final/prof -name "*kernel_trace.csv" | head -1)
 python scripts/prof_summary.py $f > gpurun_out/final/kernel_trace_summary.md
 g=$(find gpurun_out/final/prof -name "*kernel_stats.csv" | head -1)

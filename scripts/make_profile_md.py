@@ -4,9 +4,9 @@ import csv, json, os
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 F = os.path.join(R, "gpurun_out", "final")
 out = []
-out.append("# Round 1 final: rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline` (F = 1024 C1 frames, MI355X)\n")
-out.append("Command (scripts/final_round.sh): `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`\n")
-out.append("Default path: fused column sweep `k_colx16` (inverse column pass of step s + step controller + forward column pass of step s+1) and `k_row`: two launches, two HBM sweeps per SSFM step.  (The run ends with one single-frame pass for `config.single_frame`: 52 more, tiny launches of each kernel.)\n")
+out.append("# Round 1 final: rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-frame` (F = 1024 C1 frames, MI355X)\n")
+out.append("Command (scripts/final_round.sh): `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-frame`\n")
+out.append("Default path: fused column sweep `k_colx16` (inverse column pass of step s + step controller + forward column pass of step s+1) and `k_row`: two launches, two HBM sweeps per SSFM step.\n")
 out.append("## Per-kernel summary from the kernel trace (scripts/prof_summary.py; 'active' = launches longer than 20 us --\nthe chunked step loop also issues launches that return at once when every frame has reached the fibre end)\n")
 out.append(open(os.path.join(F, "kernel_trace_summary.md")).read())
 out.append("\n## rocprofv3 --stats (kernel_stats.csv, top rows)\n\n```")
