@@ -62,6 +62,9 @@ struct SsfmArgs {
     unsigned *arrive, *epoch;      // [F] frame barrier of the fused column sweep (tickets / completed rounds)
     double *pub;                   // [F][2] words published inside a launch: leff, done flag
     int *syncerr;                  // set if a frame barrier timed out
+    unsigned long long *slots;     // [F][tiles per frame] per-tile max |u|^2 of the current round (k_colx16), ~0 = not arrived
+    unsigned long long *pubw;      // [F][2] published Leff (or -1: frame finished) of the round, by launch parity, ~0 = not yet
+    int round;                     // launch index of the fused sweep within this propagate call
     int p1, p2, nfc, dual, W, logW, T, logT, R, logR; // column tile: N1 rows x T complex (T = W*npol)
     int spm, xpm, manakov, pmd, nplates, brf_per_frame;
     int nframes; // frames of the current propagate call (kernels return at once when all are done)
@@ -165,7 +168,9 @@ __global__ __launch_bounds__(256) void k_umax(SsfmArgs a)
 // --------------------------------------------------------------- step control ---
 // nextstep (fiber.m:682-715), the loop head/tail of matrix_ssfm/scalar_ssfm
 // (:512-551, :585-636) and checkstep (:718-758), one lane per frame.
-template <bool AGENT> __device__ __forceinline__ void ctrl_step(const SsfmArgs &a, int f)
+// have_pmax: Pmax = max_k gam(k)*Umax(k) (fiber.m:694-698) is handed in by the caller (the fused sweep collects it from
+// the per-tile slots of its frame barrier) instead of being formed from the umax words.
+template <bool AGENT> __device__ __forceinline__ void ctrl_step(const SsfmArgs &a, int f, bool have_pmax = false, double pmax_in = 0.0)
 {
     FrameCtl c = a.ctl[f];
     if (c.done) return;
@@ -180,13 +185,17 @@ template <bool AGENT> __device__ __forceinline__ void ctrl_step(const SsfmArgs &
     }
     // nextstep
     double Pmax = -INFINITY;
-    for (int k = 0; k < a.nfc; k++) {
-        unsigned long long *up = a.umax + f * a.nfc + k;
-        const unsigned long long bits = AGENT ? ld_agent(up) : *up;
-        double Umax = __longlong_as_double((long long)bits);
-        double gp = a.gam[k] * Umax;
-        Pmax = gp > Pmax ? gp : Pmax;
-        if (AGENT) st_agent(up, 0ull); else *up = 0ull;
+    if (have_pmax) {
+        Pmax = pmax_in;
+    } else {
+        for (int k = 0; k < a.nfc; k++) {
+            unsigned long long *up = a.umax + f * a.nfc + k;
+            const unsigned long long bits = AGENT ? ld_agent(up) : *up;
+            double Umax = __longlong_as_double((long long)bits);
+            double gp = a.gam[k] * Umax;
+            Pmax = gp > Pmax ? gp : Pmax;
+            if (AGENT) st_agent(up, 0ull); else *up = 0ull;
+        }
     }
     double leffn = a.dphimax / Pmax;
     double dl = a.alphalin * leffn;
@@ -1158,39 +1167,57 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             m = wave_max(m);
             if ((tid & 63) == 0) red[tid >> 6] = m;
             __syncthreads();
-            if (tid == 0) {
-                double mm = red[0];
-                for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
-                // frame barrier with a FIXED leader (the workgroup of the frame's first tile): members publish
-                // their maximum and leave one ticket without waiting for its return value; the leader waits for
-                // the tickets, runs the step controller and publishes (epoch, Leff, done).
-                const unsigned prev_epoch = ld_agent(a.epoch + f);     // rounds completed so far (stable until we all arrive)
-                const unsigned round = prev_epoch + 1;
-                const bool leader = (tl % tiles_pf) == 0;
-                const unsigned long long prev = atomicMax(a.umax + fc, (unsigned long long)__double_as_longlong(mm));
-                if (!leader) {
-                    if (prev != ~0ull) atomicAdd(a.arrive + f, 1u);    // ordered after the max (its result is in hand)
-                    unsigned spins = 0;
-                    while (ld_agent(a.epoch + f) < round) {
-                        nap();
-                        if (++spins > (1u << 21)) { atomicAdd(a.syncerr, 1); break; }
+            // Frame barrier (dz of the next step needs the frame-wide maximum, fiber.m:694-698).  One launch = one round,
+            // so kernel boundaries order the rounds and the protocol needs no read-modify-write at all: every member
+            // stores its tile maximum into its own slot and polls ONE word; the leader (workgroup of the frame's first
+            // tile) polls the slots with a whole wave, runs the step controller and publishes Leff (or -1: finished) in
+            // the word of this launch's parity, having reset the slots and the other parity's word for the next round.
+            {
+                const int ti = tl % tiles_pf;
+                const unsigned par = (unsigned)a.round & 1u;
+                unsigned long long *slots = a.slots + (size_t)f * tiles_pf;
+                unsigned long long *pubw = a.pubw + 2 * (size_t)f;
+                if (ti != 0) {
+                    if (tid == 0) {
+                        double mm = red[0];
+                        for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
+                        st_agent(slots + ti, (unsigned long long)__double_as_longlong(mm));
+                        unsigned long long v = ~0ull;
+                        unsigned spins = 0;
+                        while ((v = ld_agent(pubw + par)) == ~0ull) {
+                            nap();
+                            if (++spins > (1u << 21)) { atomicAdd(a.syncerr, 1); v = (unsigned long long)__double_as_longlong(-1.0); break; }
+                        }
+                        const double pv = __longlong_as_double((long long)v);
+                        red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm;
                     }
-                } else {
-                    const unsigned want = round * (unsigned)(tiles_pf - 1);
+                } else if (tid < 64) {
+                    double mm = red[0];
+                    for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
+                    double pm;
                     unsigned spins = 0;
-                    while (prev != ~0ull && ld_agent(a.arrive + f) < want) {
+                    for (;;) {
+                        bool all = true;
+                        pm = (tid == 0) ? a.gam[c] * mm : -INFINITY;       // the leader's own tile (channel c of tile 0)
+                        for (int i = 1 + tid; i < tiles_pf; i += 64) {
+                            const unsigned long long b = ld_agent(slots + i);
+                            if (b == ~0ull) all = false;
+                            else { const double gp = a.gam[i / tiles_x] * __longlong_as_double((long long)b); pm = gp > pm ? gp : pm; }
+                        }
+                        if (__all(all)) break;
                         nap();
-                        if (++spins > (1u << 21)) { atomicAdd(a.syncerr, 1); break; }
+                        if (++spins > (1u << 21)) { if (tid == 0) atomicAdd(a.syncerr, 1); break; }
                     }
-                    ctrl_step<true>(a, f);
-                    st_agent_f64(a.pub + 2 * f, a.ctl[f].leff);
-                    st_agent_f64(a.pub + 2 * f + 1, a.ctl[f].done ? 1.0 : 0.0);
-                    drain_vmem();
-                    st_agent(a.epoch + f, round);
+                    pm = wave_max(pm);
+                    for (int i = 1 + tid; i < tiles_pf; i += 64) st_agent(slots + i, ~0ull);
+                    if (tid == 0) {
+                        ctrl_step<true>(a, f, true, pm);
+                        const double pv = a.ctl[f].done ? -1.0 : a.ctl[f].leff;
+                        st_agent(pubw + (par ^ 1u), ~0ull);
+                        st_agent_f64((double *)(pubw + par), pv);
+                        red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm;
+                    }
                 }
-                red[16] = ld_agent_f64(a.pub + 2 * f);
-                red[17] = ld_agent_f64(a.pub + 2 * f + 1);
-                red[18] = mm;
             }
             __syncthreads();
             const double leff = red[16];
@@ -1289,6 +1316,7 @@ struct plx_ssfm {
     size_t lds_col = 0, lds_row = 0;
     unsigned *d_sync = nullptr;   // arrive[F] | epoch[F] | syncerr
     double *d_pub = nullptr;
+    unsigned long long *d_slots = nullptr, *d_pubw = nullptr;   // slot barrier of k_colx16
     int fused = 0, fused_grid = 0, tiles_pf = 0;
     int row16 = 0;                // register-blocked row pass usable (N2 == 256, dual, no PMD)
     int row_threads = ROW_THREADS; // workgroup size of k_row, chosen at plan creation
@@ -1316,7 +1344,7 @@ static void free_plan(plx_ssfm *P)
     if (!P) return;
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
-    hipFree(P->d_ndone); hipFree(P->d_sync); hipFree(P->d_pub);
+    hipFree(P->d_ndone); hipFree(P->d_sync); hipFree(P->d_pub); hipFree(P->d_slots); hipFree(P->d_pubw);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     for (int k = 0; k < 2; k++) {
         if (P->h_brf[k]) hipHostFree(P->h_brf[k]);
@@ -1514,6 +1542,12 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
                 PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed");
             }
             a.arrive = P->d_sync; a.epoch = P->d_sync + F; a.syncerr = (int *)(P->d_sync + 2 * (size_t)F); a.pub = P->d_pub;
+            if (hipMalloc((void **)&P->d_slots, sizeof(unsigned long long) * (size_t)F * tiles_pf) != hipSuccess ||
+                hipMalloc((void **)&P->d_pubw, sizeof(unsigned long long) * 2 * (size_t)F) != hipSuccess) {
+                free_plan(P);
+                PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed");
+            }
+            a.slots = P->d_slots; a.pubw = P->d_pubw;
         }
     }
     if (allow_lds(k_row16, P->lds_row) != hipSuccess) { free_plan(P); PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS"); }
@@ -1623,6 +1657,8 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     if (fused) { // the first fused launch also forms nextstep's initial maximum
         PLX_HIP(hipMemsetAsync(P->d_sync, 0, sizeof(unsigned) * (2 * (size_t)P->d.max_frames + 16), st));
         PLX_HIP(hipMemsetAsync(P->d_pub, 0, sizeof(double) * 2 * (size_t)P->d.max_frames, st));
+        PLX_HIP(hipMemsetAsync(P->d_slots, 0xFF, sizeof(unsigned long long) * (size_t)P->d.max_frames * P->tiles_pf, st));   // ~0 = "not arrived"
+        PLX_HIP(hipMemsetAsync(P->d_pubw, 0xFF, sizeof(unsigned long long) * 2 * (size_t)P->d.max_frames, st));
     } else {
         unsigned gx = (unsigned)((P->N + 255) / 256);
         if (gx > 64) gx = 64;
@@ -1651,6 +1687,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
 #ifdef PLX_EMU
                 emu::g_concurrency = P->tiles_pf; // the emulator must keep one frame's workgroups alive together
 #endif
+                a.round = steps + sidx;
                 if (P->fused == 8 && a.p1 == 8 && a.W == 8 && !getenv("PLX_SSFM_NO_R16"))
                     PLX_LAUNCH(k_colx16, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
                 else if (P->fused == 8 && getenv("PLX_SSFM_FUSE_512")) PLX_LAUNCH((k_colx<4, 512>), gx, dim3(512), P->lds_col, st, a, tcx, P->tiles_pf, tct);

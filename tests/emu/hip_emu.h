@@ -104,6 +104,12 @@ static inline int __any(int pred)
     for (int m = 32; m >= 1; m >>= 1) v |= __shfl_xor(v, m, 64);
     return v;
 }
+static inline int __all(int pred)
+{
+    int v = pred ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) v &= __shfl_xor(v, m, 64);
+    return v;
+}
 
 static inline unsigned long long atomicMax(unsigned long long *p, unsigned long long v)
 {
