@@ -1318,6 +1318,7 @@ struct plx_ssfm {
     double *d_pub = nullptr;
     unsigned long long *d_slots = nullptr, *d_pubw = nullptr;   // slot barrier of k_colx16
     int fused = 0, fused_grid = 0, tiles_pf = 0;
+    int use_r16 = 0;              // fused sweep runs the register-blocked k_colx16 (256 x (8+8) tiles)
     int row16 = 0;                // register-blocked row pass usable (N2 == 256, dual, no PMD)
     int row_threads = ROW_THREADS; // workgroup size of k_row, chosen at plan creation
     int row_split = 0, rs_threads = 0; // long rows without PMD: one polarisation per workgroup (scalar row pass twice)
@@ -1533,6 +1534,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         const int cap = ncu * wg;
         if ((nel_col == 8 * 256 || nel_col == 4 * 256 || nel_col == 16 * 256) && tiles_pf <= cap) {
             P->fused = nel_col / 256;
+            P->use_r16 = (P->fused == 8 && a.p1 == 8 && a.W == 8 && !getenv("PLX_SSFM_NO_R16")) ? 1 : 0;
             P->tiles_pf = tiles_pf;
             P->fused_grid = (cap / tiles_pf) * tiles_pf;
             if (const char *e = getenv("PLX_SSFM_FUSE_GRID")) { int v = atoi(e); if (v >= tiles_pf && v <= cap) P->fused_grid = (v / tiles_pf) * tiles_pf; }
@@ -1688,7 +1690,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
                 emu::g_concurrency = P->tiles_pf; // the emulator must keep one frame's workgroups alive together
 #endif
                 a.round = steps + sidx;
-                if (P->fused == 8 && a.p1 == 8 && a.W == 8 && !getenv("PLX_SSFM_NO_R16"))
+                if (P->use_r16)
                     PLX_LAUNCH(k_colx16, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
                 else if (P->fused == 8 && getenv("PLX_SSFM_FUSE_512")) PLX_LAUNCH((k_colx<4, 512>), gx, dim3(512), P->lds_col, st, a, tcx, P->tiles_pf, tct);
                 else if (P->fused == 8) PLX_LAUNCH((k_colx<8, 256>), gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);

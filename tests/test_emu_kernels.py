@@ -300,7 +300,7 @@ def test_emu_fused_and_persistent_variants(emu, oracle, monkeypatch):
     betat, db1 = _tables(n, nt, fls, 1)
     fields = [_qpsk_field(n, nt, p)[:2] for p in (6.0, 9.0, 12.0)]
     ref = [oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0]) for f in fields]
-    for env in ({"PLX_SSFM_FUSE": "1"}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_PERSIST": "1", "PLX_SSFM_NO_FUSE": "1"},
+    for env in ({"PLX_SSFM_NO_R16": "1"}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_PERSIST": "1", "PLX_SSFM_NO_FUSE": "1"},
                 {"PLX_SSFM_P1": "4", "PLX_SSFM_ROW16": "1"}, {"PLX_SSFM_P1": "4"}):
         nf = 1 if "PLX_SSFM_P1" in env else 3          # the row variants have no cross-frame machinery
         for k, v in env.items():
