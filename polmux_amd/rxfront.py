@@ -326,6 +326,51 @@ def _apply_dcf(samples, p):
     return rows.transpose(0, 1).contiguous()
 
 
+def eye_opening(irx, pat, delay, ts=0.0):
+    """worsteyeop of RxPdmCohQpsk.m:87 / dsp4cohdec.m:283 from mygeteyeinfo with a fixed sampling time x.ts and the
+    'theory' delay (RxPdmCohQpsk.m:100-166): phase eye of the photocurrents irx [Nfft x 2 or 4] (after the ADC), per
+    alphabet value, at sample xopt = round((ts+0.5)*NT).  Host diagnostic (O(Nfft) numpy on downloaded currents)."""
+    irx = np.asarray(irx, dtype=float)
+    pat = np.asarray(pat)
+    if pat.ndim == 1:
+        pat = pat.reshape(-1, 1)
+    nt, nsymb = GSTATE.NT, GSTATE.NSYMB
+    npol = irx.shape[1] // 2
+    minv = np.full((nt, 4 * npol), np.nan)
+    maxv = np.full((nt, 4 * npol), np.nan)
+    delay = np.ones(npol) * np.asarray(delay, dtype=float)
+    for p in range(npol):
+        ipat = pat[:, p].astype(int)
+        ph = np.angle(irx[:, 2 * p] + 1j * irx[:, 2 * p + 1])                       # Iric_t, :131-132
+        nshift = _mround(nt / 2 - delay[p] * nt)                                   # :139-141
+        mat = np.roll(ph, nshift).reshape(nsymb, nt)                               # reshape(...,NT,NSYMB)' : rows = symbols
+        for v in range(int(ipat.max()) + 1):                                       # :143-146
+            sel = mat[ipat == v]
+            if sel.size:
+                minv[:, v + 4 * p] = sel.min(0)
+                maxv[:, v + 4 * p] = sel.max(0)
+    eyeop = np.full((nt, 4 * npol), np.nan)
+    for p in range(npol):                                                          # :159-168
+        o = 4 * p
+        eyeop[:, o + 0] = minv[:, o + 2] - maxv[:, o + 0]
+        eyeop[:, o + 1] = minv[:, o + 1] - maxv[:, o + 3]
+        eyeop[:, o + 2] = minv[:, o + 3] - maxv[:, o + 2]
+        eyeop[:, o + 3] = minv[:, o + 0] - (maxv[:, o + 1] - 2 * math.pi)
+    xopt = int(_mround((ts + 0.5) * nt))                                           # :172 (1-based row)
+    eyeb = eyeop[xopt - 1].copy()
+    eyeb[eyeb < 0] = np.nan                                                        # :174
+    with np.errstate(invalid="ignore"):
+        ok = np.abs(eyeb - np.mod(eyeb, math.pi / 2)) < 1e-10                      # RxPdmCohQpsk.m:87
+    return float(np.min(eyeb[ok])) if ok.any() else float("nan")
+
+
+def _adc_numpy(irx, bits):
+    M = np.max(np.abs(irx))
+    q = (irx + M) / 2 / M * 2 ** bits
+    fl = np.floor(q)
+    return (fl + ((q - fl) >= 0.5)) * 2 * M / 2 ** bits - M                        # RxPdmCohQpsk.m:36-40
+
+
 def _mround(v):
     """MATLAB round (half away from zero)."""
     return math.floor(abs(v) + 0.5) * (1 if v >= 0 else -1)
@@ -333,9 +378,10 @@ def _mround(v):
 
 def RxPdmCohQpsk(chNum, symbolPattern, RxParams, rng=None):
     """[RxSamples, worsteyeop] = RxPdmCohQpsk(chNum, symbolPattern, RxParams)  RxPdmCohQpsk.m:3-87.
-    RxSamples: torch complex128 [nout, 1 or 2] on the GPU.  worsteyeop (the eye-opening diagnostic of
-    mygeteyeinfo, :139-166) is not evaluated on the device path and is returned as NaN.  RxParams.applydcf runs the
-    DispCompFilter response (:74-98) through the device FFT engine (sample counts that are powers of two >= 256)."""
+    RxSamples: torch complex128 [nout, 1 or 2] on the GPU.  worsteyeop: the eye-opening diagnostic of mygeteyeinfo
+    (:100-166, fixed x.ts, 'theory' delay), evaluated on the host from the downloaded photocurrents when RxParams has
+    'ts' (NaN otherwise).  RxParams.applydcf runs the DispCompFilter response (:74-98) through the device FFT engine
+    (sample counts that are powers of two >= 256)."""
     sp = np.asarray(symbolPattern)
     isy = GSTATE.FIELDY is not None and sp.ndim == 2 and sp.shape[1] != 1      # :27-33
     fr, shifts, info = rx_plan(chNum, RxParams, isy, 1, rng)
@@ -345,9 +391,17 @@ def RxPdmCohQpsk(chNum, symbolPattern, RxParams, rng=None):
     finally:
         fr.close()
     samples = out[0].transpose(0, 1).contiguous()
+    eye = float("nan")
+    if "ts" in RxParams and GSTATE.NSYMB * GSTATE.NT == ux.shape[1]:
+        cols = [ux[0].real, ux[0].imag] + ([uy[0].real, uy[0].imag] if fr.dual else [])   # ux/uy now hold the currents
+        import torch
+        cur = torch.stack(cols, 1).cpu().numpy()
+        if RxParams.get("applyadc"):
+            cur = _adc_numpy(cur, int(RxParams["adcbits"]))
+        eye = eye_opening(cur, sp, info["delay"], float(RxParams["ts"]))
     if RxParams.get("applydcf"):
         samples = _apply_dcf(samples, RxParams)                       # :74-84
-    return samples, float("nan")
+    return samples, eye
 
 
 def dsp4cohdec(ich, pat, x, p, rng=None):

@@ -1160,3 +1160,27 @@ def test_hot_path_multi_span_with_inline_amplifiers(lib, oracle):
     assert torch.equal(a[0][2], b[0][0]) and torch.equal(a[1][0], b[1][1])           # noise keyed by realisation, not position
     assert float((a[0][0] - a[0][1]).abs().max()) > 1e-3
     hp.close()
+
+
+def test_eye_opening_diagnostic_back_to_back(lib):
+    """worsteyeop (mygeteyeinfo, RxPdmCohQpsk.m:100-166, :87): noise-free back-to-back PDM-QPSK through the script's filters:
+    the phase eye at the symbol centre is open, below the ideal pi/2, and the same for dsp4cohdec."""
+    import polmux_amd as px
+    from polmux_amd import synth
+    from polmux_amd.gstate import GSTATE
+    nsymb, nt = 256, 32
+    px.reset_all(nsymb, nt, 1)
+    GSTATE.SYMBOLRATE = 10.0
+    E = px.lasersource(2.0, 1550.0)
+    sxp, bx = synth.pattern_debruijn(nsymb, 2, 4)
+    syp, by = synth.pattern_debruijn(nsymb, 3, 4)
+    el = [synth.electricsource_qpsk(b, nt, 1.0, 0.2) for b in (bx[:, 0], bx[:, 1], by[:, 0], by[:, 1])]
+    px.create_field("sepfields", synth.qi_modulator(E[:, 0], el[0], el[1]).reshape(-1, 1),
+                    synth.qi_modulator(E[:, 0], el[2], el[3]).reshape(-1, 1), dict(power="average"))
+    rp = _rx_params(nt, applyadc=False, baudrate=10.0, samplingrate=20.0)
+    rs, eye = px.RxPdmCohQpsk(1, np.stack([sxp, syp], 1), rp)
+    assert 0.6 < eye < np.pi / 2
+    rs8, eye8 = px.RxPdmCohQpsk(1, np.stack([sxp, syp], 1), dict(rp, applyadc=True, adcbits=4))
+    assert 0.3 < eye8 < eye                                          # a 4-bit ADC closes the phase eye a little
+    rs1, eye1 = px.RxPdmCohQpsk(1, sxp, rp)                          # one pattern column: X only (:27-33)
+    assert rs1.shape[1] == 1 and 0.6 < eye1 < np.pi / 2
