@@ -10,7 +10,8 @@ from .gstate import CONSTANTS, GSTATE, create_field, lasersource, reset_all  # n
 from .fiber import fiber  # noqa: F401
 from .ampliflat import ampliflat  # noqa: F401
 from .rx import (CDE_OFDE, DspPdmCohQpsk, cmaadaptivefilter, easiadaptivefilter, fastexp, samp2pat)  # noqa: F401
-from .rxfront import RxPdmCohQpsk, dsp4cohdec, evaldelay, myfilter, receiver_cohmix  # noqa: F401
+from .rxfront import (RxPdmCohQpsk, corrdelay, dsp4cohdec, evaldelay, eye_opening, myfilter,  # noqa: F401
+                      mygeteyeinfo, receiver_cohmix)
 from .pmdinv import inverse_pmd  # noqa: F401
 from .mc import ber_estimate, mc_estimate  # noqa: F401
 

@@ -271,8 +271,8 @@ def rx_plan(chNum, RxParams, isy, max_frames=1, rng=None):
         raise ValueError("Flag X.rec must be 'coherent'")
     hopt, elo, hel, post_delay, b2b = _front_tables(chNum, RxParams, rng)
     if RxParams.get("delay") != "theory" and "delay_symbols" not in RxParams:
-        raise NotImplementedError("delay estimation by correlation (corrdelay.m) is host-side diagnostics outside the "
-                                  "accelerated path: use RxParams.delay = 'theory'")
+        raise ValueError("a batched front-end plan needs its timing up front: RxParams.delay = 'theory' or "
+                         "RxParams.delay_symbols (RxPdmCohQpsk measures it with corrdelay for a single frame)")
     dual = GSTATE.FIELDY is not None
     npol = 2 if (dual and isy) else 1
     if "delay_symbols" in RxParams:
@@ -326,10 +326,57 @@ def _apply_dcf(samples, p):
     return rows.transpose(0, 1).contiguous()
 
 
-def eye_opening(irx, pat, delay, ts=0.0):
-    """worsteyeop of RxPdmCohQpsk.m:87 / dsp4cohdec.m:283 from mygeteyeinfo with a fixed sampling time x.ts and the
-    'theory' delay (RxPdmCohQpsk.m:100-166): phase eye of the photocurrents irx [Nfft x 2 or 4] (after the ADC), per
-    alphabet value, at sample xopt = round((ts+0.5)*NT).  Host diagnostic (O(Nfft) numpy on downloaded currents)."""
+_QPSK_PHASE = np.array([-0.75 * math.pi, 0.75 * math.pi, -0.25 * math.pi, 0.25 * math.pi])   # RxPdmCohQpsk.m:118-121
+
+
+def corrdelay(iric, pat, nt, nsymb, opt=None):
+    """[delay, wrn, rho, Iric] = corrdelay(Iric, pat, Nt, Nsymb, opt)  corrdelay.m:62-116 -- system delay in symbols from
+    the peak of the circular cross-correlation of the received current with the pattern held for Nt samples per
+    symbol.  opt='phase': Iric complex, pat the symbol phases; 36 trial rotations remove the phase ambiguity (:75-90)
+    and the 4th output is the angle of Iric moved next to the reference symbol.  Host diagnostic (numpy FFTs)."""
+    if opt not in (None, "phase"):
+        raise ValueError("wrong flag for opt.")
+    MINERR, MAXERR, NPHI = 1e-4, 0.5, 36
+    nfft = nsymb * nt
+    iric = np.asarray(iric).reshape(-1)
+    pat = np.asarray(pat, dtype=float).reshape(-1)
+    if iric.size != nfft or pat.size != nsymb:
+        raise ValueError("corrdelay: Iric must hold Nsymb*Nt samples and pat Nsymb symbols")
+    if opt == "phase":
+        ref = np.repeat(np.cos(pat) + 1j * np.sin(pat), nt)                        # every column of refsig, :76
+        phi = np.linspace(0, 2 * math.pi, NPHI)
+        rep = iric[:, None] * (np.cos(phi) + 1j * np.sin(phi))[None, :]            # :78
+        cc = np.real(np.fft.ifft(np.fft.fft(rep, axis=0) * np.conj(np.fft.fft(ref))[:, None], axis=0))
+        posc1 = np.argmax(cc, axis=0)                                              # :82-85 (first maximum, as MATLAB)
+        col = int(np.argmax(cc[posc1, np.arange(NPHI)]))
+        posc = int(posc1[col])
+        maxc = cc[posc, col]
+        out = np.angle(rep[:, col] * np.conj(ref)) + np.angle(ref)                 # :86-88
+        c = cc[:, col]
+    else:
+        ref = np.repeat(pat, nt)                                                   # :91
+        c = np.real(np.fft.ifft(np.fft.fft(iric) * np.conj(np.fft.fft(ref))))
+        posc = int(np.argmax(c))
+        maxc = c[posc]
+        out = iric
+    delay = float(posc)                                                            # nmod(posc,Nfft)-1, posc 1-based there
+    ii = np.nonzero(np.diff(np.sign(np.diff(c))) == -2)[0] + 1                     # interior maxima, :101
+    allmax = np.sort(c[ii])[::-1]
+    wrn = False
+    if allmax.size:
+        first = ii[np.argmax(c[ii])]
+        inderr = 1 if first == posc else 0                                         # :103-107
+        if inderr < allmax.size and allmax[inderr] > 0 and maxc > 0:
+            relerr = 10 * math.log10(maxc / allmax[inderr])
+            wrn = MINERR < relerr < MAXERR                                         # :108-111
+    return (delay + nt / 2) / nt, wrn, maxc / nfft * 2, out                        # :113-114
+
+
+def mygeteyeinfo(irx, pat, delay=None, ts=None):
+    """[eyeb, best_ts, delay, xopt] = mygeteyeinfo(ich, Iric, x, pat)  RxPdmCohQpsk.m:100-215 on the photocurrents irx
+    [Nfft x 2 or 4] (after the ADC).  delay: the 'theory' delay in symbols (scalar or per polarisation, :124-133), or None
+    -> measured by corrdelay(...,'phase') per polarisation (:134-137).  ts: fixed sampling time x.ts (:171-175), or None
+    -> the instant of the widest worst-case eye with the three-point parabolic refinement (:176-201)."""
     irx = np.asarray(irx, dtype=float)
     pat = np.asarray(pat)
     if pat.ndim == 1:
@@ -338,11 +385,17 @@ def eye_opening(irx, pat, delay, ts=0.0):
     npol = irx.shape[1] // 2
     minv = np.full((nt, 4 * npol), np.nan)
     maxv = np.full((nt, 4 * npol), np.nan)
-    delay = np.ones(npol) * np.asarray(delay, dtype=float)
+    dl = np.zeros(npol)
+    if delay is not None:
+        dl[:] = np.asarray(delay, dtype=float)
     for p in range(npol):
         ipat = pat[:, p].astype(int)
-        ph = np.angle(irx[:, 2 * p] + 1j * irx[:, 2 * p + 1])                       # Iric_t, :131-132
-        nshift = _mround(nt / 2 - delay[p] * nt)                                   # :139-141
+        cur = irx[:, 2 * p] + 1j * irx[:, 2 * p + 1]
+        if delay is None:
+            dl[p], _, _, ph = corrdelay(cur, _QPSK_PHASE[ipat], nt, nsymb, "phase")
+        else:
+            ph = np.angle(cur)                                                     # Iric_t, :131-132
+        nshift = _mround(nt / 2 - dl[p] * nt)                                      # :139-141
         mat = np.roll(ph, nshift).reshape(nsymb, nt)                               # reshape(...,NT,NSYMB)' : rows = symbols
         for v in range(int(ipat.max()) + 1):                                       # :143-146
             sel = mat[ipat == v]
@@ -356,12 +409,40 @@ def eye_opening(irx, pat, delay, ts=0.0):
         eyeop[:, o + 1] = minv[:, o + 1] - maxv[:, o + 3]
         eyeop[:, o + 2] = minv[:, o + 3] - maxv[:, o + 2]
         eyeop[:, o + 3] = minv[:, o + 0] - (maxv[:, o + 1] - 2 * math.pi)
-    xopt = int(_mround((ts + 0.5) * nt))                                           # :172 (1-based row)
-    eyeb = eyeop[xopt - 1].copy()
-    eyeb[eyeb < 0] = np.nan                                                        # :174
+    if ts is not None:
+        xopt = int(_mround((ts + 0.5) * nt))                                       # :172 (1-based row)
+        eyeb = eyeop[xopt - 1].copy()
+        eyeb[eyeb < 0] = np.nan                                                    # :174
+        return eyeb, float(ts), dl, float(xopt)
+    with np.errstate(all="ignore"):
+        worst = np.nanmin(eyeop, axis=1)                                           # :169
+    b = int(np.nanargmax(worst)) + 1                                               # best_tsn, 1-based (:177)
+    eyeb = eyeop[b - 1].copy()
+    if nt == 2:
+        return eyeb, b / nt - 0.5, dl, float(b)
+    to = (1, 2, 3) if b == 1 else ((b - 2, b - 1, b) if b == nt else (b - 1, b, b + 1))   # :183-189
+    w = [worst[k - 1] for k in to]
+    den = to[2] * (w[0] - w[1]) + to[0] * (w[1] - w[2]) + to[1] * (w[2] - w[0])
+    num = to[2] ** 2 * (w[0] - w[1]) + to[0] ** 2 * (w[1] - w[2]) + to[1] ** 2 * (w[2] - w[0])
+    with np.errstate(all="ignore"):
+        xopt = 0.5 * np.float64(num) / np.float64(den)                             # :191-193 (0/0 -> NaN as there)
+        l0 = (xopt - to[1]) * (xopt - to[2]) / ((to[0] - to[1]) * (to[0] - to[2]))
+        l1 = (xopt - to[0]) * (xopt - to[2]) / ((to[1] - to[0]) * (to[1] - to[2]))
+        l2 = (xopt - to[0]) * (xopt - to[1]) / ((to[2] - to[0]) * (to[2] - to[1]))
+        eyeb = l0 * eyeop[to[0] - 1] + l1 * eyeop[to[1] - 1] + l2 * eyeop[to[2] - 1]   # :195-199
+    return eyeb, float(xopt / nt - 0.5), dl, float(xopt)
+
+
+def _worst_eye(eyeb):
     with np.errstate(invalid="ignore"):
         ok = np.abs(eyeb - np.mod(eyeb, math.pi / 2)) < 1e-10                      # RxPdmCohQpsk.m:87
     return float(np.min(eyeb[ok])) if ok.any() else float("nan")
+
+
+def eye_opening(irx, pat, delay, ts=0.0):
+    """worsteyeop of RxPdmCohQpsk.m:87 / dsp4cohdec.m:283: the smallest of mygeteyeinfo's per-level phase-eye openings
+    that lies in [0, pi/2).  delay None -> corrdelay, ts None -> best sampling instant (see mygeteyeinfo)."""
+    return _worst_eye(mygeteyeinfo(irx, pat, delay, ts)[0])
 
 
 def _adc_numpy(irx, bits):
@@ -378,27 +459,51 @@ def _mround(v):
 
 def RxPdmCohQpsk(chNum, symbolPattern, RxParams, rng=None):
     """[RxSamples, worsteyeop] = RxPdmCohQpsk(chNum, symbolPattern, RxParams)  RxPdmCohQpsk.m:3-87.
-    RxSamples: torch complex128 [nout, 1 or 2] on the GPU.  worsteyeop: the eye-opening diagnostic of mygeteyeinfo
-    (:100-166, fixed x.ts, 'theory' delay), evaluated on the host from the downloaded photocurrents when RxParams has
-    'ts' (NaN otherwise).  RxParams.applydcf runs the DispCompFilter response (:74-98) through the device FFT engine
-    (sample counts that are powers of two >= 256)."""
+    RxSamples: torch complex128 [nout, 1 or 2] on the GPU.  The front end (hybrid, photodiodes, filters, ADC, timing,
+    decimation) runs on the device; mygeteyeinfo (:100-215) is a host diagnostic on the downloaded photocurrents.  With
+    RxParams.delay == 'theory' the timing is known up front and the eye is evaluated only on request (RxParams.ts, or
+    RxParams.evaleye for the best-instant search); otherwise the delay is MEASURED as the reference does (corrdelay on
+    the currents, :134-137): one device pass for the currents, the host correlation, a second pass with the timing.
+    RxParams.applydcf runs the DispCompFilter response (:74-98) through the device FFT engine (sample counts that are
+    powers of two >= 256)."""
+    import torch
     sp = np.asarray(symbolPattern)
     isy = GSTATE.FIELDY is not None and sp.ndim == 2 and sp.shape[1] != 1      # :27-33
+    measured = RxParams.get("delay") != "theory" and "delay_symbols" not in RxParams
+    ts = float(RxParams["ts"]) if "ts" in RxParams else None
+
+    def currents(fr, ux, uy):
+        cols = [ux[0].real, ux[0].imag] + ([uy[0].real, uy[0].imag] if fr.dual else [])   # ux/uy now hold the currents
+        cur = torch.stack(cols, 1).cpu().numpy()
+        if RxParams.get("applyadc"):
+            cur = _adc_numpy(cur, int(RxParams["adcbits"]))
+        return cur
+
+    eye = float("nan")
+    if measured:
+        if GSTATE.NSYMB * GSTATE.NT != GSTATE.FIELDX.shape[1]:
+            raise ValueError("corrdelay needs the whole NSYMB*NT frame")
+        rng = rng or np.random.default_rng()
+        state = rng.bit_generator.state                                # both passes see the same LO phase noise
+        fr, _, info = rx_plan(chNum, dict(RxParams, delay_symbols=0.0), isy, 1, rng)
+        rng.bit_generator.state = state
+        try:
+            ux, uy = _channel_fields(chNum, info["b2b"])
+            fr.run(ux, uy if fr.dual else None, [0] * (2 if fr.dual else 1))
+            eyeb, _, delay, _ = mygeteyeinfo(currents(fr, ux, uy), sp, None, ts)      # :41
+        finally:
+            fr.close()
+        eye = _worst_eye(eyeb)
+        RxParams = dict(RxParams, delay_symbols=delay)
     fr, shifts, info = rx_plan(chNum, RxParams, isy, 1, rng)
     try:
         ux, uy = _channel_fields(chNum, info["b2b"])
         out = fr.run(ux, uy if fr.dual else None, shifts)
+        if not measured and (ts is not None or RxParams.get("evaleye")) and GSTATE.NSYMB * GSTATE.NT == ux.shape[1]:
+            eye = eye_opening(currents(fr, ux, uy), sp, info["delay"], ts)
     finally:
         fr.close()
     samples = out[0].transpose(0, 1).contiguous()
-    eye = float("nan")
-    if "ts" in RxParams and GSTATE.NSYMB * GSTATE.NT == ux.shape[1]:
-        cols = [ux[0].real, ux[0].imag] + ([uy[0].real, uy[0].imag] if fr.dual else [])   # ux/uy now hold the currents
-        import torch
-        cur = torch.stack(cols, 1).cpu().numpy()
-        if RxParams.get("applyadc"):
-            cur = _adc_numpy(cur, int(RxParams["adcbits"]))
-        eye = eye_opening(cur, sp, info["delay"], float(RxParams["ts"]))
     if RxParams.get("applydcf"):
         samples = _apply_dcf(samples, RxParams)                       # :74-84
     return samples, eye
@@ -408,7 +513,7 @@ def dsp4cohdec(ich, pat, x, p, rng=None):
     """[Phases, Amplitudes, worsteyeop] = dsp4cohdec(ich, pat, x, p)  dsp4cohdec.m:100-282 -- Optilux's own coherent
     receiver + DSP (ex19/ex20): receiver_cohmix with the receiver struct x, ADC / timing / decimation with the DSP
     struct p (:121-160), then the DSP body that DspPdmCohQpsk shares with it (:212-282).  Phases/Amplitudes are torch
-    float64 [Nsymb, 1 or 2] on the GPU; worsteyeop is NaN (eye diagnostics are not evaluated on the device path)."""
+    float64 [Nsymb, 1 or 2] on the GPU; worsteyeop as RxPdmCohQpsk returns it."""
     import torch
     from .rx import DspPdmCohQpsk
     rxp = dict(x)

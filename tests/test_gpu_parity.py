@@ -1184,3 +1184,43 @@ def test_eye_opening_diagnostic_back_to_back(lib):
     assert 0.3 < eye8 < eye                                          # a 4-bit ADC closes the phase eye a little
     rs1, eye1 = px.RxPdmCohQpsk(1, sxp, rp)                          # one pattern column: X only (:27-33)
     assert rs1.shape[1] == 1 and 0.6 < eye1 < np.pi / 2
+
+
+def test_measured_delay_receiver_back_to_back(lib):
+    """RxPdmCohQpsk.m:41-44 without x.delay='theory': the timing comes from corrdelay on the device's photocurrents
+    (:134-137).  Back-to-back it agrees with the filters' theoretical delay to a sample, the samples are exactly those of
+    the same receiver handed that delay up front, and the best-instant eye search (no x.ts) reports an open eye."""
+    import torch
+    import polmux_amd as px
+    from polmux_amd import rxfront, synth
+    from polmux_amd.gstate import GSTATE
+    nsymb, nt = 256, 32
+    px.reset_all(nsymb, nt, 1)
+    GSTATE.SYMBOLRATE = 10.0
+    E = px.lasersource(2.0, 1550.0)
+    sxp, bx = synth.pattern_debruijn(nsymb, 2, 4)
+    syp, by = synth.pattern_debruijn(nsymb, 3, 4)
+    el = [synth.electricsource_qpsk(b, nt, 1.0, 0.2) for b in (bx[:, 0], bx[:, 1], by[:, 0], by[:, 1])]
+    px.create_field("sepfields", synth.qi_modulator(E[:, 0], el[0], el[1]).reshape(-1, 1),
+                    synth.qi_modulator(E[:, 0], el[2], el[3]).reshape(-1, 1), dict(power="average"))
+    pat = np.stack([sxp, syp], 1)
+    rp = _rx_params(nt, applyadc=True, adcbits=6, baudrate=10.0, samplingrate=20.0)
+    theory = rxfront.theory_delay(1, rp, True, 0.0)
+    cur, _ = px.receiver_cohmix(1, dict(rp))
+    eyeb, best_ts, delay, _ = px.mygeteyeinfo(cur.cpu().numpy(), pat, None, None)
+    assert np.all(np.abs((delay - theory + nsymb / 2) % nsymb - nsymb / 2) <= 1.0 / nt)
+    assert abs(best_ts) <= 2.0 / nt and 0.6 < np.min(eyeb) < np.pi / 2 + 1e-3
+    rpm = {k: v for k, v in rp.items() if k not in ("delay", "ts")}
+    rs_m, eye_m = px.RxPdmCohQpsk(1, pat, rpm)                                    # measured delay, best-instant eye
+    cur_adc = rxfront._adc_numpy(cur.cpu().numpy(), 6)
+    eyeb_a, _, delay_a, _ = px.mygeteyeinfo(cur_adc, pat, None, None)
+    rs_g, _ = px.RxPdmCohQpsk(1, pat, dict(rpm, delay_symbols=delay_a))
+    assert torch.equal(rs_m, rs_g)
+    assert eye_m == rxfront._worst_eye(eyeb_a) and 0.5 < eye_m < np.pi / 2
+    rs_t, eye_t = px.RxPdmCohQpsk(1, pat, dict(rp, evaleye=True, **{"ts": 0}))
+    assert float((rs_m - rs_t).abs().max()) < 0.35 * float(rs_t.abs().max())      # at most a sample of timing apart
+    x = {k: rpm[k] for k in ("rec", "oftype", "obw", "eftype", "ebw", "lopower")}
+    p = dict(sps=nt, workatbaudrate=False, applyadc=True, adcbits=6, samplingrate=20.0, applydcf=False, applynlr=False,
+             applypol=False, modorder=2, freqavg=500, phasavg=3, poworder=2)
+    ph, amp, eye_d = px.dsp4cohdec(1, pat, x, p)                                 # dsp4cohdec.m:524: the same corrdelay route
+    assert ph.shape == (nsymb, 2) and eye_d == eye_m

@@ -276,3 +276,72 @@ def test_pat_decoder_host_logic_matches_reference_text():
     np.testing.assert_array_equal(patterns.pat_decoder(np.array([0, 1, 1, 0]), "dpsk"), [1, 0, 1, 0])
     with pytest.raises(ValueError, match="wrong modulation format"):
         patterns.pat_decoder(pat, "nope")
+
+
+def test_corrdelay_recovers_delay_and_phase_ambiguity():
+    """corrdelay.m:62-116: binary route on a delayed NRZ current; 'phase' route on a delayed, rotated QPSK phasor."""
+    import polmux_amd as px
+    rng = np.random.default_rng(11)
+    nt, nsymb = 16, 256
+    bits = rng.integers(0, 2, nsymb).astype(float)
+    nrz = np.repeat(bits, nt)
+    for d in (0, 5, 37, nt * nsymb - 3):
+        cur = np.roll(nrz, d) + 0.05 * rng.standard_normal(nrz.size)
+        delay, wrn, rho, out = px.corrdelay(cur, bits, nt, nsymb)
+        assert delay == (d + nt / 2) / nt and not wrn and np.array_equal(out, cur)       # +Nt/2: the first bit is centred on sample 1
+        assert abs(rho - 2 * np.mean(bits)) < 0.05                        # maxc/Nfft*2 of a 0/1 signal
+    sym = rng.integers(0, 4, nsymb)
+    phases = np.array([-0.75, 0.75, -0.25, 0.25])[sym] * math.pi          # RxPdmCohQpsk.m:118-121
+    ref = np.repeat(np.exp(1j * phases), nt)
+    for d, rot in ((0, 0.0), (21, 0.9), (100, -2.4), (7, math.pi)):
+        cur = np.roll(ref, d) * np.exp(1j * rot) + 0.05 * (rng.standard_normal(ref.size) + 1j * rng.standard_normal(ref.size))
+        delay, wrn, rho, ang = px.corrdelay(cur, phases, nt, nsymb, "phase")
+        assert delay == (d + nt / 2) / nt
+        # 4th output: the angle next to the reference symbol, the rotation removed up to half a trial step (2*pi/35/2)
+        # (the representative is chosen next to the UNDELAYED reference, corrdelay.m:86-88: equal mod 2*pi otherwise)
+        err = np.roll(ang, -d) - np.angle(ref)
+        assert np.max(np.abs(np.angle(np.exp(1j * err)))) < math.pi / 35 + 0.25
+        assert np.max(np.abs(ang - np.angle(ref))) < math.pi + math.pi / 35 + 0.25
+        if d == 0:
+            assert np.max(np.abs(err)) < math.pi / 35 + 0.25
+        assert abs(rho - 2.0) < 0.05
+    with pytest.raises(ValueError, match="wrong flag"):
+        px.corrdelay(nrz, bits, nt, nsymb, "angle")
+    with pytest.raises(ValueError, match="Nsymb"):
+        px.corrdelay(nrz[:-1], bits, nt, nsymb)
+
+
+def test_mygeteyeinfo_best_instant_and_measured_delay():
+    """RxPdmCohQpsk.m:100-215: smooth QPSK currents delayed by a known amount: corrdelay finds the delay, the widest
+    eye sits at the symbol centre (best_ts ~ 0, parabolic refinement), a fixed x.ts reads the same table."""
+    import polmux_amd as px
+    from polmux_amd import synth
+    nt, nsymb = 16, 256
+    px.reset_all(nsymb, nt, 1)
+    pat, _ = synth.pattern_debruijn(nsymb, 1, 4)
+    pat2, _ = synth.pattern_debruijn(nsymb, 2, 4)
+    cols = []
+    d = nt // 2          # (within a symbol: corrdelay's 4th output is unwrapped next to the UNDELAYED reference, :86-88)
+    for p_ in (pat, pat2):
+        ph = np.array([-0.75, 0.75, -0.25, 0.25])[p_] * math.pi
+        e = np.repeat(np.exp(1j * ph), nt)
+        e = np.roll(e, -nt // 2)                                         # first symbol centred on sample 1
+        h = np.hanning(nt + 1); h /= h.sum()
+        e = np.fft.ifft(np.fft.fft(e) * np.fft.fft(np.roll(np.pad(h, (0, e.size - h.size)), -(nt // 2))))
+        e = np.roll(e, d)
+        cols += [e.real, e.imag]
+    irx = np.stack(cols, 1)
+    eyeb, best_ts, delay, xopt = px.mygeteyeinfo(irx, np.stack([pat, pat2], 1), None, None)
+    np.testing.assert_allclose(delay, d / nt, atol=1.0 / nt)
+    assert eyeb.shape == (8,) and abs(best_ts) < 1.5 / nt and 0.9 < np.min(eyeb) <= math.pi / 2 + 2e-3
+    eyef, ts, delay_f, xf = px.mygeteyeinfo(irx, np.stack([pat, pat2], 1), delay, 0.0)
+    assert ts == 0.0 and xf == nt / 2 and np.all(delay_f == delay)
+    assert np.nanmin(eyef) <= np.min(eyeb) + 1e-9                        # the refined optimum is at least as open
+    w = px.eye_opening(irx, np.stack([pat, pat2], 1), delay, 0.0)
+    assert w == np.nanmin(eyef[eyef < math.pi / 2]) and 0.9 < w < math.pi / 2
+    # a delay of several symbols is still measured (modulo the frame)
+    big = np.roll(irx, 5 * nt + 3, axis=0)
+    np.testing.assert_allclose(px.mygeteyeinfo(big, np.stack([pat, pat2], 1), None, None)[2], (d + 5 * nt + 3) / nt, atol=1e-12)
+    # X only
+    e1 = px.mygeteyeinfo(irx[:, :2], pat, None, None)
+    np.testing.assert_allclose(e1[0], eyeb[:4], atol=1e-12)
