@@ -57,7 +57,10 @@ int main()
     y = x + F * NS;
     hipMemset(x, 0, F * NS * sizeof(cplx) * 2);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    struct Cfg { const char *name; int narr, segc; size_t pitchc, framec; int tiles; } cfgs[] = {
+    struct Cfg { const char *name; int narr, segc; size_t pitchc, framec; int tiles; int nthr = 512; } cfgs[] = {
+        {"separate X,Y arrays, 64 B segments (W=4, tile 32 KiB: 4 WG/CU), 128 thr", 2, 4, (size_t)N2, NS, N2 / 4, 128},
+        {"separate X,Y arrays, 64 B segments (W=4, tile 32 KiB: 4 WG/CU), 256 thr", 2, 4, (size_t)N2, NS, N2 / 4, 256},
+        {"separate X,Y arrays, 128 B segments (W=8), 256 thr", 2, 8, (size_t)N2, NS, N2 / 8, 256},
         {"separate X,Y arrays, 128 B segments (W=8)", 2, 8, (size_t)N2, NS, N2 / 8},
         {"separate X,Y arrays, 256 B segments (W=16, tile 128 KiB: 1 WG/CU)", 2, 16, (size_t)N2, NS, N2 / 16},
         {"interleaved pols, 256 B segments (8 samples x 2 pols)", 1, 16, (size_t)2 * N2, 2 * NS, 2 * N2 / 16},
@@ -70,8 +73,8 @@ int main()
         float best = 1e9;
         for (int it = 0; it < 6; it++) {
             hipEventRecord(e0, 0);
-            if (c.narr == 2) hipLaunchKernelGGL(k_tile<2>, dim3(c.tiles, F), dim3(512), ldsb, 0, x, y, N1, c.segc, c.pitchc, c.framec);
-            else hipLaunchKernelGGL(k_tile<1>, dim3(c.tiles, F), dim3(512), ldsb, 0, x, x, N1, c.segc, c.pitchc, c.framec);
+            if (c.narr == 2) hipLaunchKernelGGL(k_tile<2>, dim3(c.tiles, F), dim3(c.nthr), ldsb, 0, x, y, N1, c.segc, c.pitchc, c.framec);
+            else hipLaunchKernelGGL(k_tile<1>, dim3(c.tiles, F), dim3(c.nthr), ldsb, 0, x, x, N1, c.segc, c.pitchc, c.framec);
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); if (it && ms < best) best = ms;
         }
