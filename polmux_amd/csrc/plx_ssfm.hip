@@ -170,15 +170,15 @@ __global__ __launch_bounds__(256) void k_umax(SsfmArgs a)
 // (:512-551, :585-636) and checkstep (:718-758), one lane per frame.
 // have_pmax: Pmax = max_k gam(k)*Umax(k) (fiber.m:694-698) is handed in by the caller (the fused sweep collects it from
 // the per-tile slots of its frame barrier) instead of being formed from the umax words.
-template <bool AGENT> __device__ __forceinline__ void ctrl_step(const SsfmArgs &a, int f, bool have_pmax = false, double pmax_in = 0.0)
+// ctrl_core works on a copy of the frame's record (the fused sweep keeps the leader's copy in LDS and publishes the
+// result before the record goes back to memory); ctrl_step is load -> ctrl_core -> store.
+template <bool AGENT> __device__ __forceinline__ void ctrl_core(const SsfmArgs &a, int f, FrameCtl &c, bool have_pmax, double pmax_in)
 {
-    FrameCtl c = a.ctl[f];
     if (c.done) return;
     if (c.started) {
         if (a.dual) c.ntot = c.ntot + c.ntrunk - c.nmem; // :529
         if (c.last) {
             c.done = 1;
-            a.ctl[f] = c;
             atomicAdd(a.ndone, 1);
             return;
         }
@@ -254,6 +254,12 @@ template <bool AGENT> __device__ __forceinline__ void ctrl_step(const SsfmArgs &
             }
         }
     }
+}
+template <bool AGENT> __device__ __forceinline__ void ctrl_step(const SsfmArgs &a, int f, bool have_pmax = false, double pmax_in = 0.0)
+{
+    FrameCtl c = a.ctl[f];
+    if (c.done) return;
+    ctrl_core<AGENT>(a, f, c, have_pmax, pmax_in);
     a.ctl[f] = c;
 }
 
@@ -1122,6 +1128,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     cplx *s = (cplx *)lds;                 // [256][16] exchange buffer
     cplx *tw = s + 4096;                   // W_256^k, k < 128
     double *red = (double *)(tw + 128);
+    FrameCtl *lctl = (FrameCtl *)(red + 32);
     lds_load_twiddles(tw, a.tw1, 128, tid, 256);
     cplx *const fld = (t < 8) ? a.ux : a.uy;
     const int colt = t & 7;
@@ -1133,6 +1140,8 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         bool started = false;
         if (cur) {
             started = a.ctl[f].started != 0;
+            // the frame's leader takes the step-control record along now: at barrier time it is one LDS read away
+            if (tid == 0 && tl % tiles_pf == 0) *lctl = a.ctl[f];
             cplx x[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = fld[cbase + (size_t)(16 * j + k) * N2];
@@ -1211,10 +1220,12 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                     pm = wave_max(pm);
                     for (int i = 1 + tid; i < tiles_pf; i += 64) st_agent(slots + i, ~0ull);
                     if (tid == 0) {
-                        ctrl_step<true>(a, f, true, pm);
-                        const double pv = a.ctl[f].done ? -1.0 : a.ctl[f].leff;
+                        FrameCtl cc = *lctl;
+                        ctrl_core<true>(a, f, cc, true, pm);
+                        const double pv = cc.done ? -1.0 : cc.leff;
                         st_agent(pubw + (par ^ 1u), ~0ull);
-                        st_agent_f64((double *)(pubw + par), pv);
+                        st_agent_f64((double *)(pubw + par), pv);    // the frame is released ...
+                        a.ctl[f] = cc;                               // ... before the record goes back (k_row reads it)
                         red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm;
                     }
                 }
@@ -1500,7 +1511,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     a.gam = P->d_gam; a.ctl = P->d_ctl; a.umax = P->d_umax; a.ndone = P->d_ndone; a.psum = P->d_psum;
     P->h_ctl.resize(F);
 
-    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double);
+    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double) + sizeof(FrameCtl);
     P->lds_row = ((size_t)(a.dual ? 2 : 1) * a.R * (N2 + N2 / 16) + N2 / 2) * sizeof(cplx);
     // persistent software-pipelined sweeps: measured 5-8 % slower than the plain grid on MI355X at
     // F = 256..1024 (profiles/), kept opt-in for experiments
