@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_umax(SsfmArgs a)
 // the per-tile slots of its frame barrier) instead of being formed from the umax words.
 // ctrl_core works on a copy of the frame's record (the fused sweep keeps the leader's copy in LDS and publishes the
 // result before the record goes back to memory); ctrl_step is load -> ctrl_core -> store.
-template <bool AGENT> __device__ __forceinline__ void ctrl_core(const SsfmArgs &a, int f, FrameCtl &c, bool have_pmax, double pmax_in)
+template <bool AGENT, class ARGS> __device__ __forceinline__ void ctrl_core(const ARGS &a, int f, FrameCtl &c, bool have_pmax, double pmax_in)
 {
     if (c.done) return;
     if (c.started) {
@@ -254,6 +254,22 @@ template <bool AGENT> __device__ __forceinline__ void ctrl_core(const SsfmArgs &
             }
         }
     }
+}
+// The fused sweep calls the controller OUT OF LINE (one lane of one workgroup per frame and launch): inlined, the libm
+// log / exp constants are hoisted into registers for the whole kernel and push the 16-point register blocks into scratch.
+struct CtrlK {
+    double dphimax, alphalin, dzmax, dz0, zdone0, Lf, lcorr;
+    int dual, resume, ncycle0, nfc;
+    int *ndone;
+    unsigned long long *umax;
+    const double *gam;
+};
+__device__ __noinline__ double ctrl_core_call(CtrlK k, int f, FrameCtl *rec, double pmax)
+{   // rec: the leader's copy (LDS).  Returns Leff of the next step, or -1 when the frame has reached the fibre end.
+    FrameCtl c = *rec;
+    ctrl_core<true>(k, f, c, true, pmax);
+    *rec = c;
+    return c.done ? -1.0 : c.leff;
 }
 template <bool AGENT> __device__ __forceinline__ void ctrl_step(const SsfmArgs &a, int f, bool have_pmax = false, double pmax_in = 0.0)
 {
@@ -1113,6 +1129,32 @@ template <int PF, int NT> __global__ __launch_bounds__(NT) void k_colx(SsfmArgs 
     }
 }
 
+// The rare full-range Kerr step of k_colx16 ('--s-' exact single step: |gamma Leff P| not small), on the tile parked in the
+// exchange buffer, one lane per polarisation pair.  Out of line for the same reason as ctrl_core_call: the argument
+// reduction constants of sincos must not live in the registers of the hot loop.
+__device__ __noinline__ void kerr_full_range(int j, int t, double gamleff, int manakov)
+{
+    PLX_DYN_LDS(lds);
+    cplx *s = (cplx *)lds;
+    for (int k = 0; k < 16; k++) {
+        cplx X = s[((j + 16 * k) << 4) + t], Y = s[((j + 16 * k) << 4) + t + 8];
+        const double P = X.x * X.x + X.y * X.y + Y.x * Y.x + Y.y * Y.y;
+        const cplx nl = cexpi(-gamleff * P);
+        X = cmul(X, nl);
+        Y = cmul(Y, nl);
+        if (!manakov) {
+            const double s3 = 2 * (X.x * Y.y - X.y * Y.x);
+            double sp, cp;
+            sincos(gamleff * s3 / 3, &sp, &cp);
+            const cplx xx = make_double2(cp * X.x + sp * Y.x, cp * X.y + sp * Y.y);
+            const cplx yy = make_double2(cp * Y.x - sp * X.x, cp * Y.y - sp * X.y);
+            X = xx; Y = yy;
+        }
+        s[((j + 16 * k) << 4) + t] = X;
+        s[((j + 16 * k) << 4) + t + 8] = Y;
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // k_colx16: the fused column sweep for the 256 x (8+8) tile with both column transforms held in
 // REGISTERS (16 points per thread, r16_* + lvl2_*256): per tile one LDS exchange per transform instead
@@ -1220,12 +1262,14 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                     pm = wave_max(pm);
                     for (int i = 1 + tid; i < tiles_pf; i += 64) st_agent(slots + i, ~0ull);
                     if (tid == 0) {
-                        FrameCtl cc = *lctl;
-                        ctrl_core<true>(a, f, cc, true, pm);
-                        const double pv = cc.done ? -1.0 : cc.leff;
+                        CtrlK ck;
+                        ck.dphimax = a.dphimax; ck.alphalin = a.alphalin; ck.dzmax = a.dzmax; ck.dz0 = a.dz0; ck.zdone0 = a.zdone0;
+                        ck.Lf = a.Lf; ck.lcorr = a.lcorr; ck.dual = a.dual; ck.resume = a.resume; ck.ncycle0 = a.ncycle0;
+                        ck.nfc = a.nfc; ck.ndone = a.ndone; ck.umax = a.umax; ck.gam = a.gam;
+                        const double pv = ctrl_core_call(ck, f, lctl, pm);
                         st_agent(pubw + (par ^ 1u), ~0ull);
                         st_agent_f64((double *)(pubw + par), pv);    // the frame is released ...
-                        a.ctl[f] = cc;                               // ... before the record goes back (k_row reads it)
+                        a.ctl[f] = *lctl;                            // ... before the record goes back (k_row reads it)
                         red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm;
                     }
                 }
@@ -1267,25 +1311,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
 #pragma unroll
                         for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
                         __syncthreads();
-                        if (isx) {
-                            for (int k = 0; k < 16; k++) {
-                                cplx X = s[((j + 16 * k) << 4) + t], Y = s[((j + 16 * k) << 4) + t + 8];
-                                const double P = X.x * X.x + X.y * X.y + Y.x * Y.x + Y.y * Y.y;
-                                const cplx nl = cexpi(-gamleff * P);
-                                X = cmul(X, nl);
-                                Y = cmul(Y, nl);
-                                if (!a.manakov) {
-                                    const double s3 = 2 * (X.x * Y.y - X.y * Y.x);
-                                    double sp, cp;
-                                    sincos(gamleff * s3 / 3, &sp, &cp);
-                                    const cplx xx = make_double2(cp * X.x + sp * Y.x, cp * X.y + sp * Y.y);
-                                    const cplx yy = make_double2(cp * Y.x - sp * X.x, cp * Y.y - sp * X.y);
-                                    X = xx; Y = yy;
-                                }
-                                s[((j + 16 * k) << 4) + t] = X;
-                                s[((j + 16 * k) << 4) + t + 8] = Y;
-                            }
-                        }
+                        if (isx) kerr_full_range(j, t, gamleff, a.manakov);
                         __syncthreads();
 #pragma unroll
                         for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
