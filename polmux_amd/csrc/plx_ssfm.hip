@@ -113,16 +113,13 @@ __device__ __forceinline__ void sincos_small(double a, double *s, double *c)
 
 // branch-free Taylor form (callers guarantee |a| < 2^-4)
 __device__ __forceinline__ void sincos_taylor(double a, double *s, double *c)
-{
+{   // |a| < 2^-4: the first neglected terms, a^11/11! and a^10/10!, are below 3e-20 and 3e-19 relative
     const double z = a * a;
-    double ps = fma(z, -1.0 / 39916800.0, 1.0 / 362880.0);
-    ps = fma(z, ps, -1.0 / 5040.0);
+    double ps = fma(z, 1.0 / 362880.0, -1.0 / 5040.0);
     ps = fma(z, ps, 1.0 / 120.0);
     ps = fma(z, ps, -1.0 / 6.0);
     *s = fma(a * z, ps, a);
-    double pc = fma(z, 1.0 / 479001600.0, -1.0 / 3628800.0);
-    pc = fma(z, pc, 1.0 / 40320.0);
-    pc = fma(z, pc, -1.0 / 720.0);
+    double pc = fma(z, 1.0 / 40320.0, -1.0 / 720.0);
     pc = fma(z, pc, 1.0 / 24.0);
     pc = fma(z, pc, -0.5);
     *c = fma(z, pc, 1.0);
@@ -1207,12 +1204,10 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 y[k] = cscale(y[k], sc);
-                // the other polarisation of the same sample lives in lane t^8
-                const cplx o = make_double2(lane_xchg<8>(y[k].x), lane_xchg<8>(y[k].y));
-                const cplx X = csel(isx, y[k], o), Y = csel(isx, o, y[k]);
-                double p = X.x * X.x + X.y * X.y;
-                p = p + Y.x * Y.x;
-                p = p + Y.y * Y.y;
+                // the other polarisation of the same sample lives in lane t^8: |ux|^2 + |uy|^2 from the two lanes' own
+                // powers (the same instructions on both, and a + b == b + a: the pair agrees to the bit)
+                const double po = fma(y[k].y, y[k].y, y[k].x * y[k].x);
+                const double p = po + lane_xchg<8>(po);
                 m = p > m ? p : m;
             }
             m = wave_max(m);
@@ -1286,26 +1281,30 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                     // |gamleff*P| <= gamleff * (tile maximum): a few mrad under the step controller, so the
                     // Taylor form applies to the whole tile; otherwise ('--s-' exact single step) the rare
                     // full-range path goes through LDS, one thread per polarisation pair.
+                    const double sgn = isx ? 1.0 : -1.0;
                     if (fabs(gamleff) * red[18] < 0.0625) {
 #pragma unroll
                         for (int k = 0; k < 16; k++) {
-                            const cplx o = make_double2(lane_xchg<8>(y[k].x), lane_xchg<8>(y[k].y));
-                            cplx X = csel(isx, y[k], o), Y = csel(isx, o, y[k]);
-                            const double P = X.x * X.x + X.y * X.y + Y.x * Y.x + Y.y * Y.y;
+                            // own / oth = this lane's and its partner's polarisation of the sample.  Everything the two
+                            // lanes both need (P, nl, s3, the rotation) is formed by the same instructions on the same
+                            // numbers in either lane, so the pair stays consistent to the bit without select chains.
+                            const cplx own = y[k], oth = make_double2(lane_xchg<8>(own.x), lane_xchg<8>(own.y));
+                            const double P = fma(own.y, own.y, own.x * own.x) + fma(oth.y, oth.y, oth.x * oth.x);
                             double sn, cs;
                             sincos_taylor(-gamleff * P, &sn, &cs);
                             const cplx nl = make_double2(cs, sn);
-                            X = cmul(X, nl);
-                            Y = cmul(Y, nl);
+                            cplx A = cmul(own, nl);
                             if (!a.manakov) {
-                                const double s3 = 2 * (X.x * Y.y - X.y * Y.x);
+                                const cplx B = cmul(oth, nl);
+                                // s3 = 2 (Re ux Im uy - Im ux Re uy) (:841-851): on the Y lane own/oth are swapped, the two
+                                // products swap and the difference changes sign exactly
+                                const double s3 = 2 * sgn * __dsub_rn(__dmul_rn(A.x, B.y), __dmul_rn(A.y, B.x));
                                 double sp, cp;
                                 sincos_taylor(gamleff * s3 / 3, &sp, &cp);
-                                const cplx xx = make_double2(cp * X.x + sp * Y.x, cp * X.y + sp * Y.y);
-                                const cplx yy = make_double2(cp * Y.x - sp * X.x, cp * Y.y - sp * X.y);
-                                X = xx; Y = yy;
+                                const double sg = sgn * sp;      // ux' = cp ux + sp uy,  uy' = cp uy - sp ux
+                                A = make_double2(cp * A.x + sg * B.x, cp * A.y + sg * B.y);
                             }
-                            y[k] = csel(isx, X, Y);
+                            y[k] = A;
                         }
                     } else {
 #pragma unroll

@@ -133,6 +133,8 @@ static inline int min(int a, int b) { return a < b ? a : b; }
 static inline int max(int a, int b) { return a > b ? a : b; }
 static inline long long __double_as_longlong(double d) { long long r; std::memcpy(&r, &d, 8); return r; }
 static inline double __longlong_as_double(long long l) { double r; std::memcpy(&r, &l, 8); return r; }
+static inline double __dmul_rn(double a, double b) { volatile double r = a * b; return r; }   // (never contracted into an fma)
+static inline double __dsub_rn(double a, double b) { volatile double r = a - b; return r; }
 
 // ---- runtime subset -------------------------------------------------------------
 static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "emu error"; }
