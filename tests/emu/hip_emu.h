@@ -36,6 +36,7 @@ struct int2 { int x, y; };
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 #define __restrict__
 
