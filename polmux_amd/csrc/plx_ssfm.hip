@@ -112,6 +112,14 @@ __device__ __forceinline__ void sincos_small(double a, double *s, double *c)
 }
 
 // branch-free Taylor form (callers guarantee |a| < 2^-4)
+// x / 3 (fiber.m:844 divides) without the ~20-instruction IEEE division sequence: one Newton correction of x * (1/3)
+// (Markstein: q = x*c, r = x - 3q exactly in an fma, q + r*c rounds like the quotient)
+__device__ __forceinline__ double div3(double x)
+{
+    const double c = 1.0 / 3.0;
+    const double q = x * c;
+    return fma(fma(-3.0, q, x), c, q);
+}
 __device__ __forceinline__ void sincos_taylor(double a, double *s, double *c)
 {   // |a| < 2^-4: the first neglected terms, a^11/11! and a^10/10!, are below 3e-20 and 3e-19 relative
     const double z = a * a;
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_fwd(SsfmArgs a)
                     if (!a.manakov) { // CNLSE rotation :842-850
                         const double s3 = 2 * (x.x * y.y - x.y * y.x);
                         double sp, cp;
-                        sincos_small(gamleff * s3 / 3, &sp, &cp);
+                        sincos_small(div3(gamleff * s3), &sp, &cp);
                         const cplx xx = make_double2(cp * x.x + sp * y.x, cp * x.y + sp * y.y);
                         const cplx yy = make_double2(cp * y.x - sp * x.x, cp * y.y - sp * x.y);
                         x = xx; y = yy;
@@ -787,7 +795,7 @@ template <int PF> __global__ __launch_bounds__(256) void k_col_fwd_p(SsfmArgs a,
                     if (!a.manakov) { // CNLSE rotation :842-850
                         const double s3 = 2 * (x.x * y.y - x.y * y.x);
                         double sp, cp;
-                        sincos_small(gamleff * s3 / 3, &sp, &cp);
+                        sincos_small(div3(gamleff * s3), &sp, &cp);
                         const cplx xx = make_double2(cp * x.x + sp * y.x, cp * x.y + sp * y.y);
                         const cplx yy = make_double2(cp * y.x - sp * x.x, cp * y.y - sp * x.y);
                         x = xx; y = yy;
@@ -1101,7 +1109,7 @@ template <int PF, int NT> __global__ __launch_bounds__(NT) void k_colx(SsfmArgs 
                     if (!a.manakov) {
                         const double s3 = 2 * (x.x * y.y - x.y * y.x);
                         double sp, cp;
-                        sincos_small(gamleff * s3 / 3, &sp, &cp);
+                        sincos_small(div3(gamleff * s3), &sp, &cp);
                         const cplx xx = make_double2(cp * x.x + sp * y.x, cp * x.y + sp * y.y);
                         const cplx yy = make_double2(cp * y.x - sp * x.x, cp * y.y - sp * x.y);
                         x = xx; y = yy;
@@ -1208,7 +1216,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                 // powers (the same instructions on both, and a + b == b + a: the pair agrees to the bit)
                 const double po = fma(y[k].y, y[k].y, y[k].x * y[k].x);
                 const double p = po + lane_xchg<8>(po);
-                m = p > m ? p : m;
+                m = fmax(p, m);
             }
             m = wave_max(m);
             if ((tid & 63) == 0) red[tid >> 6] = m;
@@ -1300,7 +1308,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                                 // products swap and the difference changes sign exactly
                                 const double s3 = 2 * sgn * __dsub_rn(__dmul_rn(A.x, B.y), __dmul_rn(A.y, B.x));
                                 double sp, cp;
-                                sincos_taylor(gamleff * s3 / 3, &sp, &cp);
+                                sincos_taylor(div3(gamleff * s3), &sp, &cp);
                                 const double sg = sgn * sp;      // ux' = cp ux + sp uy,  uy' = cp uy - sp ux
                                 A = make_double2(cp * A.x + sg * B.x, cp * A.y + sg * B.y);
                             }
