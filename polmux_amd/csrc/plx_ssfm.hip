@@ -269,10 +269,15 @@ struct CtrlK {
     unsigned long long *umax;
     const double *gam;
 };
-__device__ __noinline__ double ctrl_core_call(CtrlK k, int f, FrameCtl *rec, double pmax)
-{   // rec: the leader's copy (LDS).  Returns Leff of the next step, or -1 when the frame has reached the fibre end.
+__device__ __noinline__ double ctrl_core_call(double dphimax, double alphalin, double dzmax, double dz0, double zdone0, double Lf, double lcorr,
+                                              int dual_resume, int ncycle0, int *ndone, FrameCtl *rec, double pmax)
+{   // scalar arguments travel in registers (a by-value record goes through the stack).  rec: the leader's copy (LDS).
+    // Returns Leff of the next step, or -1 when the frame has reached the fibre end.
+    CtrlK k;
+    k.dphimax = dphimax; k.alphalin = alphalin; k.dzmax = dzmax; k.dz0 = dz0; k.zdone0 = zdone0; k.Lf = Lf; k.lcorr = lcorr;
+    k.dual = dual_resume & 1; k.resume = dual_resume >> 1; k.ncycle0 = ncycle0; k.nfc = 0; k.ndone = ndone; k.umax = nullptr; k.gam = nullptr;
     FrameCtl c = *rec;
-    ctrl_core<true>(k, f, c, true, pmax);
+    ctrl_core<true>(k, 0, c, true, pmax);
     *rec = c;
     return c.done ? -1.0 : c.leff;
 }
@@ -1265,11 +1270,8 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                     pm = wave_max(pm);
                     for (int i = 1 + tid; i < tiles_pf; i += 64) st_agent(slots + i, ~0ull);
                     if (tid == 0) {
-                        CtrlK ck;
-                        ck.dphimax = a.dphimax; ck.alphalin = a.alphalin; ck.dzmax = a.dzmax; ck.dz0 = a.dz0; ck.zdone0 = a.zdone0;
-                        ck.Lf = a.Lf; ck.lcorr = a.lcorr; ck.dual = a.dual; ck.resume = a.resume; ck.ncycle0 = a.ncycle0;
-                        ck.nfc = a.nfc; ck.ndone = a.ndone; ck.umax = a.umax; ck.gam = a.gam;
-                        const double pv = ctrl_core_call(ck, f, lctl, pm);
+                        const double pv = ctrl_core_call(a.dphimax, a.alphalin, a.dzmax, a.dz0, a.zdone0, a.Lf, a.lcorr,
+                                                         (a.dual ? 1 : 0) | (a.resume ? 2 : 0), a.ncycle0, a.ndone, lctl, pm);
                         st_agent(pubw + (par ^ 1u), ~0ull);
                         st_agent_f64((double *)(pubw + par), pv);    // the frame is released ...
                         a.ctl[f] = *lctl;                            // ... before the record goes back (k_row reads it)
