@@ -35,8 +35,8 @@ SSFM_BYTES_PER_SAMPLE_STEP = 272.0   # 4 sweeps x (32 R + 32 W) + 1
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1024, help="frames per GPU per step")
     ap.add_argument("--nsymb", type=int, default=1024)
     ap.add_argument("--nt", type=int, default=64)
