@@ -21,11 +21,9 @@
 
 __device__ __forceinline__ cplx tw3(const cplx *tw, int k3, int halfM)
 { // W^{k3}, k3 < 3M/4, from the half table: W^{k+M/2} = -W^k
-    if (k3 >= halfM) {
-        cplx w = tw[k3 - halfM];
-        return make_double2(-w.x, -w.y);
-    }
-    return tw[k3];
+    const cplx w = tw[k3 & (halfM - 1)];      // (halfM is a power of two, k3 < 3 halfM / 2: one load, no divergent branch)
+    const bool neg = k3 >= halfM;
+    return make_double2(neg ? -w.x : w.x, neg ? -w.y : w.y);
 }
 
 // T = 1<<logT transforms of length M = 1<<logM.  Caller has synchronised the data
@@ -186,7 +184,7 @@ __device__ __forceinline__ void lvl2_dit256(cplx *y, int j, const cplx *tw)
 #pragma unroll
     for (int r2 = 0; r2 < 4; r2++) { // m = 64
         cplx c0 = y[4 * r2], c2 = y[4 * r2 + 1], c1 = y[4 * r2 + 2], c3 = y[4 * r2 + 3];
-        if (j) { c1 = cmulc(c1, u1); c2 = cmulc(c2, u2); c3 = cmulc(c3, u3); }
+        c1 = cmulc(c1, u1); c2 = cmulc(c2, u2); c3 = cmulc(c3, u3);   // (W^0 = 1 for j = 0: no divergent guard, one basic block)
         const cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
         y[4 * r2] = cadd(s0, s2); y[4 * r2 + 1] = cadd(s1, s3); y[4 * r2 + 2] = csub(s0, s2); y[4 * r2 + 3] = csub(s1, s3);
     }
@@ -194,7 +192,7 @@ __device__ __forceinline__ void lvl2_dit256(cplx *y, int j, const cplx *tw)
     for (int r1 = 0; r1 < 4; r1++) { // m = 256
         const int k8 = j + 16 * r1;
         cplx c0 = y[r1], c2 = y[r1 + 4], c1 = y[r1 + 8], c3 = y[r1 + 12];
-        if (k8) { c1 = cmulc(c1, tw[k8]); c2 = cmulc(c2, tw[2 * k8]); c3 = cmulc(c3, tw3(tw, 3 * k8, 128)); }
+        c1 = cmulc(c1, tw[k8]); c2 = cmulc(c2, tw[2 * k8]); c3 = cmulc(c3, tw3(tw, 3 * k8, 128));
         const cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
         y[r1] = cadd(s0, s2); y[r1 + 4] = cadd(s1, s3); y[r1 + 8] = csub(s0, s2); y[r1 + 12] = csub(s1, s3);
     }
@@ -207,7 +205,7 @@ __device__ __forceinline__ void lvl2_dif256(cplx *y, int j, const cplx *tw)
         const cplx a0 = y[r1], a1 = y[r1 + 4], a2 = y[r1 + 8], a3 = y[r1 + 12];
         const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
         cplx y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
-        if (k8) { y1 = cmul(y1, tw[k8]); y2 = cmul(y2, tw[2 * k8]); y3 = cmul(y3, tw3(tw, 3 * k8, 128)); }
+        y1 = cmul(y1, tw[k8]); y2 = cmul(y2, tw[2 * k8]); y3 = cmul(y3, tw3(tw, 3 * k8, 128));
         y[r1] = cadd(t0, t2); y[r1 + 4] = y2; y[r1 + 8] = y1; y[r1 + 12] = y3;
     }
     const int k6 = 4 * j;
@@ -217,7 +215,7 @@ __device__ __forceinline__ void lvl2_dif256(cplx *y, int j, const cplx *tw)
         const cplx a0 = y[4 * r2], a1 = y[4 * r2 + 1], a2 = y[4 * r2 + 2], a3 = y[4 * r2 + 3];
         const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
         cplx y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
-        if (j) { y1 = cmul(y1, u1); y2 = cmul(y2, u2); y3 = cmul(y3, u3); }
+        y1 = cmul(y1, u1); y2 = cmul(y2, u2); y3 = cmul(y3, u3);
         y[4 * r2] = cadd(t0, t2); y[4 * r2 + 1] = y2; y[4 * r2 + 2] = y1; y[4 * r2 + 3] = y3;
     }
 }
@@ -251,11 +249,9 @@ __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const c
             cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
             const int k = j << sh;
             cplx y0 = cadd(t0, t2), y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
-            if (k) {
-                y1 = cmul(y1, tw[k]);
-                y2 = cmul(y2, tw[2 * k]);
-                y3 = cmul(y3, tw3(tw, 3 * k, halfM));
-            }
+            y1 = cmul(y1, tw[k]);      // (no guard for k = 0: it diverges inside every wave and splits the basic block)
+            y2 = cmul(y2, tw[2 * k]);
+            y3 = cmul(y3, tw3(tw, 3 * k, halfM));
             p[0] = y0; p[qs] = y2; p[2 * qs] = y1; p[3 * qs] = y3;
         }
         __syncthreads();
@@ -304,11 +300,9 @@ __device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const c
             cplx *p = s + t * TSp + row_phys(base);
             cplx c0 = p[0], c2 = p[qs], c1 = p[2 * qs], c3 = p[3 * qs];
             const int k = j << sh;
-            if (k) {
-                c1 = cmulc(c1, tw[k]);
-                c2 = cmulc(c2, tw[2 * k]);
-                c3 = cmulc(c3, tw3(tw, 3 * k, halfM));
-            }
+            c1 = cmulc(c1, tw[k]);
+            c2 = cmulc(c2, tw[2 * k]);
+            c3 = cmulc(c3, tw3(tw, 3 * k, halfM));
             cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
             p[0] = cadd(s0, s2); p[qs] = cadd(s1, s3); p[2 * qs] = csub(s0, s2); p[3 * qs] = csub(s1, s3);
         }
