@@ -24,6 +24,7 @@
 // lock-step launches while every frame keeps the reference's own step sequence.
 #include "../../include/polmux_hip.h"
 #include "plx_fft.h"
+#include <type_traits>
 #include "plx_internal.h"
 
 #include <cmath>
@@ -519,6 +520,15 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     // in registers for the conjugate multiply on the way out
     const bool keep_tw = nel == nthr * ROW_CH;
     cplx tkeep[ROW_CH];
+    // ... and so does beta of its ROW_CH bins when the multiplier is the step's plain exp(-i beta dz): the (L2-resident)
+    // table reads travel with the tile loads instead of sitting, one after the other, between the two transforms
+    const double *bt = a.betat_p + (size_t)c * N + rowbase;
+    const bool fastmul = keep_tw && a.dual && !a.pmd && !a.umat && !a.hmul && !(a.dbg & 8);
+    double btk[ROW_CH];
+    if (fastmul) {
+#pragma unroll
+        for (int k = 0; k < ROW_CH; k++) btk[k] = bt[tid + k * nthr];
+    }
     for (int e0 = tid; e0 < nel; e0 += nthr * ROW_CH) {
         cplx tv[ROW_CH], xv[ROW_CH], yv[ROW_CH];
 #pragma unroll
@@ -544,7 +554,6 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     __syncthreads();
     if (!(a.dbg & 2)) row_fft_dif(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     const double cur = a.force ? a.f_cur : ctl->cur;
-    const double *bt = a.betat_p + (size_t)c * N + rowbase;
     if (!a.dual) {
         for (int e = tid; e < nel; e += nthr) { // Hf = fastexp(-betat*dz) :771
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
@@ -552,18 +561,38 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         }
     } else if (!a.pmd) {
         // zero birefringence, one trunk (fiber.m:291-297): matR = I, deltabeta = 0
-        for (int e = tid; e < nel; e += nthr) {
-            const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-            if (a.umat) { // Uinv = conj(Hgvd) [conj(U11) -U12; conj(U12) U11] applied to [x; y]  (inverse_pmd.m:130-141)
+        // (one loop per kind of multiplier: the step's exp(-i beta dz) loop stays a single basic block)
+        if (a.umat) { // Uinv = conj(Hgvd) [conj(U11) -U12; conj(U12) U11] applied to [x; y]  (inverse_pmd.m:130-141)
+            for (int e = tid; e < nel; e += nthr) {
+                const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
                 const cplx *um = a.umat + 3 * ((size_t)f * N + rowbase + e);
                 const cplx u11 = um[0], u12 = um[1], hg = um[2], x = s[o], y = s[o + R * TSp];
                 s[o] = cmulc(csub(cmulc(x, u11), cmul(u12, y)), hg);
                 s[o + R * TSp] = cmulc(cadd(cmulc(x, u12), cmul(u11, y)), hg);
-                continue;
             }
-            const cplx h = a.hmul ? a.hmul[rowbase + e] : (a.dbg & 8) ? make_double2(1.0, bt[e]) : cexp_neg_turns(bt[e] * cur);
-            s[o] = cmul(h, s[o]);
-            s[o + R * TSp] = cmul(h, s[o + R * TSp]);
+        } else if (a.hmul || (a.dbg & 8)) {
+            for (int e = tid; e < nel; e += nthr) {
+                const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+                const cplx h = a.hmul ? a.hmul[rowbase + e] : make_double2(1.0, bt[e]);
+                s[o] = cmul(h, s[o]);
+                s[o + R * TSp] = cmul(h, s[o + R * TSp]);
+            }
+        } else if (fastmul) {
+#pragma unroll
+            for (int k = 0; k < ROW_CH; k++) {
+                const int e = tid + k * nthr;
+                const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+                const cplx h = cexp_neg_turns(btk[k] * cur);
+                s[o] = cmul(h, s[o]);
+                s[o + R * TSp] = cmul(h, s[o + R * TSp]);
+            }
+        } else {
+            for (int e = tid; e < nel; e += nthr) {
+                const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
+                const cplx h = cexp_neg_turns(bt[e] * cur);
+                s[o] = cmul(h, s[o]);
+                s[o + R * TSp] = cmul(h, s[o + R * TSp]);
+            }
         }
     } else {
         const double *d1 = a.db1_p + (size_t)c * N + rowbase;
@@ -1293,6 +1322,9 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                     // full-range path goes through LDS, one thread per polarisation pair.
                     const double sgn = isx ? 1.0 : -1.0;
                     if (fabs(gamleff) * red[18] < 0.0625) {
+                        // (one loop per equation: a uniform branch inside the unrolled body would cut it into 32 basic blocks)
+                        auto kerr16 = [&](auto cn) {
+                            constexpr bool CNLSE = decltype(cn)::value;
 #pragma unroll
                         for (int k = 0; k < 16; k++) {
                             // own / oth = this lane's and its partner's polarisation of the sample.  Everything the two
@@ -1304,7 +1336,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                             sincos_taylor(-gamleff * P, &sn, &cs);
                             const cplx nl = make_double2(cs, sn);
                             cplx A = cmul(own, nl);
-                            if (!a.manakov) {
+                            if (CNLSE) {
                                 const cplx B = cmul(oth, nl);
                                 // s3 = 2 (Re ux Im uy - Im ux Re uy) (:841-851): on the Y lane own/oth are swapped, the two
                                 // products swap and the difference changes sign exactly
@@ -1316,6 +1348,8 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                             }
                             y[k] = A;
                         }
+                        };
+                        if (a.manakov) kerr16(std::false_type{}); else kerr16(std::true_type{});
                     } else {
 #pragma unroll
                         for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
