@@ -20,7 +20,7 @@ out.append("## Cross-check with bench.py's live HIP-event measurement (same conf
 out.append("* bench.py: fibre %.1f ms per step (HIP events on the launch stream) = %.3f ms per step-launch over %d launches, roofline.achieved %.0f GB/s (272 B x sample-steps / fibre time), frac %.3f, traffic %.3g B per step-launch (PMC, r01_traffic.json)" % (
     d["config"]["fibre_ms_per_step"], d["roofline"]["ms_per_step_launch"], d["roofline"]["launches"], d["roofline"]["achieved"], d["roofline"]["frac"], d["roofline"]["traffic"]))
 out.append("* kernel trace: k_colx16 + k_row total %.1f ms over 3 batches (1 warm-up + 2 timed) = %.1f ms per batch = %.3f ms per step-launch (76 launches per batch); the HIP-event figure adds k_umax, the launch gaps of the chunked loop and, in the default run, the receiver of the previous batch sharing the GPU on its own stream." % (tot, tot / 3, tot / 3 / 76))
-out.append("* one active launch processes F x nfft = 1024 x 65536 dual-pol samples; per SSFM step the two kernels move 130.7 B per sample (PMC) against the SURVEY's 272 B accounting.\n")
+out.append("* one active launch processes F x nfft = 1024 x 65536 dual-pol samples; per SSFM step the two kernels move ~129 B per sample (PMC, profiles/r01_traffic.json) against the SURVEY's 272 B accounting.\n")
 open(os.path.join(R, "profiles", "r01_final_kernel_trace.md"), "w").write("\n".join(out))
 lines = [open(os.path.join(F, "bench_%s.json" % n)).read().strip().splitlines()[-1] for n in ("default", "cohmix", "mc")]
 open(os.path.join(R, "profiles", "r01_final_bench.jsonl"), "w").write("\n".join(lines) + "\n")

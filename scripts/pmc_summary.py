@@ -9,6 +9,7 @@ for k, cs in agg.items():
     if not k.startswith("k_"): continue
     out = []
     for c, v in sorted(cs.items()):
-        top = sorted(v)[len(v) // 2:]        # upper half = active launches
+        top = [x for x in v if x >= 0.5 * max(v)] or v   # active launches: at least half of the largest (the chunked loop
+                                                         # also issues launches that return at once)
         out.append("%s=%.4g" % (c, sum(top) / len(top)))
     print(k, " ".join(out))
