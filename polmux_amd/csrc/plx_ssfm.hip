@@ -1226,8 +1226,6 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             cplx x[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = fld[cbase + (size_t)(16 * j + k) * N2];
-#pragma unroll
-            for (int k = 0; k < 16; k++) pin(x[k]);
             if (started) r16_dit(x);       // rows 16j .. 16j+15 of the (bit-reversed) column spectrum
 #pragma unroll
             for (int k = 0; k < 16; k++) s[((16 * j + k) << 4) + t] = x[k];
