@@ -472,6 +472,7 @@ __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_fwd(SsfmArgs a)
 __device__ __forceinline__ void pmd_trunks(cplx &x, cplx &y, double btf, double d1f, const double *brf, int nplates, int n0, int ntrunk,
                                            double dzb_first, double dzb_last, double lcorr, double dz_total)
 {
+    const double rl = 1.0 / lcorr;          // x / lcorr as x*rl with one Newton correction (rounds like the quotient; see div3)
     for (int k = 1; k <= ntrunk; k++) {
         int plate = n0 + k - 1; // the reference indexes brf.theta(n) unchecked; stay in bounds
         plate = plate < 0 ? 0 : (plate >= nplates ? nplates - 1 : plate);
@@ -479,7 +480,8 @@ __device__ __forceinline__ void pmd_trunks(cplx &x, cplx &y, double btf, double 
         const double s11 = m[0];
         const cplx s12 = make_double2(m[1], m[2]);
         const double dzk = (k == 1) ? dzb_first : (k == ntrunk ? dzb_last : lcorr);
-        const double deltabeta = 0.5 * (d1f + m[3]) * dzk / lcorr;              // :925 (turns)
+        const double num = 0.5 * (d1f + m[3]) * dzk, q0 = num * rl;
+        const double deltabeta = fma(fma(-lcorr, q0, num), rl, q0);            // = num / lcorr, :925 (turns)
         const cplx e = cexp_neg_turns(deltabeta);                               // (cos b, -sin b)
         const cplx sx = cadd(cscale(x, s11), cmul(s12, y));                     // S u
         const cplx sy = csub(cmulc(x, s12), cscale(y, s11));
