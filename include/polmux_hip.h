@@ -87,12 +87,20 @@ int plx_ssfm_set_birefringence_dev(plx_ssfm *plan, const double *db0, const doub
 /* Propagate nframes frames in place.  d_ux/d_uy: device, interleaved complex128,
  * layout [frame][channel][nfft]; d_uy NULL for a scalar plan.  Asynchronous on
  * `stream` except for the bounded polling of the data-dependent step loop: the call
- * returns when every frame has reached the fibre end.  Dual-polarisation plans with
- * 256-row column tiles use a fused sweep whose workgroups of one frame meet at a
- * barrier and must be co-resident: do not overlap two propagate calls (two host
- * threads, two plans) on one device -- batch the frames into one call instead; a
- * barrier that cannot complete is reported as PLX_ERR_HIP, and PLX_SSFM_NO_FUSE=1
- * selects the barrier-free sweeps.                                                  */
+ * returns when every frame has reached the fibre end.
+ * A plan is NOT re-entrant: it owns the per-call step-control state, so ONE propagate
+ * (or filter) call may be in flight per plan; different plans may run from different
+ * host threads / streams.
+ * Dual-polarisation plans with 256-row column tiles use a fused sweep (k_colx16) whose
+ * workgroups of one frame meet at a barrier inside the launch.  Its grid is sized at
+ * plan creation from hipOccupancyMaxActiveBlocksPerMultiprocessor for that kernel, so
+ * the frame's workgroups are co-resident on a GPU the process has to itself; when the
+ * frame does not fit the chip that way the plan takes the barrier-free three-sweep
+ * step.  If another long-running kernel holds the device (two processes on one GPU, a
+ * second plan propagating at the same time), a barrier that cannot complete within
+ * 0.5 s raises a sticky abort: nothing is stored or advanced after it and the call
+ * returns PLX_ERR_HIP ("frame barrier timed out"); PLX_SSFM_NO_FUSE=1 at plan creation
+ * selects the barrier-free sweeps for such deployments.                             */
 int plx_ssfm_propagate_dev(plx_ssfm *plan, double *d_ux, double *d_uy, int nframes, void *stream);
 /* per-frame results of the last propagate: firstdz, ncycle (fiber.m:431)           */
 int plx_ssfm_results(plx_ssfm *plan, int nframes, double *firstdz, int32_t *ncycle);

@@ -117,6 +117,7 @@ __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long 
 __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { emu_atomic_store_u64(p, v); }
 __device__ __forceinline__ void drain_vmem() {}
 __device__ __forceinline__ void nap() { std::this_thread::yield(); }
+__device__ __forceinline__ long long plx_clock() { return (long long)(emu_now_ms() * 1e5); }   // 10 ns ticks
 #else
 __device__ __forceinline__ unsigned ld_agent(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -124,6 +125,8 @@ __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long 
 __device__ __forceinline__ void st_agent(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void nap() { __builtin_amdgcn_s_sleep(4); }
+// constant-rate wall clock (100 MHz on gfx950: 10 ns ticks), for time-based spin limits
+__device__ __forceinline__ long long plx_clock() { return (long long)wall_clock64(); }
 #endif
 __device__ __forceinline__ double ld_agent_f64(const double *p) { return __longlong_as_double((long long)ld_agent((const unsigned long long *)p)); }
 __device__ __forceinline__ void st_agent_f64(double *p, double v) { st_agent((unsigned long long *)p, (unsigned long long)__double_as_longlong(v)); }

@@ -3,11 +3,10 @@
 // Reference: /root/reference/fiber.m:459-935 (matrix_ssfm, scalar_ssfm, nextstep,
 // checkstep, lin_step, nl_step, matrix_nl_step, matrix_step).
 //
-// MI355X design (not a translation of the MATLAB): one SSFM step is THREE sweeps
-// over the field, organised around a four-step FFT  N = N1 x N2  whose forward
-// half is decimation-in-frequency and whose inverse half is decimation-in-time,
-// so the spectrum is only ever held in (bit-reversed, transposed) order and no
-// reorder pass exists:
+// MI355X design (not a translation of the MATLAB): the field stays in HBM, a step is two or three
+// sweeps over it, organised around a four-step FFT  N = N1 x N2  whose forward half is
+// decimation-in-frequency and whose inverse half is decimation-in-time, so the spectrum is only
+// ever held in (bit-reversed, transposed) order and no reorder pass exists:
 //
 //   k_col_fwd  load N1 x 16 column tile -> [Kerr step fused on load] -> N1-point
 //              DIF in LDS -> store in place
@@ -18,10 +17,15 @@
 //              wave-shuffle max of |ux|^2+|uy|^2 -> one atomicMax per workgroup
 //   k_ctrl     one lane per frame: nextstep + checkstep + last-step rule; the
 //              data-dependent step loop never round-trips to the host
+//   k_colx16   dual-polarisation plans with 256-row tiles: k_col_inv of step s, the step
+//              controller and k_col_fwd of step s+1 in ONE launch on a register-resident
+//              tile (the step is then two sweeps), the tiles of a frame meeting at a barrier
 //
 // Twiddles of the in-LDS transforms are staged in LDS; frames of a batch carry
 // their own step state, so a batch of Monte-Carlo realisations advances in
 // lock-step launches while every frame keeps the reference's own step sequence.
+// (Variants that were measured and lost -- persistent prefetching sweeps, register-blocked rows,
+// an LDS-resident fused sweep -- live in the history and in profiles/r01_notes.md, not here.)
 #include "../../include/polmux_hip.h"
 #include "plx_fft.h"
 #include <type_traits>
@@ -59,10 +63,8 @@ struct SsfmArgs {
     double *psum;                  // [F][N] row-sum of channel powers (scalar XPM, :795)
     FrameCtl *ctl;
     unsigned long long *umax;      // [F][nfc] bit pattern of max |u|^2 (>= 0)
-    int *ndone;
-    unsigned *arrive, *epoch;      // [F] frame barrier of the fused column sweep (tickets / completed rounds)
-    double *pub;                   // [F][2] words published inside a launch: leff, done flag
-    int *syncerr;                  // set if a frame barrier timed out
+    int *ndone;                    // [0] frames that have reached the fibre end, [1] sticky abort word (a frame barrier timed out)
+    long long spin_ticks;          // frame-barrier timeout in ticks of plx_clock() (10 ns)
     unsigned long long *slots;     // [F][tiles per frame] per-tile max |u|^2 of the current round (k_colx16), ~0 = not arrived
     unsigned long long *pubw;      // [F][2] published Leff (or -1: frame finished) of the round, by launch parity, ~0 = not yet
     int round;                     // launch index of the fused sweep within this propagate call
@@ -76,7 +78,6 @@ struct SsfmArgs {
     // resume the constant-phase loop after an adaptive first step (tolflag == 1, fiber.m:588-611)
     int resume, ncycle0;
     double dz0, zdone0;
-    int dbg; // timing experiments only (PLX_SSFM_DBG): 1 skip column FFTs, 2 skip row FFTs, 4 skip Kerr math, 8 skip exp(-i beta dz)
     double alphalin, Lf, dzmax, dphimax, lcorr, invN;
 };
 
@@ -88,6 +89,10 @@ __device__ __forceinline__ double wave_max(double v)
     }
     return v;
 }
+
+// Every kernel of the step loop returns at once when all frames of the call are done, or after a frame barrier of the
+// fused sweep has timed out (sticky: nothing is stored or advanced any more, the host reports the error).
+template <class ARGS> __device__ __forceinline__ bool all_done_or_aborted(const ARGS &a) { return a.ndone[0] >= a.nframes || a.ndone[1] != 0; }
 
 // exp(i a) for the Kerr step.  The step controller bounds |a| by dphimax (fiber.m:699), a few
 // mrad, so the Taylor branch (|a| < 2^-4, truncation < 1e-25, ~1 ulp) is the one that runs;
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(256) void k_rowsum(SsfmArgs a)
 __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_fwd(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
-    if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
+    if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
     const FrameCtl *ctl = a.ctl + f;
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_fwd(SsfmArgs a)
                 const int e = e0 + k * nthr;
                 if (e >= nel) continue;
                 cplx x = xv[k], y = yv[k];
-                if (a.spm && !(a.dbg & 4)) {
+                if (a.spm) {
                     const double P = x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y; // :834-835
                     double sn, cs;
                     sincos_small(-gamleff * P, &sn, &cs);                             // :837
@@ -453,7 +458,7 @@ __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_fwd(SsfmArgs a)
         }
     }
     __syncthreads();
-    if (!(a.dbg & 1)) lds_fft_dif(s, a.p1, T, 1, a.logT, tw, tid, nthr, true);
+    lds_fft_dif(s, a.p1, T, 1, a.logT, tw, tid, nthr, true);
     for (int e = tid; e < nel; e += nthr) {
         const int row = e >> a.logW, col = e & (W - 1);
         const size_t g = base + (size_t)row * N2 + col0 + col;
@@ -503,7 +508,7 @@ __device__ __forceinline__ void pmd_trunks(cplx &x, cplx &y, double btf, double 
 __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
-    if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
+    if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
     const FrameCtl *ctl = a.ctl + f;
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     // ... and so does beta of its ROW_CH bins when the multiplier is the step's plain exp(-i beta dz): the (L2-resident)
     // table reads travel with the tile loads instead of sitting, one after the other, between the two transforms
     const double *bt = a.betat_p + (size_t)c * N + rowbase;
-    const bool fastmul = keep_tw && a.dual && !a.pmd && !a.umat && !a.hmul && !(a.dbg & 8);
+    const bool fastmul = keep_tw && a.dual && !a.pmd && !a.umat && !a.hmul;
     double btk[ROW_CH];
     if (fastmul) {
 #pragma unroll
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         }
     }
     __syncthreads();
-    if (!(a.dbg & 2)) row_fft_dif(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
+    row_fft_dif(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     const double cur = a.force ? a.f_cur : ctl->cur;
     if (!a.dual) {
         for (int e = tid; e < nel; e += nthr) { // Hf = fastexp(-betat*dz) :771
@@ -572,10 +577,10 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
                 s[o] = cmulc(csub(cmulc(x, u11), cmul(u12, y)), hg);
                 s[o + R * TSp] = cmulc(cadd(cmulc(x, u12), cmul(u11, y)), hg);
             }
-        } else if (a.hmul || (a.dbg & 8)) {
+        } else if (a.hmul) {
             for (int e = tid; e < nel; e += nthr) {
                 const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-                const cplx h = a.hmul ? a.hmul[rowbase + e] : make_double2(1.0, bt[e]);
+                const cplx h = a.hmul[rowbase + e];
                 s[o] = cmul(h, s[o]);
                 s[o + R * TSp] = cmul(h, s[o + R * TSp]);
             }
@@ -610,7 +615,7 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         }
     }
     __syncthreads();
-    if (!(a.dbg & 2)) row_fft_dit(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
+    row_fft_dit(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     if (keep_tw) {
 #pragma unroll
         for (int k = 0; k < ROW_CH; k++) {
@@ -629,98 +634,13 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     }
 }
 
-// ----------------------------------------------- pass 2, register-blocked (N2 = 256) ---
-// The row pass for 256-point rows with every transform level in registers: thread (j, t) owns points
-// j + 16k of transform t (t = pol*R + r), loads them straight from HBM (16 lanes = 256 contiguous bytes),
-// runs lvl2_dif256, exchanges ONCE through LDS (padded: lane stride 17 slots), finishes with r16_dif,
-// applies exp(-i beta dz) at the 16 bit-reversed bins it holds, and goes back the same way: 4 LDS
-// passes instead of 16.  One workgroup = ONE wave (2 rows x 2 polarisations x 16 lanes), so its barriers are
-// free; the two polarisations take turns in the exchange buffer (10.7 KiB of LDS).  Opt-in (PLX_SSFM_ROW16=1):
-// the 16 complex128 points + twiddles + butterfly temporaries need ~200 VGPRs per lane, i.e. 2 waves per SIMD;
-// at that occupancy it only matches k_row (41.7 vs 40.4 ms per 256-frame pass), and capping the registers for 3
-// or 4 waves per SIMD spills (57 ms) -- profiles/r01_notes.md.  Dual-polarisation plans without PMD (the
-// waveplate loop needs both polarisations of a bin in one thread: k_row).
-#define ROW16_R 2
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_row16(SsfmArgs a)
-{
-    PLX_DYN_LDS(lds);
-    if (*a.ndone >= a.nframes) return;
-    const int tid = threadIdx.x, j = tid & 15, t = tid >> 4;
-    const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
-    const FrameCtl *ctl = a.ctl + f;
-    if (ctl->done) return;
-    const int pol = t >> 1, r = t & 1;
-    cplx *s = (cplx *)lds;                       // [ROW16_R][272], used by polarisation 0 then 1
-    cplx *tw = s + (size_t)ROW16_R * 272;        // W_256^k, k < 128
-    lds_load_twiddles(tw, a.tw2, 128, tid, 64);
-    const size_t N = (size_t)1 << (a.p1 + a.p2);
-    const size_t rowoff = ((size_t)blockIdx.x * ROW16_R + r) << 8;   // row start inside the frame
-    cplx *const u = (pol ? a.uy : a.ux) + (size_t)fc * N + rowoff;
-    const cplx *const tp = a.tpass + rowoff;
-    cplx x[16];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {                // two batches of 8 + 8 loads keep the register file at 128
-        cplx xv[8], tv[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { xv[k] = u[j + 16 * (8 * h + k)]; tv[k] = tp[j + 16 * (8 * h + k)]; }
-#pragma unroll
-        for (int k = 0; k < 8; k++) { pin(xv[k]); pin(tv[k]); }
-#pragma unroll
-        for (int k = 0; k < 8; k++) x[8 * h + k] = cmul(xv[k], tv[k]);
-    }
-    __syncthreads();                             // twiddles staged
-    lvl2_dif256(x, j, tw);
-    cplx *const st = s + r * 272;
-#pragma unroll
-    for (int p = 0; p < 2; p++) {                // exchange: write points j+16k, read block j
-        if (pol == p) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) st[j + 17 * k] = x[k];      // row_phys(j + 16k)
-        }
-        __syncthreads();
-        if (pol == p) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = st[17 * j + k];      // block j: points 16j .. 16j+15
-        }
-        __syncthreads();
-    }
-    r16_dif(x);
-    {
-        const double cur = a.force ? a.f_cur : ctl->cur;
-        int o16 = 16 * j;
-        pin(o16);
-        const double *bt = a.betat_p + (size_t)c * N + rowoff + o16;
-#pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = cmul(cexp_neg_turns(bt[k] * cur), x[k]);   // :927-928 with matR = I
-    }
-    r16_dit(x);
-#pragma unroll
-    for (int p = 0; p < 2; p++) {
-        if (pol == p) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) st[17 * j + k] = x[k];
-        }
-        __syncthreads();
-        if (pol == p) {
-#pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = st[j + 17 * k];
-        }
-        __syncthreads();
-    }
-    lvl2_dit256(x, j, tw);
-    int jo = j;
-    pin(jo);
-#pragma unroll
-    for (int k = 0; k < 16; k++) u[jo + 16 * k] = cmulc(x[k], tp[jo + 16 * k]);
-}
-
 // ------------------------------------------------------ pass 3: inverse columns ---
 // Completes ifft (1/N), applies the attenuation of the step (:531-532) and feeds
 // nextstep's global maximum (:694-696) -- no extra pass over the field.
 __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_inv(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
-    if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
+    if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int fc = blockIdx.y, f = fc / a.nfc;
     const FrameCtl *ctl = a.ctl + f;
@@ -756,7 +676,7 @@ __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_inv(SsfmArgs a)
         }
     }
     __syncthreads();
-    if (!(a.dbg & 1)) lds_fft_dit(s, a.p1, T, 1, a.logT, tw, tid, nthr, true);
+    lds_fft_dit(s, a.p1, T, 1, a.logT, tw, tid, nthr, true);
     const double sc = a.force ? a.f_sc : ctl->att * a.invN;
     double m = 0;
     for (int e = tid; e < nel; e += nthr) {
@@ -774,400 +694,6 @@ __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_inv(SsfmArgs a)
         m = p > m ? p : m;
     }
     block_atomic_max(m, red, a.umax + fc, tid, nthr);
-}
-
-// ============================================================================
-// Persistent, software-pipelined forms of the three sweeps (dual-polarisation plans).
-// A workgroup walks over tiles (tile index += gridDim.x); while it transforms tile k out
-// of LDS, the global loads of tile k+1 are already in flight into registers (PF complex
-// per polarisation per thread), so HBM streaming overlaps the LDS/VALU phases instead of
-// alternating with them.  Chosen when the tile size matches PF x blockDim exactly; the
-// kernels above stay as the general form.
-template <int PF> __global__ __launch_bounds__(256) void k_col_fwd_p(SsfmArgs a, int tiles_x, int total)
-{
-    PLX_DYN_LDS(lds);
-    if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
-    const int tid = threadIdx.x;
-    const int N1 = 1 << a.p1, N2 = 1 << a.p2, T = a.T, W = a.W;
-    cplx *s = (cplx *)lds;
-    cplx *tw = s + ((size_t)N1 << a.logT);
-    lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, 256);
-    cplx xv[PF], yv[PF];
-    int tl = blockIdx.x;
-    bool have = false;
-    size_t gbase = 0;
-    auto issue = [&](int t) {
-        const int fc = t / tiles_x, bx = t - fc * tiles_x, f = fc / a.nfc;
-        have = !a.ctl[f].done;
-        gbase = ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * W;
-        if (have) {
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int e = tid + k * 256;
-                const size_t g = gbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
-                xv[k] = a.ux[g]; yv[k] = a.uy[g];
-            }
-        }
-    };
-    if (tl < total) issue(tl);
-    while (tl < total) {
-        const bool cur = have;
-        const size_t cbase = gbase;
-        if (cur) {
-            const int fc = tl / tiles_x, f = fc / a.nfc, c = fc - f * a.nfc;
-            const double gamleff = a.gam[c] * a.ctl[f].leff;
-#pragma unroll
-            for (int k = 0; k < PF; k++) { pin(xv[k]); pin(yv[k]); }
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                cplx x = xv[k], y = yv[k];
-                if (a.spm && !(a.dbg & 4)) {
-                    const double P = x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y; // :834-835
-                    double sn, cs;
-                    sincos_small(-gamleff * P, &sn, &cs);                             // :837
-                    const cplx nl = make_double2(cs, sn);
-                    x = cmul(x, nl);
-                    y = cmul(y, nl);
-                    if (!a.manakov) { // CNLSE rotation :842-850
-                        const double s3 = 2 * (x.x * y.y - x.y * y.x);
-                        double sp, cp;
-                        sincos_small(div3(gamleff * s3), &sp, &cp);
-                        const cplx xx = make_double2(cp * x.x + sp * y.x, cp * x.y + sp * y.y);
-                        const cplx yy = make_double2(cp * y.x - sp * x.x, cp * y.y - sp * x.y);
-                        x = xx; y = yy;
-                    }
-                }
-                const int e = tid + k * 256;
-                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
-                s[o] = x;
-                s[o + W] = y;
-            }
-        }
-        __syncthreads();
-        const int nxt = tl + gridDim.x;
-        if (nxt < total) issue(nxt); else have = false;
-        if (cur) {
-            if (!(a.dbg & 1)) lds_fft_dif(s, a.p1, T, 1, a.logT, tw, tid, 256, true);
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int e = tid + k * 256;
-                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
-                const size_t g = cbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
-                a.ux[g] = s[o];
-                a.uy[g] = s[o + W];
-            }
-        }
-        __syncthreads();
-        tl = nxt;
-    }
-}
-
-template <int PF> __global__ __launch_bounds__(256) void k_col_inv_p(SsfmArgs a, int tiles_x, int total)
-{
-    PLX_DYN_LDS(lds);
-    if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
-    const int tid = threadIdx.x;
-    const int N1 = 1 << a.p1, N2 = 1 << a.p2, T = a.T, W = a.W;
-    cplx *s = (cplx *)lds;
-    cplx *tw = s + ((size_t)N1 << a.logT);
-    double *red = (double *)(tw + (N1 >> 1));
-    lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, 256);
-    cplx xv[PF], yv[PF];
-    int tl = blockIdx.x;
-    bool have = false;
-    size_t gbase = 0;
-    auto issue = [&](int t) {
-        const int fc = t / tiles_x, bx = t - fc * tiles_x, f = fc / a.nfc;
-        have = !a.ctl[f].done;
-        gbase = ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * W;
-        if (have) {
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int e = tid + k * 256;
-                const size_t g = gbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
-                xv[k] = a.ux[g]; yv[k] = a.uy[g];
-            }
-        }
-    };
-    if (tl < total) issue(tl);
-    while (tl < total) {
-        const bool cur = have;
-        const size_t cbase = gbase;
-        if (cur) {
-#pragma unroll
-            for (int k = 0; k < PF; k++) { pin(xv[k]); pin(yv[k]); }
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int e = tid + k * 256;
-                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
-                s[o] = xv[k];
-                s[o + W] = yv[k];
-            }
-        }
-        __syncthreads();
-        const int nxt = tl + gridDim.x;
-        if (nxt < total) issue(nxt); else have = false;
-        if (cur) {
-            const int fc = tl / tiles_x, f = fc / a.nfc;
-            if (!(a.dbg & 1)) lds_fft_dit(s, a.p1, T, 1, a.logT, tw, tid, 256, true);
-            const double sc = a.ctl[f].att * a.invN;
-            double m = 0;
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int e = tid + k * 256;
-                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
-                const size_t g = cbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
-                const cplx x = cscale(s[o], sc), y = cscale(s[o + W], sc);
-                double p = x.x * x.x + x.y * x.y;
-                p = p + y.x * y.x;
-                p = p + y.y * y.y;
-                a.ux[g] = x;
-                a.uy[g] = y;
-                m = p > m ? p : m;
-            }
-            block_atomic_max(m, red, a.umax + fc, tid, 256); // contains a barrier
-        }
-        __syncthreads();
-        tl = nxt;
-    }
-}
-
-template <int PF> __global__ __launch_bounds__(ROW_THREADS) void k_row_p(SsfmArgs a, int tiles_x, int total)
-{
-    PLX_DYN_LDS(lds);
-    if (*a.ndone >= a.nframes) return; // every frame of this call has reached the fibre end
-    const int tid = threadIdx.x;
-    const int N2 = 1 << a.p2, R = a.R, TSp = row_pitch(N2);
-    cplx *s = (cplx *)lds;
-    cplx *tw = s + (size_t)2 * R * TSp;
-    lds_load_twiddles(tw, a.tw2, N2 >> 1, tid, ROW_THREADS);
-    const size_t N = (size_t)1 << (a.p1 + a.p2);
-    cplx tv[PF], xv[PF], yv[PF];
-    int tl = blockIdx.x;
-    bool have = false;
-    size_t gbase = 0, rbase = 0;
-    auto issue = [&](int t) {
-        const int fc = t / tiles_x, bx = t - fc * tiles_x, f = fc / a.nfc;
-        have = !a.ctl[f].done;
-        rbase = (size_t)bx * R * N2;
-        gbase = (size_t)fc * N + rbase;
-        if (have) {
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int e = tid + k * ROW_THREADS;
-                tv[k] = a.tpass[rbase + e];
-                xv[k] = a.ux[gbase + e];
-                yv[k] = a.uy[gbase + e];
-            }
-        }
-    };
-    if (tl < total) issue(tl);
-    while (tl < total) {
-        const bool cur = have;
-        const size_t cg = gbase, cr = rbase;
-        if (cur) {
-#pragma unroll
-            for (int k = 0; k < PF; k++) { pin(tv[k]); pin(xv[k]); pin(yv[k]); }
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int e = tid + k * ROW_THREADS;
-                const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-                s[o] = cmul(xv[k], tv[k]);
-                s[o + R * TSp] = cmul(yv[k], tv[k]);
-            }
-        }
-        __syncthreads();
-        const int nxt = tl + gridDim.x;
-        if (nxt < total) issue(nxt); else have = false;
-        if (cur) {
-            const int fc = tl / tiles_x, f = fc / a.nfc, c = fc - f * a.nfc;
-            const FrameCtl *ctl = a.ctl + f;
-            if (!(a.dbg & 2)) row_fft_dif(s, a.p2, a.logR + 1, tw, tid, ROW_THREADS);
-            const double curdz = ctl->cur;
-            const double *bt = a.betat_p + (size_t)c * N + cr;
-            if (!a.pmd) {
-#pragma unroll
-                for (int k = 0; k < PF; k++) {
-                    const int e = tid + k * ROW_THREADS;
-                    const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-                    const cplx h = (a.dbg & 8) ? make_double2(1.0, bt[e]) : cexp_neg_turns(bt[e] * curdz);
-                    s[o] = cmul(h, s[o]);
-                    s[o + R * TSp] = cmul(h, s[o + R * TSp]);
-                }
-            } else {
-                const double *d1 = a.db1_p + (size_t)c * N + cr;
-                const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * BRF_STRIDE : 0);
-                const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem;
-                const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last, lcorr = a.lcorr;
-                for (int k = 0; k < PF; k++) {
-                    const int e = tid + k * ROW_THREADS;
-                    const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-                    cplx x = s[o], y = s[o + R * TSp];
-                    pmd_trunks(x, y, bt[e], d1[e], brf, a.nplates, n0, ntrunk, dzb_first, dzb_last, lcorr, curdz);
-                    s[o] = x;
-                    s[o + R * TSp] = y;
-                }
-            }
-            __syncthreads();
-            if (!(a.dbg & 2)) row_fft_dit(s, a.p2, a.logR + 1, tw, tid, ROW_THREADS);
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int e = tid + k * ROW_THREADS;
-                const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-                const cplx t = a.tpass[cr + e];
-                a.ux[cg + e] = cmulc(s[o], t);
-                a.uy[cg + e] = cmulc(s[o + R * TSp], t);
-            }
-        }
-        __syncthreads();
-        tl = nxt;
-    }
-}
-
-// ============================================================================
-// Fused column sweep: inverse column transform of step s, the step controller, and the Kerr step +
-// forward column transform of step s+1 on the SAME LDS-resident tile -- one read and one write of the
-// field instead of two (the step is then 2 sweeps: 128 B of HBM traffic per dual-pol sample).
-// The only obstacle is nextstep's maximum over the whole frame (fiber.m:694-698): the tiles of one
-// frame are therefore handled by workgroups that are resident at the same time (persistent grid, a
-// multiple of tiles-per-frame and at most the chip's residency) and meet at a per-frame barrier:
-// ticket counter -> the last arriver runs ctrl_step and publishes (Leff, done) -> the others poll one
-// word.  All shared words use agent-scope atomics (CDNA guide G16); the next tile's loads are already
-// in flight while a workgroup waits.  Spins are bounded; a timeout raises an error on the host.
-template <int PF, int NT> __global__ __launch_bounds__(NT) void k_colx(SsfmArgs a, int tiles_x, int tiles_pf, int total)
-{
-    PLX_DYN_LDS(lds);
-    if (*a.ndone >= a.nframes) return;
-    const int tid = threadIdx.x;
-    const int N1 = 1 << a.p1, N2 = 1 << a.p2, T = a.T, W = a.W;
-    cplx *s = (cplx *)lds;
-    cplx *tw = s + ((size_t)N1 << a.logT);
-    double *red = (double *)(tw + (N1 >> 1)); // [16] + broadcast slots [16..19]
-    lds_load_twiddles(tw, a.tw1, N1 >> 1, tid, NT);
-    cplx xv[PF], yv[PF];
-    int tl = blockIdx.x;
-    bool have = false;
-    size_t gbase = 0;
-    auto issue = [&](int t) {
-        const int fc = t / tiles_x, bx = t - fc * tiles_x, f = fc / a.nfc;
-        have = !a.ctl[f].done;
-        gbase = ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * W;
-        if (have) {
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int e = tid + k * NT;
-                const size_t g = gbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
-                xv[k] = a.ux[g]; yv[k] = a.uy[g];
-            }
-        }
-    };
-    if (tl < total) issue(tl);
-    while (tl < total) {
-        const bool cur = have;
-        const size_t cbase = gbase;
-        const int fc = tl / tiles_x, f = fc / a.nfc, c = fc - f * a.nfc;
-        if (cur) {
-#pragma unroll
-            for (int k = 0; k < PF; k++) { pin(xv[k]); pin(yv[k]); }
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int e = tid + k * NT;
-                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
-                s[o] = xv[k];
-                s[o + W] = yv[k];
-            }
-        }
-        __syncthreads();
-        const int nxt = tl + gridDim.x;
-        if (nxt < total) issue(nxt); else have = false;
-        if (cur) {
-            const bool started = a.ctl[f].started != 0;
-            double sc = 1.0;
-            if (started) { // finish step s: ifft (1/N) and attenuation (:531-532)
-                if (!(a.dbg & 1)) lds_fft_dit(s, a.p1, T, 1, a.logT, tw, tid, NT, true);
-                sc = a.ctl[f].att * a.invN;
-            }
-            double m = 0;
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int e = tid + k * NT;
-                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
-                const cplx x = cscale(s[o], sc), y = cscale(s[o + W], sc);
-                double p = x.x * x.x + x.y * x.y;
-                p = p + y.x * y.x;
-                p = p + y.y * y.y;
-                s[o] = x;
-                s[o + W] = y;
-                m = p > m ? p : m;
-            }
-            m = wave_max(m);
-            if ((tid & 63) == 0) red[tid >> 6] = m;
-            __syncthreads();
-            if (tid == 0) {
-                double mm = red[0];
-                for (int w = 1; w < NT / 64; w++) mm = red[w] > mm ? red[w] : mm;
-                const unsigned long long prev = atomicMax(a.umax + fc, (unsigned long long)__double_as_longlong(mm));
-                unsigned ticket = 0;
-                if (prev != ~0ull) ticket = atomicAdd(a.arrive + f, 1u); // (prev used: the max has completed first)
-                const unsigned round = ticket / (unsigned)tiles_pf + 1;
-                if ((ticket + 1) % (unsigned)tiles_pf == 0) { // last arriver of the frame: step controller
-                    ctrl_step<true>(a, f);
-                    st_agent_f64(a.pub + 2 * f, a.ctl[f].leff);
-                    st_agent_f64(a.pub + 2 * f + 1, a.ctl[f].done ? 1.0 : 0.0);
-                    drain_vmem();
-                    st_agent(a.epoch + f, round);
-                } else {
-                    unsigned spins = 0;
-                    while (ld_agent(a.epoch + f) < round && !(a.dbg & 16)) {
-                        nap();
-                        if (++spins > (1u << 21)) { atomicAdd(a.syncerr, 1); break; }
-                    }
-                }
-                red[16] = ld_agent_f64(a.pub + 2 * f);
-                red[17] = ld_agent_f64(a.pub + 2 * f + 1);
-            }
-            __syncthreads();
-            const double leff = red[16];
-            const bool finished = red[17] != 0.0;
-            if (!finished && a.spm && !(a.dbg & 4)) { // Kerr step of step s+1 on the resident tile (:832-852)
-                const double gamleff = a.gam[c] * leff;
-#pragma unroll
-                for (int k = 0; k < PF; k++) {
-                    const int e = tid + k * NT;
-                    const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
-                    cplx x = s[o], y = s[o + W];
-                    const double P = x.x * x.x + x.y * x.y + y.x * y.x + y.y * y.y;
-                    double sn, cs;
-                    sincos_small(-gamleff * P, &sn, &cs);
-                    const cplx nl = make_double2(cs, sn);
-                    x = cmul(x, nl);
-                    y = cmul(y, nl);
-                    if (!a.manakov) {
-                        const double s3 = 2 * (x.x * y.y - x.y * y.x);
-                        double sp, cp;
-                        sincos_small(div3(gamleff * s3), &sp, &cp);
-                        const cplx xx = make_double2(cp * x.x + sp * y.x, cp * x.y + sp * y.y);
-                        const cplx yy = make_double2(cp * y.x - sp * x.x, cp * y.y - sp * x.y);
-                        x = xx; y = yy;
-                    }
-                    s[o] = x;
-                    s[o + W] = y;
-                }
-            }
-            __syncthreads();
-            if (!finished && !(a.dbg & 1)) lds_fft_dif(s, a.p1, T, 1, a.logT, tw, tid, NT, true);
-#pragma unroll
-            for (int k = 0; k < PF; k++) {
-                const int e = tid + k * NT;
-                const int o = ((e >> a.logW) << a.logT) + (e & (W - 1));
-                const size_t g = cbase + (size_t)(e >> a.logW) * N2 + (e & (W - 1));
-                a.ux[g] = s[o];
-                a.uy[g] = s[o + W];
-            }
-        }
-        __syncthreads();
-        tl = nxt;
-    }
 }
 
 // The rare full-range Kerr step of k_colx16 ('--s-' exact single step: |gamma Leff P| not small), on the tile parked in the
@@ -1205,7 +731,7 @@ __device__ __noinline__ void kerr_full_range(int j, int t, double gamleff, int m
 __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf, int total)
 {
     PLX_DYN_LDS(lds);
-    if (*a.ndone >= a.nframes) return;
+    if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, t = tid & 15, j = tid >> 4;
     const int N2 = 1 << a.p2;
     cplx *s = (cplx *)lds;                 // [256][16] exchange buffer
@@ -1272,18 +798,26 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                         st_agent(slots + ti, (unsigned long long)__double_as_longlong(mm));
                         unsigned long long v = ~0ull;
                         unsigned spins = 0;
+                        bool dead = false;
+                        const long long t0 = plx_clock();
                         while ((v = ld_agent(pubw + par)) == ~0ull) {
                             nap();
-                            if (++spins > (1u << 21)) { atomicAdd(a.syncerr, 1); v = (unsigned long long)__double_as_longlong(-1.0); break; }
+                            if ((++spins & 255u) == 0 && (ld_agent((const unsigned *)a.ndone + 1) != 0 || plx_clock() - t0 > a.spin_ticks)) {
+                                st_agent((unsigned *)a.ndone + 1, 1u);   // the frame's partners are not co-resident: abort, store nothing
+                                dead = true;
+                                break;
+                            }
                         }
                         const double pv = __longlong_as_double((long long)v);
-                        red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm;
+                        red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm; red[19] = dead ? 1.0 : 0.0;
                     }
                 } else if (tid < 64) {
                     double mm = red[0];
                     for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
                     double pm;
                     unsigned spins = 0;
+                    bool dead = false;
+                    const long long t0 = plx_clock();
                     for (;;) {
                         bool all = true;
                         pm = (tid == 0) ? a.gam[c] * mm : -INFINITY;       // the leader's own tile (channel c of tile 0)
@@ -1294,9 +828,15 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                         }
                         if (__all(all)) break;
                         nap();
-                        if (++spins > (1u << 21)) { if (tid == 0) atomicAdd(a.syncerr, 1); break; }
+                        if ((++spins & 255u) == 0) {           // (wave-uniform: every lane evaluates the same test)
+                            const int late = ld_agent((const unsigned *)a.ndone + 1) != 0 || plx_clock() - t0 > a.spin_ticks;
+                            if (__any(late)) { dead = true; break; }
+                        }
                     }
                     pm = wave_max(pm);
+                    if (dead) {
+                        if (tid == 0) { st_agent((unsigned *)a.ndone + 1, 1u); red[19] = 1.0; }
+                    } else {
                     for (int i = 1 + tid; i < tiles_pf; i += 64) st_agent(slots + i, ~0ull);
                     if (tid == 0) {
                         const double pv = ctrl_core_call(a.dphimax, a.alphalin, a.dzmax, a.dz0, a.zdone0, a.Lf, a.lcorr,
@@ -1304,11 +844,13 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                         st_agent(pubw + (par ^ 1u), ~0ull);
                         st_agent_f64((double *)(pubw + par), pv);    // the frame is released ...
                         a.ctl[f] = *lctl;                            // ... before the record goes back (k_row reads it)
-                        red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm;
+                        red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm; red[19] = 0.0;
+                    }
                     }
                 }
             }
             __syncthreads();
+            if (red[19] != 0.0) return;    // barrier timed out (uniform over the workgroup): no store, no control update
             const double leff = red[16];
             const bool finished = red[17] != 0.0;
             if (finished) {                // the frame has reached the fibre end: write the field out
@@ -1389,26 +931,22 @@ struct plx_ssfm {
     cplx *d_tpass = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
     FrameCtl *d_ctl = nullptr;
     unsigned long long *d_umax = nullptr;
-    int *d_ndone = nullptr;
-    int *h_ndone = nullptr; // pinned
+    int *d_ndone = nullptr;   // [0] frames done, [1] abort word
+    int *h_ndone = nullptr;   // pinned copy of the two words
+    hipEvent_t ev = nullptr;  // completion of the last read-back of d_ndone
     std::vector<FrameCtl> h_ctl;
     int brf_sets = 0;
     size_t lds_col = 0, lds_row = 0;
-    unsigned *d_sync = nullptr;   // arrive[F] | epoch[F] | syncerr
-    double *d_pub = nullptr;
-    unsigned long long *d_slots = nullptr, *d_pubw = nullptr;   // slot barrier of k_colx16
+    unsigned long long *d_slots = nullptr, *d_pubw = nullptr;   // slot barrier of the fused column sweep
     int fused = 0, fused_grid = 0, tiles_pf = 0;
-    int use_r16 = 0;              // fused sweep runs the register-blocked k_colx16 (256 x (8+8) tiles)
-    int row16 = 0;                // register-blocked row pass usable (N2 == 256, dual, no PMD)
-    int row_threads = ROW_THREADS; // workgroup size of k_row, chosen at plan creation
+    int col_threads = 512;         // workgroup size of k_col_fwd / k_col_inv
+    int row_threads = ROW_THREADS; // workgroup size of k_row
     int row_split = 0, rs_threads = 0; // long rows without PMD: one polarisation per workgroup (scalar row pass twice)
     size_t rs_lds = 0;
     double *h_brf[2] = {nullptr, nullptr}; // pinned staging of the waveplate tables
     hipEvent_t brf_ev[2] = {nullptr, nullptr};
     int brf_slot = 0;
-    int pf_col = 0, pf_row = 0;   // > 0: persistent prefetching kernels usable (tile == PF x threads)
-    int grid_col = 0, grid_row = 0;
-    int64_t row_launches = 0, sample_steps = 0;
+    int64_t row_launches = 0, sample_steps = 0, frame_launches = 0;
 };
 
 static const double kInv2Pi = 0.15915494309189533577;
@@ -1425,8 +963,9 @@ static void free_plan(plx_ssfm *P)
     if (!P) return;
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
-    hipFree(P->d_ndone); hipFree(P->d_sync); hipFree(P->d_pub); hipFree(P->d_slots); hipFree(P->d_pubw);
+    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_pubw);
     if (P->h_ndone) hipHostFree(P->h_ndone);
+    if (P->ev) hipEventDestroy(P->ev);
     for (int k = 0; k < 2; k++) {
         if (P->h_brf[k]) hipHostFree(P->h_brf[k]);
         if (P->brf_ev[k]) hipEventDestroy(P->brf_ev[k]);
@@ -1448,9 +987,39 @@ template <class K> static hipError_t allow_lds(K kern, size_t bytes)
 {
     return hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
+// workgroups of `kern` the runtime admits per CU at this block size and dynamic LDS (0 on failure)
+template <class K> static int blocks_per_cu(K kern, int threads, size_t lds)
+{
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, threads, lds) != hipSuccess) return 0;
+    return nb;
+}
 #else
 template <class K> static hipError_t allow_lds(K, size_t) { return hipSuccess; }
+template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 #endif
+
+// Plan-time tuning overrides for development sweeps (scripts/experiments/): read ONCE, in plx_ssfm_create.
+// PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
+namespace {
+struct Tune {
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0;
+    double barrier_timeout_ms = 500.0;
+    static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+    Tune()
+    {
+        no_fuse = geti("PLX_SSFM_NO_FUSE", 0);
+        p1 = geti("PLX_SSFM_P1", -1);
+        logW = geti("PLX_SSFM_LOGW", -1);
+        rows = geti("PLX_SSFM_ROWS", -1);
+        row_threads = geti("PLX_SSFM_ROW_THREADS", -1);
+        col_threads = geti("PLX_SSFM_COL_THREADS", -1);
+        no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
+        if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
+    }
+};
+bool pow2_in(int v, int lo, int hi) { return v >= lo && v <= hi && (v & (v - 1)) == 0; }
+} // namespace
 
 extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
 {
@@ -1466,6 +1035,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         PLX_FAIL(PLX_ERR_REFERENCE, "The CNLSE with separate fields is not yet implemented"); // fiber.m:854
     if (desc->dual_pol && desc->fls[3] && desc->nfc == 1) { /* xpm flag is forced to 0 for one field, :224 */ }
     if (desc->nplates < 1) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: nplates must be >= 1");
+    const Tune tune;
 
     plx_ssfm *P = new plx_ssfm();
     P->d = *desc;
@@ -1474,60 +1044,58 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     // polarisation x npol) and is kept at <= 64 KiB so two workgroups share a CU; a wider, shorter
     // tile means longer contiguous row segments in HBM (W*16 B per polarisation).  The row pass
     // holds npol x N2 complex (+ twiddles) in LDS, which bounds N2 at 2048 for dual-pol frames.
+    int logW;
     {
         const int npol = desc->dual_pol ? 2 : 1;
-        int logW = desc->dual_pol ? 3 : 4;                   // 8 (dual) / 16 (scalar) columns per tile (measured best)
+        logW = desc->dual_pol ? 3 : 4;                       // 8 (dual) / 16 (scalar) columns per tile (measured best)
         int p1 = 12 - (logW + (npol == 2 ? 1 : 0));          // N1 * T = 4096 complex = 64 KiB
         const int p2max = 11;
         if (p - p1 > p2max) p1 = p - p2max;                  // large frames: taller tiles instead
         if (p1 > p - 4) p1 = p - 4;                          // keep N2 >= 16
         if (p1 < 2) p1 = 2;
         while ((((size_t)1 << p1) << (logW + (npol == 2 ? 1 : 0))) * sizeof(cplx) > 128 * 1024 && logW > 3) logW--;
-        if (const char *e = getenv("PLX_SSFM_P1")) { int v = atoi(e); if (v >= 2 && v <= p - 4) p1 = v; }
-        if (const char *e = getenv("PLX_SSFM_LOGW")) { int v = atoi(e); if (v >= 2 && v <= 6) logW = v; }
+        if (tune.p1 >= 2 && tune.p1 <= p - 4) p1 = tune.p1;
+        if (tune.logW >= 2 && tune.logW <= 6) logW = tune.logW;
         while (((int64_t)1 << (p - p1)) < ((int64_t)1 << logW)) logW--;  // tile not wider than a row
         P->p1 = p1;
-        P->a.logW = logW;
     }
     P->p2 = p - P->p1;
     P->N = (size_t)N;
     const int N1 = 1 << P->p1, N2 = 1 << P->p2;
     const int nfc = desc->nfc, F = desc->max_frames;
     SsfmArgs &a = P->a;
-    const int keep_logW = P->a.logW;
     std::memset(&a, 0, sizeof(a));
     a.p1 = P->p1; a.p2 = P->p2; a.nfc = nfc; a.dual = desc->dual_pol ? 1 : 0;
-    a.logW = keep_logW; a.W = 1 << a.logW;
+    a.logW = logW; a.W = 1 << a.logW;
     a.logT = a.logW + (a.dual ? 1 : 0); a.T = 1 << a.logT;
     // rows per workgroup in the row pass: >= one 16-point register block per thread
     {
         int R = 1, npol = a.dual ? 2 : 1;
         while (R * npol * (N2 / 16) < ROW_THREADS / 2 && R * 2 <= N1) R *= 2;   // measured: 2 rows x 2 pols at N2 = 256
-        if (const char *e = getenv("PLX_SSFM_ROWS")) { int v = atoi(e); if (v >= 1 && v <= N1 && (v & (v - 1)) == 0) R = v; }
+        if (pow2_in(tune.rows, 1, N1)) R = tune.rows;
         a.R = R; a.logR = ilog2(R);
         // row pass: ~8 points per thread (128 threads for 2 rows x 2 polarisations x 256 points); long rows leave room
         // for only one or two workgroups per CU, so those get proportionally more waves (up to 1024 threads)
         int rowthr = ROW_THREADS;
         const int64_t pts = (int64_t)npol * R * N2;
         while (rowthr < 1024 && (int64_t)rowthr * 8 < pts) rowthr *= 2;
-        if (const char *e = getenv("PLX_SSFM_ROW_THREADS")) { int v = atoi(e); if (v >= 64 && v <= 1024 && (v & (v - 1)) == 0) rowthr = v; }
+        if (pow2_in(tune.row_threads, 64, 1024)) rowthr = tune.row_threads;
         P->row_threads = rowthr;
     }
     // Long rows leave room for a single dual-polarisation workgroup per CU.  Without PMD the two polarisations only
     // share the multiplier, so each gets its own workgroup (the scalar form of the row pass, R = 1): half the LDS,
     // 2-3 workgroups per CU.
-    if (a.dual && N2 >= 2048 && !getenv("PLX_SSFM_NO_ROW_SPLIT")) {   // measured: 2^20 frames 74 -> 66 ms; at N2 = 1024 it loses (47 -> 52)
+    if (a.dual && N2 >= 2048 && !tune.no_row_split) {   // measured: 2^20 frames 74 -> 66 ms; at N2 = 1024 it loses (47 -> 52)
         P->row_split = 1;
         P->rs_threads = N2 / 8 < ROW_THREADS ? ROW_THREADS : (N2 / 8 > 1024 ? 1024 : N2 / 8);
-        if (const char *e = getenv("PLX_SSFM_RS_THREADS")) { int v = atoi(e); if (v >= 64 && v <= 1024 && (v & (v - 1)) == 0) P->rs_threads = v; }
         P->rs_lds = ((size_t)(N2 + N2 / 16) + N2 / 2) * sizeof(cplx);
     }
     a.spm = desc->fls[2]; a.xpm = desc->fls[3]; a.manakov = desc->manakov ? 1 : 0; a.pmd = desc->fls[1] ? 1 : 0;
     a.nplates = desc->nplates;
     a.alphalin = desc->alphalin; a.Lf = desc->length; a.dzmax = desc->dzmaxt; a.dphimax = desc->dphimaxt;
     a.lcorr = desc->length / desc->nplates; // fiber.m:507
-    if (const char *e = getenv("PLX_SSFM_DBG")) a.dbg = atoi(e);
     a.invN = 1.0 / (double)N;
+    a.spin_ticks = (long long)(tune.barrier_timeout_ms * 1e5);
 
     // ---- tables: spectral multipliers in the order the row pass sees them ----
     std::vector<double> bt((size_t)nfc * N), d1;
@@ -1573,7 +1141,8 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     bool ok = hipMalloc((void **)&P->d_ctl, sizeof(FrameCtl) * F) == hipSuccess &&
               hipMalloc((void **)&P->d_umax, sizeof(unsigned long long) * F * nfc) == hipSuccess &&
               hipMalloc((void **)&P->d_ndone, 64) == hipSuccess &&
-              hipHostMalloc((void **)&P->h_ndone, 64, hipHostMallocDefault) == hipSuccess;
+              hipHostMalloc((void **)&P->h_ndone, 64, hipHostMallocDefault) == hipSuccess &&
+              hipEventCreateWithFlags(&P->ev, hipEventDisableTiming) == hipSuccess;
     if (ok && !a.dual && a.xpm) ok = hipMalloc((void **)&P->d_psum, sizeof(double) * (size_t)F * N) == hipSuccess;
     if (!ok) { free_plan(P); PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed"); }
     a.betat_p = P->d_betat; a.db1_p = P->d_db1; a.tpass = P->d_tpass; a.tw1 = P->d_tw1; a.tw2 = P->d_tw2;
@@ -1582,48 +1151,33 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
 
     P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double) + sizeof(FrameCtl);
     P->lds_row = ((size_t)(a.dual ? 2 : 1) * a.R * (N2 + N2 / 16) + N2 / 2) * sizeof(cplx);
-    // persistent software-pipelined sweeps: measured 5-8 % slower than the plain grid on MI355X at
-    // F = 256..1024 (profiles/), kept opt-in for experiments
-    if (a.dual && getenv("PLX_SSFM_PERSIST")) {
-        const int nel_col = N1 << a.logW, nel_row = a.R << a.p2;
-        if (nel_col == 8 * 256) P->pf_col = 8; else if (nel_col == 4 * 256) P->pf_col = 4;
-        if (nel_row == 4 * ROW_THREADS) P->pf_row = 4; else if (nel_row == 8 * ROW_THREADS) P->pf_row = 8;
-        int wg = (int)(160 * 1024 / (P->lds_col + 1024)); if (wg < 1) wg = 1; if (wg > 4) wg = 4;
-        P->grid_col = 256 * wg;
-        wg = (int)(160 * 1024 / (P->lds_row + 1024)); if (wg < 1) wg = 1; if (wg > 8) wg = 8;
-        P->grid_row = 256 * wg;
-        if (const char *e = getenv("PLX_SSFM_GRID_COL")) P->grid_col = atoi(e);
-        if (const char *e = getenv("PLX_SSFM_GRID_ROW")) P->grid_row = atoi(e);
+    P->col_threads = P->lds_col > 80 * 1024 ? 1024 : 512;   // measured: 512-thread column workgroups (2 per CU, 16 waves) beat
+                                                            // 256 by 3-12 %; tall tiles of large frames: one workgroup per CU, 16 waves
+    if (tune.col_threads == 128 || tune.col_threads == 256 || tune.col_threads == 512 || tune.col_threads == 1024) P->col_threads = tune.col_threads;
+    if (allow_lds(k_colx16, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
+        allow_lds(k_col_inv, P->lds_col) != hipSuccess || allow_lds(k_row, P->lds_row > P->rs_lds ? P->lds_row : P->rs_lds) != hipSuccess) {
+        free_plan(P);
+        PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
     }
-    P->row16 = (a.dual && !a.pmd && a.p2 == 8 && N1 % ROW16_R == 0 && getenv("PLX_SSFM_ROW16")) ? 1 : 0;   // opt-in (profiles/r01_notes.md)
-    // Fused column sweep: the inverse column pass of step s, the step controller and the forward column pass of
-    // step s+1 in ONE launch on an LDS/register-resident tile (2 sweeps over HBM per step instead of 3).  Needs
-    // the tile to be PF x 256 and every tile of a frame co-resident (per-frame ticket barrier).  Default for the
-    // 256 x (8+8) tile, where the register-blocked k_colx16 applies: measured 139.5 vs 148.8 ms per 1024-frame
-    // pass (profiles/r01_notes.md); opt-in (PLX_SSFM_FUSE=1) elsewhere, PLX_SSFM_NO_FUSE=1 switches it off.
-    int ncu = 256;
-    {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            ncu = v;
-    }
-    const bool fuse_default = a.p1 == 8 && a.W == 8;
-    if (a.dual && !getenv("PLX_SSFM_NO_FUSE") && (fuse_default || getenv("PLX_SSFM_FUSE"))) {
-        const int nel_col = N1 << a.logW, tiles_pf = nfc * (N2 / a.W);
-        int wg = (int)(160 * 1024 / (P->lds_col + 1024)); if (wg < 1) wg = 1; if (wg > 2) wg = 2;
-        const int cap = ncu * wg;
-        if ((nel_col == 8 * 256 || nel_col == 4 * 256 || nel_col == 16 * 256) && tiles_pf <= cap) {
-            P->fused = nel_col / 256;
-            P->use_r16 = (P->fused == 8 && a.p1 == 8 && a.W == 8 && !getenv("PLX_SSFM_NO_R16")) ? 1 : 0;
+    // Fused column sweep (k_colx16): the inverse column pass of step s, the step controller and the forward column
+    // pass of step s+1 in ONE launch on a register/LDS-resident tile (2 sweeps over HBM per step instead of 3), for
+    // dual-polarisation plans with 256 x (8+8) column tiles.  The tiles of a frame meet at a barrier inside the
+    // launch, so all of them must be resident together: the grid is sized from the runtime's own occupancy answer
+    // for this kernel (block size and dynamic LDS as launched), a multiple of the tiles per frame; a plan whose
+    // frame does not fit the chip that way takes the barrier-free three-sweep step.
+    if (a.dual && !tune.no_fuse && a.p1 == 8 && a.W == 8) {
+        int ncu = 256;
+        {
+            int dev = 0, v = 0;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+                ncu = v;
+        }
+        const int tiles_pf = nfc * (N2 / a.W);
+        const int cap = ncu * blocks_per_cu(k_colx16, 256, P->lds_col);
+        if (tiles_pf <= cap) {
+            P->fused = 1;
             P->tiles_pf = tiles_pf;
             P->fused_grid = (cap / tiles_pf) * tiles_pf;
-            if (const char *e = getenv("PLX_SSFM_FUSE_GRID")) { int v = atoi(e); if (v >= tiles_pf && v <= cap) P->fused_grid = (v / tiles_pf) * tiles_pf; }
-            if (hipMalloc((void **)&P->d_sync, sizeof(unsigned) * (2 * (size_t)F + 16)) != hipSuccess ||
-                hipMalloc((void **)&P->d_pub, sizeof(double) * 2 * (size_t)F) != hipSuccess) {
-                free_plan(P);
-                PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed");
-            }
-            a.arrive = P->d_sync; a.epoch = P->d_sync + F; a.syncerr = (int *)(P->d_sync + 2 * (size_t)F); a.pub = P->d_pub;
             if (hipMalloc((void **)&P->d_slots, sizeof(unsigned long long) * (size_t)F * tiles_pf) != hipSuccess ||
                 hipMalloc((void **)&P->d_pubw, sizeof(unsigned long long) * 2 * (size_t)F) != hipSuccess) {
                 free_plan(P);
@@ -1631,21 +1185,6 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             }
             a.slots = P->d_slots; a.pubw = P->d_pubw;
         }
-    }
-    if (allow_lds(k_row16, P->lds_row) != hipSuccess) { free_plan(P); PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS"); }
-    if (allow_lds(k_colx16, P->lds_col) != hipSuccess || allow_lds(k_colx<8, 256>, P->lds_col) != hipSuccess ||
-        allow_lds(k_colx<4, 256>, P->lds_col) != hipSuccess || allow_lds(k_colx<16, 256>, P->lds_col) != hipSuccess ||
-        allow_lds(k_colx<8, 512>, P->lds_col) != hipSuccess || allow_lds(k_colx<4, 512>, P->lds_col) != hipSuccess) {
-        free_plan(P);
-        PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
-    }
-    if (allow_lds(k_col_fwd_p<8>, P->lds_col) != hipSuccess || allow_lds(k_col_inv_p<8>, P->lds_col) != hipSuccess ||
-        allow_lds(k_col_fwd_p<4>, P->lds_col) != hipSuccess || allow_lds(k_col_inv_p<4>, P->lds_col) != hipSuccess ||
-        allow_lds(k_row_p<4>, P->lds_row) != hipSuccess || allow_lds(k_row_p<8>, P->lds_row) != hipSuccess ||
-        allow_lds(k_col_fwd, P->lds_col) != hipSuccess || allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
-        allow_lds(k_row, P->lds_row) != hipSuccess) {
-        free_plan(P);
-        PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
     }
     if (a.pmd && !a.dual) { free_plan(P); PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: PMD needs a dual-polarisation plan"); }
     if (!a.pmd) { // fiber.m:291-297: birefringence off
@@ -1737,10 +1276,8 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     PLX_HIP(hipMemsetAsync(P->d_ndone, 0, 64, st));
     const bool fused = P->fused != 0;
     if (fused) { // the first fused launch also forms nextstep's initial maximum
-        PLX_HIP(hipMemsetAsync(P->d_sync, 0, sizeof(unsigned) * (2 * (size_t)P->d.max_frames + 16), st));
-        PLX_HIP(hipMemsetAsync(P->d_pub, 0, sizeof(double) * 2 * (size_t)P->d.max_frames, st));
-        PLX_HIP(hipMemsetAsync(P->d_slots, 0xFF, sizeof(unsigned long long) * (size_t)P->d.max_frames * P->tiles_pf, st));   // ~0 = "not arrived"
-        PLX_HIP(hipMemsetAsync(P->d_pubw, 0xFF, sizeof(unsigned long long) * 2 * (size_t)P->d.max_frames, st));
+        PLX_HIP(hipMemsetAsync(P->d_slots, 0xFF, sizeof(unsigned long long) * (size_t)nframes * P->tiles_pf, st));   // ~0 = "not arrived"
+        PLX_HIP(hipMemsetAsync(P->d_pubw, 0xFF, sizeof(unsigned long long) * 2 * (size_t)nframes, st));
     } else {
         unsigned gx = (unsigned)((P->N + 255) / 256);
         if (gx > 64) gx = 64;
@@ -1748,40 +1285,29 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     }
     const dim3 gcol((unsigned)(N2 / a.W), FC), grow((unsigned)(N1 / a.R), FC), blk(256);
     const dim3 gctl((unsigned)((nframes + 63) / 64)), bctl(64);
-    int colthr = 512; // measured: 512-thread column workgroups (2 per CU, 16 waves) beat 256 by 3-12 %
-    if (P->lds_col > 80 * 1024) colthr = 1024;   // tall tiles of large frames: one workgroup per CU, give it 16 waves
-    if (const char *e = getenv("PLX_SSFM_COL_THREADS")) { int v = atoi(e); if (v == 128 || v == 256 || v == 512 || v == 1024) colthr = v; }
-    const dim3 bcol((unsigned)colthr);
+    const dim3 bcol((unsigned)P->col_threads);
     const int rowthr = P->row_threads;
     P->row_launches = 0;
-    // Data-dependent trip count (fiber.m:518): steps are enqueued in chunks; the
-    // completed-frame counter of chunk k is read back while chunk k+1 executes.
+    // Data-dependent trip count (fiber.m:518): steps are enqueued in chunks; the completed-frame counter and the
+    // abort word of chunk k are read back while chunk k+1 executes.
     int chunk = 4, steps = 0;
     const int kMaxSteps = 1 << 22;
-    hipEvent_t ev;
-    PLX_HIP(hipEventCreate(&ev));
-    bool pending = false;
+    bool pending = false, aborted = false;
     for (;;) {
         for (int sidx = 0; sidx < chunk; sidx++) {
             if (fused) {
                 const int tcx = (int)gcol.x, tct = (int)(gcol.x * FC);
                 const dim3 gx((unsigned)(tct < P->fused_grid ? tct : P->fused_grid));
 #ifdef PLX_EMU
-                emu::g_concurrency = P->tiles_pf; // the emulator must keep one frame's workgroups alive together
+                // the emulator must keep one frame's workgroups alive together (PLX_EMU_STARVE: a test starves the barrier)
+                emu::g_concurrency = getenv("PLX_EMU_STARVE") ? 1 : P->tiles_pf;
 #endif
                 a.round = steps + sidx;
-                if (P->use_r16)
-                    PLX_LAUNCH(k_colx16, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
-                else if (P->fused == 8 && getenv("PLX_SSFM_FUSE_512")) PLX_LAUNCH((k_colx<4, 512>), gx, dim3(512), P->lds_col, st, a, tcx, P->tiles_pf, tct);
-                else if (P->fused == 8) PLX_LAUNCH((k_colx<8, 256>), gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
-                else if (P->fused == 4) PLX_LAUNCH((k_colx<4, 256>), gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
-                else if (getenv("PLX_SSFM_FUSE_256")) PLX_LAUNCH((k_colx<16, 256>), gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
-                else PLX_LAUNCH((k_colx<8, 512>), gx, dim3(512), P->lds_col, st, a, tcx, P->tiles_pf, tct);
+                PLX_LAUNCH(k_colx16, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
 #endif
-                if (P->row16) PLX_LAUNCH(k_row16, dim3((unsigned)(N1 / ROW16_R), FC), dim3(64), (size_t)(ROW16_R * 272 + 128) * sizeof(cplx), st, a);
-                else PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
+                PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
                 P->row_launches++;
                 continue;
             }
@@ -1791,15 +1317,8 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
                 if (gx > 256) gx = 256;
                 PLX_LAUNCH(k_rowsum, dim3(gx, (unsigned)nframes), blk, 0, st, a);
             }
-            const int tcx = (int)gcol.x, tct = (int)(gcol.x * FC), trx = (int)grow.x, trt = (int)(grow.x * FC);
-            const dim3 pgc((unsigned)(tct < P->grid_col ? tct : P->grid_col)), pgr((unsigned)(trt < P->grid_row ? trt : P->grid_row));
-            if (P->pf_col == 8) PLX_LAUNCH(k_col_fwd_p<8>, pgc, blk, P->lds_col, st, a, tcx, tct);
-            else if (P->pf_col == 4) PLX_LAUNCH(k_col_fwd_p<4>, pgc, blk, P->lds_col, st, a, tcx, tct);
-            else PLX_LAUNCH(k_col_fwd, gcol, bcol, P->lds_col, st, a);
-            if (P->pf_row == 4) PLX_LAUNCH(k_row_p<4>, pgr, dim3(ROW_THREADS), P->lds_row, st, a, trx, trt);
-            else if (P->pf_row == 8) PLX_LAUNCH(k_row_p<8>, pgr, dim3(ROW_THREADS), P->lds_row, st, a, trx, trt);
-            else if (P->row16) PLX_LAUNCH(k_row16, dim3((unsigned)(N1 / ROW16_R), FC), dim3(64), (size_t)(ROW16_R * 272 + 128) * sizeof(cplx), st, a);
-            else if (P->row_split && !a.pmd) {
+            PLX_LAUNCH(k_col_fwd, gcol, bcol, P->lds_col, st, a);
+            if (P->row_split && !a.pmd) {
                 SsfmArgs b = a;
                 b.dual = 0; b.R = 1; b.logR = 0;
                 const dim3 gs((unsigned)N1, FC), bs((unsigned)P->rs_threads);
@@ -1808,28 +1327,28 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
                 PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
             }
             else PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
-            if (P->pf_col == 8) PLX_LAUNCH(k_col_inv_p<8>, pgc, blk, P->lds_col, st, a, tcx, tct);
-            else if (P->pf_col == 4) PLX_LAUNCH(k_col_inv_p<4>, pgc, blk, P->lds_col, st, a, tcx, tct);
-            else PLX_LAUNCH(k_col_inv, gcol, bcol, P->lds_col, st, a);
+            PLX_LAUNCH(k_col_inv, gcol, bcol, P->lds_col, st, a);
             P->row_launches++;
         }
         steps += chunk;
         if (pending) {
-            PLX_HIP(hipEventSynchronize(ev));
-            if (*P->h_ndone >= nframes) break;
+            PLX_HIP(hipEventSynchronize(P->ev));
+            if (P->h_ndone[1]) { aborted = true; break; }
+            if (P->h_ndone[0] >= nframes) break;
         }
-        PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, sizeof(int), hipMemcpyDeviceToHost, st));
-        PLX_HIP(hipEventRecord(ev, st));
+        PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        PLX_HIP(hipEventRecord(P->ev, st));
         pending = true;
         if (chunk < 16) chunk *= 2;
-        if (steps > kMaxSteps) { hipEventDestroy(ev); PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate"); }
+        if (steps > kMaxSteps) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate");
     }
     PLX_HIP(hipMemcpyAsync(P->h_ctl.data(), P->d_ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost, st));
-    int syncerr = 0;
-    if (fused) PLX_HIP(hipMemcpyAsync(&syncerr, P->a.syncerr, sizeof(int), hipMemcpyDeviceToHost, st));
+    PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
     PLX_HIP(hipStreamSynchronize(st));
-    hipEventDestroy(ev);
-    if (syncerr) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: frame barrier timed out (workgroups of a frame were not co-resident)");
+    if (aborted || P->h_ndone[1])
+        PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: frame barrier timed out (the workgroups of a frame were not co-resident: "
+                              "another kernel holds the GPU); nothing was stored after the timeout -- create the plan with "
+                              "PLX_SSFM_NO_FUSE=1 to share the device");
     P->sample_steps = 0;
     for (int f = 0; f < nframes; f++) {
         if (!P->h_ctl[f].done) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: a frame did not reach the fibre end");
@@ -1879,9 +1398,9 @@ int plx_ssfm_filter_dev(plx_ssfm *P, cplx *d_ux, cplx *d_uy, const cplx *d_hmul,
     PLX_HIP(hipMemsetAsync(P->d_ctl, 0, sizeof(FrameCtl) * nframes, st));   // no frame is "done"
     PLX_HIP(hipMemsetAsync(P->d_ndone, 0, 64, st));
     const dim3 gcol((unsigned)(N2 / b.W), FC), grow((unsigned)(N1 / b.R), FC);
-    PLX_LAUNCH(k_col_fwd, gcol, dim3(512), P->lds_col, st, b);
+    PLX_LAUNCH(k_col_fwd, gcol, dim3((unsigned)P->col_threads), P->lds_col, st, b);
     PLX_LAUNCH(k_row, grow, dim3((unsigned)P->row_threads), P->lds_row, st, b);
-    PLX_LAUNCH(k_col_inv, gcol, dim3(512), P->lds_col, st, b);
+    PLX_LAUNCH(k_col_inv, gcol, dim3((unsigned)P->col_threads), P->lds_col, st, b);
     PLX_HIP(hipGetLastError());
     return PLX_OK;
 }

@@ -291,18 +291,17 @@ def test_emu_dsp_chain(emu, oracle, kw):
     assert err[1].sum() == int(np.sum(oracle.samp2pat_coherent(np.angle(out[1].T)).T != dp))
 
 
-def test_emu_fused_and_persistent_variants(emu, oracle, monkeypatch):
-    """The opt-in sweeps (PLX_SSFM_FUSE: col_inv + step control + col_fwd with a per-frame barrier;
-    PLX_SSFM_PERSIST: register-prefetching persistent sweeps; PLX_SSFM_P1=4 -> 256-point rows through
-    the general k_row and, with PLX_SSFM_ROW16, the register-blocked k_row16) give the same fields and step counts."""
+def test_emu_sweep_variants(emu, oracle, monkeypatch):
+    """The fused column sweep (default at this geometry: k_colx16 with its per-frame barrier), the barrier-free
+    three-sweep step (PLX_SSFM_NO_FUSE) and a 16 x 256 split (PLX_SSFM_P1=4: 256-point rows through the general
+    k_row) give the same fields and step counts."""
     n, nt, L = 4096, 64, 1.5e3
     fls = [1, 0, 1, 0]
     betat, db1 = _tables(n, nt, fls, 1)
     fields = [_qpsk_field(n, nt, p)[:2] for p in (6.0, 9.0, 12.0)]
     ref = [oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0]) for f in fields]
-    for env in ({"PLX_SSFM_NO_R16": "1"}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_PERSIST": "1", "PLX_SSFM_NO_FUSE": "1"},
-                {"PLX_SSFM_P1": "4", "PLX_SSFM_ROW16": "1"}, {"PLX_SSFM_P1": "4"}):
-        nf = 1 if "PLX_SSFM_P1" in env else 3          # the row variants have no cross-frame machinery
+    for env in ({}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_P1": "4"}):
+        nf = 1 if "PLX_SSFM_P1" in env else 3
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=nf)
@@ -322,6 +321,32 @@ def test_emu_fused_and_persistent_variants(emu, oracle, monkeypatch):
             assert ncyc[f] == onc
             assert np.abs(gx[f] - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
             assert np.abs(gy[f] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
+
+
+def test_emu_frame_barrier_timeout_aborts_cleanly(emu, monkeypatch):
+    """A fused-sweep frame whose workgroups are not co-resident (here: the emulator runs ONE workgroup at a time) must
+    end in a clean error, never a hang: the barrier times out (wall clock), raises the sticky abort word, nothing is
+    stored or advanced after it, and propagate reports PLX_ERR_HIP.  The timeout hits in the first launch, before any
+    store: the caller's field is bit-for-bit untouched."""
+    n, nt, L = 4096, 64, 1.5e3
+    fls = [1, 0, 1, 0]
+    betat, db1 = _tables(n, nt, fls, 1)
+    f = _qpsk_field(n, nt, 6.0)
+    monkeypatch.setenv("PLX_SSFM_BARRIER_TIMEOUT_MS", "30")
+    d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=2)
+    plan = C.c_void_p()
+    emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+    monkeypatch.delenv("PLX_SSFM_BARRIER_TIMEOUT_MS")
+    ux = _il(np.stack([f[0], f[0]])); uy = _il(np.stack([f[1], f[1]]))
+    ux0, uy0 = ux.copy(), uy.copy()
+    monkeypatch.setenv("PLX_EMU_STARVE", "1")
+    rc = emu.lib.plx_ssfm_propagate_dev(plan, _vp(ux), _vp(uy), 2, None)
+    monkeypatch.delenv("PLX_EMU_STARVE")
+    assert rc == -1                                     # PLX_ERR_HIP
+    assert b"frame barrier timed out" in emu.lib.plx_last_error()
+    np.testing.assert_array_equal(ux, ux0)
+    np.testing.assert_array_equal(uy, uy0)
+    emu.call("plx_ssfm_destroy", plan)
 
 
 @pytest.mark.parametrize("tolflag", [2, 1])

@@ -527,11 +527,10 @@ def test_fiber_function_surface(lib, oracle):
         px.fiber(x)
 
 
-@pytest.mark.parametrize("env", [{"PLX_SSFM_NO_R16": "1"}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_PERSIST": "1", "PLX_SSFM_NO_FUSE": "1"}])
-def test_optin_sweep_variants_match_oracle(lib, oracle, monkeypatch, env):
-    """The selectable SSFM sweeps (the generic LDS-resident fused sweep k_colx with its ticket barrier -- the register-
-    blocked k_colx16 is the default at this geometry and runs in every other test --, the plain three-sweep step,
-    persistent register-prefetching sweeps) all reproduce the oracle, frames with different step counts."""
+@pytest.mark.parametrize("env", [{}, {"PLX_SSFM_NO_FUSE": "1"}])
+def test_sweep_variants_match_oracle(lib, oracle, monkeypatch, env):
+    """Both forms of the SSFM step -- the fused column sweep k_colx16 (default at this geometry) and the barrier-free
+    three-sweep step (PLX_SSFM_NO_FUSE=1) -- reproduce the oracle on a batch whose frames have different step counts."""
     import torch
     F = 20                                           # > 16 frames: the fused grid walks more than one round
     c = _fibre_case(1024, 64, "g-s-", 2.0, length=2e4)
