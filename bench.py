@@ -1,16 +1,26 @@
 #!/usr/bin/env python
-"""bench.py -- dual-pol Gsample/s through SSFM + Rx-DSP on MI355X.
+"""bench.py -- dual-pol Gsample/s through SSFM + Rx-DSP on MI355X, and Monte-Carlo realisations/s.
 
 One "step" = one pass of the hot path (fiber 'g-s-' split-step Fourier propagation
 -> 2-sps pick -> CDE_OFDE overlap-save -> DspPdmCohQpsk with CMA + carrier recovery
 -> decisions / error count) over ONE BATCH of synthetic PDM-QPSK frames that is
 already resident in HBM when the timed region starts.  Workload at N=1: BASELINE
 config[1] (Run_my_PDM_QPSK-style: 28 Gbaud PDM-QPSK, 2^16-sample frame, one 80 km
-SSMF span + CMA demux), batched over --frames independent frames per GPU.
+SSMF span + CMA demux), batched over --frames independent frames per GPU; the frames
+of a batch carry --variants different de Bruijn sequences (and, with --power-ladder,
+BASELINE config[4]'s -4...+8 dBm launch powers, i.e. data-dependent step counts).
 
-N>1: one process per GPU (torch.distributed, backend nccl = RCCL); frames are
-independent units, so ranks shard them with no data-path collective (weak scaling);
-the only exchange is the final all-reduce of the error counters.
+N>1: one process per GPU (torch.distributed, backend nccl = RCCL).  `--gpus N` with no
+WORLD_SIZE in the environment starts the N ranks itself, as fresh child processes, BEFORE
+anything touches a GPU; under torchrun (RANK/LOCAL_RANK/WORLD_SIZE set) it is one rank.
+Frames are independent units, so ranks shard them with no data-path collective (weak
+scaling); the exchanges are the all-reduce of the error counters and, in the Monte-Carlo
+leg, one all-reduce of the round's per-realisation error counts.
+
+After the timed region (outside it) every run also does a short Monte-Carlo leg -- BASELINE
+config[3]: fresh random birefringence + amplifier ASE per realisation, through
+mc.ShardedBer (realisation r on rank r mod G, one all-reduce per round, host replay of
+ber_estimate.m:116-141) -- and reports realisations/s including the reduce in "mc".
 
 Prints ONE JSON line on rank 0.
 """
@@ -19,6 +29,8 @@ import ctypes as C
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,8 +40,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
-SSFM_BYTES_PER_SAMPLE_STEP = 272.0   # 4 sweeps x (32 R + 32 W) + 16 B of betat/db1, dual-pol
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # same guide: measured float4 copy (79 % of spec)
+INPLACE_RW_GBS = 5100.0        # scripts/experiments/micro/seg_copy.hip: in-place read-modify-write of this access pattern
+SWEEP_BYTES = 64.0             # one sweep over a dual-pol complex128 field: 32 B read + 32 B written per sample
+SURVEY_BYTES_PER_SAMPLE_STEP = 272.0   # FOUR sweeps + 16 B of tables (an upper-bound budget, not what runs)
 
 
 def parse():
@@ -42,12 +57,19 @@ def parse():
     ap.add_argument("--nt", type=int, default=64)
     ap.add_argument("--pavg", type=float, default=2.0)
     ap.add_argument("--flag", default="g-s-")
+    ap.add_argument("--variants", type=int, default=16, help="distinct Tx sequences cycled over the frames of a batch")
+    ap.add_argument("--power-ladder", action="store_true",
+                    help="frame f is launched at point f %% 64 of BASELINE config[4]'s ladder (-4...+8 dBm in equal dB steps): "
+                         "frames of one batch then need 5...90+ SSFM steps each (fiber.m:518,534)")
     ap.add_argument("--noise", type=float, default=0.05, help="receiver noise sigma per quadrature (full scale 1)")
     ap.add_argument("--frontend", default="pick", choices=["pick", "cohmix"],
                     help="pick: 2-sps sampling supplied by the harness (SURVEY 8d C1); cohmix: receiver_cohmix + ADC + decimate on the device")
     ap.add_argument("--mc", action="store_true",
-                    help="BASELINE config[3] style step: fiber('gps-') with a fresh random-birefringence draw per frame "
-                         "and per step (Monte-Carlo PMD realisations), receiver noise as ASE stand-in")
+                    help="timed region in BASELINE config[3] style: fiber('gps-') with a fresh random-birefringence draw per "
+                         "frame and per step; the Monte-Carlo leg proper (ShardedBer) runs after the timed region in every mode")
+    ap.add_argument("--mc-rounds", type=int, default=4, help="rounds of the Monte-Carlo leg (0: skip it)")
+    ap.add_argument("--mc-frames", type=int, default=128, help="realisations per GPU per round (config[3]: 1024 over 8 GPUs)")
+    ap.add_argument("--mc-nf", type=float, default=31.0, help="noise figure [dB] of the amplifier in the Monte-Carlo leg")
     ap.add_argument("--spans", type=int, default=1, help="spans per step, with in-line amplifiers between them (config[4]: 40)")
     ap.add_argument("--nf", type=float, default=None, help="noise figure [dB] of the in-line amplifiers (default: noiseless)")
     ap.add_argument("--no-overlap", action="store_true", help="run the receiver on the fibre stream (no stream overlap)")
@@ -57,16 +79,61 @@ def parse():
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------- launcher ---
+def launch_ranks(a):
+    """`bench.py --gpus N` outside a launcher: start N ranks as fresh child processes of THIS interpreter, which has not
+    touched (and never touches) a GPU; rank 0's JSON line passes through on stdout."""
+    import torch       # device_count() does not initialise the GPU on this image
+    rehearsal = os.environ.get("PLX_BENCH_REHEARSAL") == "1"
+    ndev = torch.cuda.device_count()
+    if a.gpus > ndev and not rehearsal:
+        sys.stderr.write("bench.py: --gpus %d but %d device(s) visible (PLX_BENCH_REHEARSAL=1 rehearses the N-rank path on "
+                         "one GPU with gloo)\n" % (a.gpus, ndev))
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs and rc == 0:
+            for p in list(procs):
+                r = p.poll()
+                if r is None:
+                    continue
+                procs.remove(p)
+                if r != 0:
+                    rc = r
+            time.sleep(0.05)
+    finally:
+        for p in procs:              # a rank failed (or we were interrupted): stop exactly the children we started
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    return rc
+
+
 class HipEvents:
     """HIP events on an explicit stream (torch.cuda.Event only sees torch's current stream)."""
 
     def __init__(self):
         self.hip = C.CDLL("libamdhip64.so")
         self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [C.c_void_p]
+        self.live = []
 
     def create(self):
         e = C.c_void_p()
         assert self.hip.hipEventCreate(C.byref(e)) == 0
+        self.live.append(e)
         return e
 
     def record(self, e, stream):
@@ -77,6 +144,11 @@ class HipEvents:
         ms = C.c_float()
         assert self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
         return ms.value
+
+    def destroy_all(self):
+        for e in self.live:
+            self.hip.hipEventDestroy(e)
+        self.live = []
 
 
 def host_cores():
@@ -138,8 +210,36 @@ def cpu_baseline(cfg, hp, nframes, noise):
     return one, allc
 
 
+def ladder_scales(nframes, pavg_mw):
+    """BASELINE config[4]: 64 launch powers -4...+8 dBm in equal dB steps; frame f sits at point f % 64."""
+    dbm = -4.0 + 12.0 * (np.arange(nframes) % 64) / 63.0
+    return 10 ** (dbm / 10) / pavg_mw
+
+
+def offline_traffic(fused, F, n):
+    """HBM bytes per launch of the dominant kernel from the PMC counters.  Counters need their own rocprofv3 passes
+    (FETCH_SIZE, WRITE_SIZE: MI355X_MICROARCH.md, HBM section), so this is NOT measured in this run: it is read from the
+    summary of scripts/traffic_pmc.sh on this round's build, if one is committed."""
+    for name in ("r02_traffic.json",):
+        tj = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(tj):
+            continue
+        tr = json.load(open(tj))
+        if not fused:
+            tr = tr.get("plain_three_sweep", {})
+        per = tr.get("bytes_per_sample_by_kernel")
+        if not per:
+            return None, None
+        k = "k_colx16" if fused else "k_col_fwd"
+        return per[k] * F * n, {"file": "profiles/" + name, "how": "offline rocprofv3 --pmc passes (not this run)",
+                                "bytes_per_sample_by_kernel": per}
+    return None, None
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -149,23 +249,27 @@ def main():
     rehearsal = os.environ.get("PLX_BENCH_REHEARSAL") == "1"
     if rehearsal:
         local = 0
-        os.environ["PLX_SSFM_NO_FUSE"] = "1"     # several ranks share one GPU here: the fused sweep assumes it owns the chip
+        os.environ["PLX_SSFM_NO_FUSE"] = "1"     # several ranks share one GPU here: the fused sweep needs the chip to itself
     torch.cuda.set_device(local)
     if world > 1:
         if rehearsal:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    from polmux_amd import _abi, pipeline
-    _abi.get().call("plx_set_device", local)
+    from polmux_amd import _abi, mc, pipeline
+    lib = _abi.get()
+    lib.call("plx_set_device", local)
+    cdev = "cpu" if (rehearsal or world == 1) else "cuda"        # where the collectives' tensors live
 
     if a.mc:
         a.flag = "gps-"
     cfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag=a.flag, frontend=a.frontend, nspans=a.spans,
-                                 span_nf_db=a.nf)
+                                 span_nf_db=a.nf, variants=a.variants)
     F = a.frames
     hp = pipeline.HotPath(cfg, max_frames=F)
+    hp.profile(True)          # a HIP event between consecutive launches of the step loop: per-kernel durations, live
     n = cfg.nfft
+    scales = ladder_scales(F, a.pavg) if a.power_ladder else None
     # inputs for every step are staged in HBM before the timed region (fibre works in place)
     total = a.steps + a.warmup
     # (bounded by free HBM: with more steps than buffers a buffer is refilled from a pristine copy by one
@@ -175,8 +279,8 @@ def main():
     nbuf = max(2, min(total, int(0.6 * free_b // batch_bytes)))
     if os.environ.get("PLX_BENCH_NBUF"):      # dev: force the restaging path
         nbuf = max(2, min(total, int(os.environ["PLX_BENCH_NBUF"])))
-    batches = [hp.make_batch(F) for _ in range(nbuf)]
-    pristine = hp.make_batch(F) if nbuf < total else None
+    batches = [hp.make_batch(F, scales) for _ in range(nbuf)]
+    pristine = hp.make_batch(F, scales) if nbuf < total else None
     restaged = 0
     buf_free = [None] * nbuf      # event: the receiver that last read this buffer has finished
 
@@ -205,6 +309,7 @@ def main():
     err_total = torch.zeros(2, dtype=torch.int64, device="cuda")
     errs, resolved = [], []
     fib_ms, rx_ms, row_launches, sample_steps = [], [], 0, 0
+    k_ms, k_n = np.zeros(4), np.zeros(4, np.int64)
     for i in range(a.warmup):
         ux, uy = get_batch(i)
         hp.run(ux, uy, noise_sigma=a.noise, noise_seed=1000 * rank + i)
@@ -219,7 +324,6 @@ def main():
         hp.fibre(ux, uy)
         ev.record(e1, stream)
         rs = rx_stream.cuda_stream if rx_stream is not None else stream
-        e1b = ev.create()
         err = hp.receive(ux, uy, noise_sigma=a.noise, noise_seed=1000 * rank + i, side_stream=rx_stream)
         # (receive() makes rx_stream wait for the fibre; the Rx interval is measured on the Rx stream)
         ev.record(e2, rs)
@@ -238,6 +342,8 @@ def main():
         fib_ms.append((e0, e1)); rx_ms.append((e1, e2))
         rl, ss = hp.ssfm_stats()
         row_launches += rl; sample_steps += ss
+        km, kn = hp.kernel_times()
+        k_ms += km; k_n += kn
     sync_all()
     dt = time.perf_counter() - t0
     for e in errs:
@@ -246,7 +352,6 @@ def main():
     for r_ in resolved:
         res_total += r_
     if world > 1:
-        cdev = "cpu" if rehearsal else "cuda"
         tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -255,6 +360,39 @@ def main():
         dist.all_reduce(res_total, op=dist.ReduceOp.SUM)
     fib = sum(ev.elapsed_ms(x, y) for x, y in fib_ms)
     rxm = sum(ev.elapsed_ms(x, y) for x, y in rx_ms)
+    ev.destroy_all()
+    ncyc = hp.last_ncycle(F)
+
+    # ---- Monte-Carlo leg (BASELINE config[3]; M2 of SURVEY 8d): outside the timed region above, timed on its own ----
+    mc_out = None
+    if a.mc_rounds > 0:
+        mcfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag="gps-", frontend="cohmix", rx_amp=True,
+                                      span_nf_db=a.mc_nf)
+        camp = pipeline.McCampaign(mcfg, frames_per_call=a.mc_frames)
+        x = dict(stop=(0.01, 95.0), nmin=100)                   # 1 % relative accuracy at 95 % confidence (ber_estimate.m:128-139)
+        camp.simulate(list(range(10 ** 6 + rank * a.mc_frames, 10 ** 6 + (rank + 1) * a.mc_frames)))   # warm-up, not counted
+        sb = mc.ShardedBer(camp.simulate, camp.bits_per_realisation, x, per_rank_per_round=a.mc_frames, device=cdev)
+        sync_all()
+        t1 = time.perf_counter()
+        res = sb.run(max_realisations=a.mc_rounds * a.mc_frames * world)
+        sync_all()
+        mdt = time.perf_counter() - t1
+        if world > 1:
+            tm = torch.tensor([mdt], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            mdt = float(tm.item())
+        done = len(sb.counts)
+        mc_out = {"realisations_per_s": done / mdt, "realisations": done, "rounds": sb.rounds, "seconds": mdt,
+                  "per_gpu_per_round": a.mc_frames, "bits_per_realisation": camp.bits_per_realisation,
+                  "avgber": float(res[1][0]), "stdber": float(res[3][0]), "nruns_bits": float(res[2][0]),
+                  "stopped_by_rule": bool(not res[0][0]), "stop_rule": "1 % at 95 % confidence, nmin 100 (ber_estimate.m:128-139)",
+                  "exchange": "one all_reduce(SUM) of int64[%d] per round (%s), then the sequential ber_estimate replay on "
+                              "every rank" % (a.mc_frames * world, "gloo rehearsal" if rehearsal else ("RCCL" if world > 1 else "single rank")),
+                  "realisation": "C1 frame, fiber('gps-') with 100 fresh random waveplates (fiber.m:274-276), ampliflat gain "
+                                 "%.1f dB with ASE of NF %.1f dB (ampliflat.m:91-136, device Philox keyed by realisation), "
+                                 "receiver_cohmix + ADC + decimate, CDE_OFDE, CMA + CPE, decisions with pol-swap / pi/2 "
+                                 "resolution (ex20_coherent_polmux.m:160-173)" % (10 * math.log10(math.exp(camp.hp.alphalin * mcfg.length)), a.mc_nf)}
+        camp.close()
 
     # SURVEY 8d's M1 read literally -- ONE frame through fibre + receiver, nothing else on the GPU (outside the timed region)
     single = None
@@ -272,18 +410,26 @@ def main():
     if rank == 0:
         samples = float(world) * a.steps * F * n
         value = samples / dt / 1e9
-        # roofline of the dominant kernel group: the SSFM step (3 sweeps), HBM-bound.
-        # achieved = algorithmic bytes (272 B per dual-pol sample-step) / measured fibre time (HIP events)
-        achieved = SSFM_BYTES_PER_SAMPLE_STEP * sample_steps / (fib * 1e-3) / 1e9
-        # HBM traffic per step-launch from the PMC counters (collected offline exactly as the micro-arch guide
-        # prescribes: separate FETCH_SIZE / WRITE_SIZE passes, x2 read correction on gfx950), profiles/r01_traffic.json
-        traffic = None
-        tj = os.path.join(ROOT, "profiles", "r01_traffic.json")
-        if os.path.exists(tj) and a.flag == "g-s-" and a.nsymb * a.nt == 65536:
-            tr = json.load(open(tj))
-            if os.environ.get("PLX_SSFM_NO_FUSE"):
-                tr = tr["plain_three_sweep"]
-            traffic = tr["bytes_per_sample_step"] * F * n
+        fused = hp.fused()
+        # ---- roofline: the dominant kernel, priced with the bytes it REALLY moves per launch (one sweep over the batch:
+        # 32 B read + 32 B written per dual-pol sample; tables are shared by all frames and stay in L2) over its
+        # average ACTIVE launch duration, measured live with HIP events between the launches on the fibre stream ----
+        names = ["k_colx16" if fused else "k_col_fwd", "k_row", "k_col_inv", "control"]
+        kern = {}
+        for k in range(3):
+            if k_n[k]:
+                avg_ms = k_ms[k] / k_n[k]
+                # with a power ladder the launches shrink as frames finish: bytes per launch = bytes of the frames still active
+                act = float(np.mean([(ncyc > s).sum() for s in range(int(ncyc.max()))])) if len(ncyc) else float(F)
+                gbs = SWEEP_BYTES * act * n / (avg_ms * 1e-3) / 1e9
+                kern[names[k]] = {"avg_launch_us": avg_ms * 1e3, "active_launches": int(k_n[k]), "achieved_GBs": gbs,
+                                  "frac_of_8TBs": gbs / HBM_PEAK_GBS}
+        dom = max(kern, key=lambda k_: kern[k_]["avg_launch_us"] * kern[k_]["active_launches"]) if kern else names[0]
+        sweeps = 2 if fused else 3
+        group_bytes = SWEEP_BYTES * sweeps
+        group_gbs = group_bytes * sample_steps / (fib * 1e-3) / 1e9
+        traffic, traffic_src = offline_traffic(fused, F, n) if (a.flag == "g-s-" and n == 65536) else (None, None)
+        active_frames = float(np.mean([(ncyc > s).sum() for s in range(int(ncyc.max()))])) if len(ncyc) else float(F)
         out = {
             "metric": "dual-pol Gsample/s through SSFM+Rx-DSP", "value": value, "unit": "Gsample/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -292,22 +438,43 @@ def main():
                                    "dual-pol frame, %dx80 km SSMF span fiber('%s'), CDE_OFDE 256/128, CMA 7 taps + "
                                    "V&V carrier recovery; front end: %s" % (int(np.log2(n)), a.spans, a.flag, a.frontend),
                        "frames_per_gpu_per_step": F, "nsymb": a.nsymb, "nt": a.nt, "pavg_mw": a.pavg,
-                       "ssfm_steps_per_frame": sample_steps / (a.steps * F * n), "rx_noise_sigma": a.noise,
+                       "tx_variants": hp.nvar, "power_ladder": bool(a.power_ladder),
+                       "ssfm_steps_per_frame": sample_steps / (a.steps * F * n),
+                       "ssfm_steps_min_max": [int(ncyc.min()), int(ncyc.max())] if len(ncyc) else None,
+                       # lock-step launches: share of the launched frame slots that still had a step to do (finished frames
+                       # cost an early-exit, not a sweep)
+                       "active_frame_utilisation": float(ncyc.sum() / (F * ncyc.max())) if len(ncyc) else None,
+                       "rx_noise_sigma": a.noise,
                        "fibre_ms_per_step": fib / a.steps, "rxdsp_ms_per_step": rxm / a.steps,
-                       "mc_realisations_per_s": float(world) * a.steps * F / dt, "fresh_pmd_per_realisation": bool(a.mc),
+                       "frames_per_s": float(world) * a.steps * F / dt, "fresh_pmd_per_realisation": bool(a.mc),
                        "bit_errors_xy": err_total.cpu().tolist(),
                        "bit_errors_resolved": int(res_total.item()) if a.mc else None,
                        "bits": int(world) * a.steps * F * 4 * a.nsymb, "restaged_batches": restaged,
+                       "rehearsal_all_ranks_on_one_gpu": bool(rehearsal),
                        "single_frame": single},
-            "roofline": {"bound": "hbm", "kernel": "SSFM step (k_colx16 [inverse + forward column pass, fused] + k_row)"
-                         if not os.environ.get("PLX_SSFM_NO_FUSE") and a.nsymb * a.nt == 65536 else "SSFM step (k_col_fwd + k_row + k_col_inv)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": SSFM_BYTES_PER_SAMPLE_STEP * F * n,
-                         "traffic": traffic, "sample_steps_per_s": sample_steps / (fib * 1e-3),
-                         "launches": row_launches, "ms_per_step_launch": fib / max(1, row_launches),
-                         "measured_inplace_rw_stream_GBs": 5100.0,   # scripts/micro/seg_copy.hip, profiles/r01_notes.md
-                         "note": "one step-launch = the kernels of one SSFM step over the whole batch; 'launches' also counts "
-                                 "the few no-op launches of the chunked step loop after every frame has finished"},
+            "roofline": {"bound": "hbm", "kernel": dom,
+                         "achieved": kern.get(dom, {}).get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": kern.get(dom, {}).get("frac_of_8TBs"),
+                         "algorithmic_bytes_per_launch": SWEEP_BYTES * active_frames * n,
+                         "bytes_per_sample_per_launch": SWEEP_BYTES,
+                         "avg_launch_us": kern.get(dom, {}).get("avg_launch_us"),
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernels": kern,
+                         "step_group": {"kernels": [k_ for k_ in names[:3] if k_ in kern], "bytes_per_sample_step": group_bytes,
+                                        "achieved_GBs": group_gbs, "frac_of_8TBs": group_gbs / HBM_PEAK_GBS,
+                                        "sample_steps_per_s": sample_steps / (fib * 1e-3),
+                                        "timed_by": "HIP events around plx_ssfm_propagate_dev on the fibre stream (launch gaps, "
+                                                    "memsets and the chunked loop's idle launches included)"},
+                         "achievable": {"hbm_copy_GBs": HBM_COPY_GBS, "inplace_read_modify_write_GBs": INPLACE_RW_GBS,
+                                        "frac_of_inplace_rw": (kern.get(dom, {}).get("achieved_GBs") or 0.0) / INPLACE_RW_GBS},
+                         "limiter": "below the HBM roof: %s holds 16 FP64 complex points per lane (256 VGPRs, 8 waves per CU) and "
+                                    "waits at the per-frame barrier of nextstep's maximum; k_row streams at the in-place "
+                                    "read-modify-write rate" % names[0] if fused else "three plain sweeps at the in-place streaming rate",
+                         "survey_accounting": {"bytes_per_sample_step": SURVEY_BYTES_PER_SAMPLE_STEP,
+                                               "frac": SURVEY_BYTES_PER_SAMPLE_STEP * sample_steps / (fib * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                               "note": "SURVEY 8(d)'s four-sweep budget; this implementation moves %d B" % int(group_bytes)},
+                         "launches": int(row_launches)},
+            "mc": mc_out,
         }
         if not a.no_cpu_baseline and world == 1:      # a reported baseline, timed at N = 1 only
             (v, cdt, nc), allc = cpu_baseline(cfg, hp, a.cpu_frames, a.noise)
@@ -321,6 +488,7 @@ def main():
                                                  "sample": "%d processes x %d frame(s) each, busiest process %.1f s (%.1f s "
                                                            "wall incl. process start)" % (cores, per, busiest, wall)}
         print(json.dumps(out))
+        sys.stdout.flush()
     hp.close()
     if world > 1:
         dist.destroy_process_group()

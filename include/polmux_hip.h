@@ -107,6 +107,17 @@ int plx_ssfm_results(plx_ssfm *plan, int nframes, double *firstdz, int32_t *ncyc
 /* kernel-time accounting of the last propagate: launches of the dominant
  * (row-pass) kernel and sample-steps processed                                     */
 int plx_ssfm_stats(plx_ssfm *plan, int64_t *row_pass_launches, int64_t *sample_steps);
+/* Optional per-kernel timing of the step loop, for roofline reports: with profiling enabled every propagate call
+ * records a HIP event between consecutive launches on its stream; after the call, ms[k] / launches[k] hold the
+ * summed duration and count of the ACTIVE launches (those issued before the slowest frame had finished) of kernel
+ * class k: 0 = column sweep that starts a step (fused k_colx16, or k_col_fwd), 1 = k_row, 2 = k_col_inv,
+ * 3 = step control / row sums / read-backs.  Both arrays have 4 entries.                                         */
+/* How the plan runs a step (for reports): info[0] 1 = fused column sweep (two sweeps per step), 0 = three sweeps;
+ * [1] log2 N1, [2] log2 N2 of the four-step split; [3] grid of the fused sweep; [4] column tiles per frame;
+ * [5] threads per column workgroup, [6] per row workgroup; [7] 1 = one polarisation per row workgroup.  8 entries. */
+int plx_ssfm_info(plx_ssfm *plan, int32_t *info);
+int plx_ssfm_profile(plx_ssfm *plan, int enable);
+int plx_ssfm_kernel_times(plx_ssfm *plan, double *ms, int64_t *launches);
 
 /* gateway forms: [firstdz,ncycle,ux,uy,brf]=matrix_ssfm(...) fiber.m:459-460 and
  * [firstdz,ncycle,u]=scalar_ssfm(...) :557-558 on one frame; split planes in/out
@@ -198,6 +209,10 @@ int64_t plx_dsp_out_len(const plx_dsp *plan);
  * ambiguity of each polarisation separately; their sum is the reference's err).    */
 int plx_decide_count_dev(const double *d_sym, int64_t L, int32_t ncol, int nframes, const uint8_t *d_pat,
                          uint8_t *d_pat_hat, int64_t *d_err, void *stream);
+/* the same with a transmitted pattern PER FRAME (frames of a batch that carry different sequences): frame f compares
+ * with d_pat + f * pat_frame_stride bytes (0: one shared pattern, as above)                                       */
+int plx_decide_count_frames_dev(const double *d_sym, int64_t L, int32_t ncol, int nframes, const uint8_t *d_pat,
+                                int64_t pat_frame_stride, uint8_t *d_pat_hat, int64_t *d_err, void *stream);
 
 /* ----------------------------------------------------------------- ampliflat --- */
 /* ampliflat(x,'gain',options), ampliflat.m:60-148 ("next" row): FIELD *= sqrt(gain) and

@@ -64,6 +64,9 @@ SIGNATURES = {
     "plx_ssfm_propagate_dev": [_vp, _vp, _vp, C.c_int, _vp],
     "plx_ssfm_results": [_vp, C.c_int, _vp, _vp],
     "plx_ssfm_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
+    "plx_ssfm_info": [_vp, _vp],
+    "plx_ssfm_profile": [_vp, C.c_int],
+    "plx_ssfm_kernel_times": [_vp, _vp, _vp],
     "plx_matrix_ssfm": [_vp, _vp, _vp, _vp, C.POINTER(SsfmDesc), _vp, _vp, _vp, C.POINTER(_dbl),
                         C.POINTER(_i32)],
     "plx_scalar_ssfm": [_vp, _vp, C.POINTER(SsfmDesc), C.POINTER(_dbl), C.POINTER(_i32)],
@@ -81,6 +84,7 @@ SIGNATURES = {
     "plx_dsp_run_dev": [_vp, _vp, _vp, C.c_int, _vp],
     "plx_dsp_out_len": [_vp],
     "plx_decide_count_dev": [_vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _vp],
+    "plx_decide_count_frames_dev": [_vp, _i64, _i32, C.c_int, _vp, _i64, _vp, _vp, _vp],
     "plx_ampliflat_dev": [_vp, _vp, _i64, _i32, C.c_int, _dbl, _vp, _vp, C.c_uint64, _vp, _i32, _i32, _vp],
     "plx_front_create": [C.POINTER(_vp), C.POINTER(FrontDesc)],
     "plx_front_destroy": [_vp],

@@ -612,7 +612,8 @@ __global__ __launch_bounds__(256) void k_cpe(CpeArgs a)
 // ====================================================== decisions + error count ======
 // samp2pat 'coherent' (samp2pat.m:61-66) and err = sum(sum(pat ~= pat_hat)) (ber_estimate.m:119),
 // kept per column so that a caller can resolve the pi/2 ambiguity of each polarisation.
-__global__ __launch_bounds__(256) void k_decide(const cplx *sym, int64_t L, int ncol, const uint8_t *pat,
+// pstride: bytes between the pattern blocks of consecutive frames (0: one pattern shared by all frames)
+__global__ __launch_bounds__(256) void k_decide(const cplx *sym, int64_t L, int ncol, const uint8_t *pat, size_t pstride,
                                                 uint8_t *pat_hat, unsigned long long *err)
 {
     PLX_DYN_LDS(lds);
@@ -621,6 +622,7 @@ __global__ __launch_bounds__(256) void k_decide(const cplx *sym, int64_t L, int 
     const size_t fc = blockIdx.x, f = fc / ncol;
     const int c = (int)(fc - f * ncol);
     unsigned long long cnt = 0;
+    if (pat) pat += f * pstride;
     for (int64_t i = tid; i < L; i += nthr) {
         const cplx v = sym[fc * (size_t)L + i];
         const double ph = atan2(v.y, v.x);
@@ -1039,12 +1041,18 @@ extern "C" int plx_dsp_run_dev(plx_dsp *P, const double *d_in, double *d_out, in
     return PLX_OK;
 }
 
+extern "C" int plx_decide_count_frames_dev(const double *d_sym, int64_t L, int32_t ncol, int nframes, const uint8_t *d_pat,
+                                           int64_t pat_frame_stride, uint8_t *d_pat_hat, int64_t *d_err, void *stream)
+{
+    if (!d_sym || L < 1 || ncol < 1 || nframes < 1 || pat_frame_stride < 0) PLX_FAIL(PLX_ERR_ARG, "plx_decide_count_dev: bad argument");
+    PLX_LAUNCH(k_decide, dim3((unsigned)(nframes * ncol)), dim3(256), 16 * sizeof(unsigned long long), stream,
+               (const cplx *)d_sym, L, (int)ncol, d_pat, (size_t)pat_frame_stride, d_pat_hat, (unsigned long long *)d_err);
+    PLX_HIP(hipGetLastError());
+    return PLX_OK;
+}
+
 extern "C" int plx_decide_count_dev(const double *d_sym, int64_t L, int32_t ncol, int nframes, const uint8_t *d_pat,
                                     uint8_t *d_pat_hat, int64_t *d_err, void *stream)
 {
-    if (!d_sym || L < 1 || ncol < 1 || nframes < 1) PLX_FAIL(PLX_ERR_ARG, "plx_decide_count_dev: bad argument");
-    PLX_LAUNCH(k_decide, dim3((unsigned)(nframes * ncol)), dim3(256), 16 * sizeof(unsigned long long), stream,
-               (const cplx *)d_sym, L, (int)ncol, d_pat, d_pat_hat, (unsigned long long *)d_err);
-    PLX_HIP(hipGetLastError());
-    return PLX_OK;
+    return plx_decide_count_frames_dev(d_sym, L, ncol, nframes, d_pat, 0, d_pat_hat, d_err, stream);
 }

@@ -946,7 +946,13 @@ struct plx_ssfm {
     double *h_brf[2] = {nullptr, nullptr}; // pinned staging of the waveplate tables
     hipEvent_t brf_ev[2] = {nullptr, nullptr};
     int brf_slot = 0;
-    int64_t row_launches = 0, sample_steps = 0, frame_launches = 0;
+    int64_t row_launches = 0, sample_steps = 0;
+    // optional per-kernel timing of the step loop (plx_ssfm_profile): one event between consecutive launches
+    int profile = 0;
+    std::vector<hipEvent_t> evpool;
+    std::vector<int> ev_class, ev_step;      // kernel class / step index of the launch that follows event i
+    double k_ms[4] = {0, 0, 0, 0};
+    int64_t k_launches[4] = {0, 0, 0, 0};
 };
 
 static const double kInv2Pi = 0.15915494309189533577;
@@ -966,6 +972,7 @@ static void free_plan(plx_ssfm *P)
     hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_pubw);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     if (P->ev) hipEventDestroy(P->ev);
+    for (hipEvent_t e : P->evpool) hipEventDestroy(e);
     for (int k = 0; k < 2; k++) {
         if (P->h_brf[k]) hipHostFree(P->h_brf[k]);
         if (P->brf_ev[k]) hipEventDestroy(P->brf_ev[k]);
@@ -1293,6 +1300,22 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     int chunk = 4, steps = 0;
     const int kMaxSteps = 1 << 22;
     bool pending = false, aborted = false;
+    // profiling: an event in front of every launch of the loop (and one after the last); intervals are attributed to
+    // the kernel class that follows the event.  Classes: 0 k_colx16 / k_col_fwd, 1 k_row, 2 k_col_inv, 3 control.
+    size_t nev = 0;
+    P->ev_class.clear(); P->ev_step.clear();
+    auto mark = [&](int cls, int step) -> int {
+        if (!P->profile) return PLX_OK;
+        if (nev == P->evpool.size()) {
+            hipEvent_t e;
+            PLX_HIP(hipEventCreate(&e));
+            P->evpool.push_back(e);
+        }
+        PLX_HIP(hipEventRecord(P->evpool[nev++], st));
+        P->ev_class.push_back(cls); P->ev_step.push_back(step);
+        return PLX_OK;
+    };
+#define PLX_MARK(cls, step) do { int rc_ = mark((cls), (step)); if (rc_) return rc_; } while (0)
     for (;;) {
         for (int sidx = 0; sidx < chunk; sidx++) {
             if (fused) {
@@ -1303,21 +1326,26 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
                 emu::g_concurrency = getenv("PLX_EMU_STARVE") ? 1 : P->tiles_pf;
 #endif
                 a.round = steps + sidx;
+                PLX_MARK(0, steps + sidx);
                 PLX_LAUNCH(k_colx16, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
 #endif
+                PLX_MARK(1, steps + sidx);
                 PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
                 P->row_launches++;
                 continue;
             }
+            PLX_MARK(3, steps + sidx);
             PLX_LAUNCH(k_ctrl, gctl, bctl, 0, st, a, nframes);
             if (!a.dual && a.xpm) {
                 unsigned gx = (unsigned)((P->N + 255) / 256);
                 if (gx > 256) gx = 256;
                 PLX_LAUNCH(k_rowsum, dim3(gx, (unsigned)nframes), blk, 0, st, a);
             }
+            PLX_MARK(0, steps + sidx);
             PLX_LAUNCH(k_col_fwd, gcol, bcol, P->lds_col, st, a);
+            PLX_MARK(1, steps + sidx);
             if (P->row_split && !a.pmd) {
                 SsfmArgs b = a;
                 b.dual = 0; b.R = 1; b.logR = 0;
@@ -1327,9 +1355,11 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
                 PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
             }
             else PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
+            PLX_MARK(2, steps + sidx);
             PLX_LAUNCH(k_col_inv, gcol, bcol, P->lds_col, st, a);
             P->row_launches++;
         }
+        PLX_MARK(3, steps + chunk);     // closes the last interval of the chunk (the read-back below lands in class 3)
         steps += chunk;
         if (pending) {
             PLX_HIP(hipEventSynchronize(P->ev));
@@ -1350,11 +1380,51 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
                               "another kernel holds the GPU); nothing was stored after the timeout -- create the plan with "
                               "PLX_SSFM_NO_FUSE=1 to share the device");
     P->sample_steps = 0;
+    int maxnc = 0;
     for (int f = 0; f < nframes; f++) {
         if (!P->h_ctl[f].done) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: a frame did not reach the fibre end");
         P->sample_steps += (int64_t)P->h_ctl[f].ncycle * (int64_t)P->N * nfc;
+        if (P->h_ctl[f].ncycle > maxnc) maxnc = P->h_ctl[f].ncycle;
     }
+    if (P->profile) {
+        // ACTIVE launches only: the chunked loop also issues launches after every frame has finished (they return at
+        // once).  Step s of the slowest frame is its (s+1)-th; the fused column sweep needs one more round to finish
+        // the last step and write the field out.
+        for (int k = 0; k < 4; k++) { P->k_ms[k] = 0; P->k_launches[k] = 0; }
+        for (size_t i = 0; i + 1 < nev; i++) {
+            const int cls = P->ev_class[i], step = P->ev_step[i];
+            const bool active = (fused && cls == 0) ? step <= maxnc : step < maxnc;
+            if (!active) continue;
+            float ms = 0;
+            PLX_HIP(hipEventElapsedTime(&ms, P->evpool[i], P->evpool[i + 1]));
+            P->k_ms[cls] += ms;
+            P->k_launches[cls]++;
+        }
+    }
+#undef PLX_MARK
     PLX_HIP(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_info(plx_ssfm *P, int32_t *info)
+{
+    if (!P || !info) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_info: null argument");
+    info[0] = P->fused; info[1] = P->p1; info[2] = P->p2; info[3] = P->fused_grid; info[4] = P->tiles_pf;
+    info[5] = P->col_threads; info[6] = P->row_threads; info[7] = P->row_split;
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_profile(plx_ssfm *P, int enable)
+{
+    if (!P) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_profile: null plan");
+    P->profile = enable ? 1 : 0;
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_kernel_times(plx_ssfm *P, double *ms, int64_t *launches)
+{
+    if (!P || !ms || !launches) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_kernel_times: null argument");
+    for (int k = 0; k < 4; k++) { ms[k] = P->k_ms[k]; launches[k] = P->k_launches[k]; }
     return PLX_OK;
 }
 

@@ -37,12 +37,16 @@ class HotPathConfig:
                  dgd=0.1, nplates=100, manakov="no", nspans=1, fft_length=256, cde_L=128, applypol=True,
                  polmethod="cma", cma_taps=7, cma_mu=1 / 6000, freqavg=500, phasavg=3, poworder=2,
                  frontend="pick", oftype="gauss", obw=1.9, oord=3, eftype="bessel5", ebw=0.65, eord=4, lopower=0.0,
-                 adcbits=5, span_nf_db=None):
+                 adcbits=5, span_nf_db=None, rx_amp=False, variants=1):
         """frontend: 'pick' = 2-sps sampling supplied by the harness; 'cohmix' = the reference's own
         receiver_cohmix + ADC + decimate chain (RxPdmCohQpsk.m, Run_my_PDM_QPSK.m:52-73 defaults) on the device.
         nspans > 1: every span but the last is followed by an in-line flat amplifier restoring its loss
         (ampliflat(G,'gain'), noiseless or with noise figure span_nf_db and ASE keyed per frame); the last span's loss is
-        undone in the receiver scale, as for one span."""
+        undone in the receiver scale, as for one span -- unless rx_amp: then the last span is followed by an amplifier as
+        well (gain = span loss, ASE from span_nf_db), the `fiber(...); ampliflat(Gerbio,'gain',ampli)` of
+        ex20_coherent_polmux.m:147-148 / ex24_pmd.m:86-87, and the receiver sees the amplified, noise-loaded field.
+        variants: number of distinct Tx waveforms (de Bruijn seed pairs s+1, s+2 as Run_my_PDM_QPSK.m:104-105 does per
+        channel); frame f carries variant f % variants, with its own transmitted bits for the error count."""
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -58,8 +62,6 @@ class HotPath:
         self.cfg = cfg
         self.F = int(max_frames)
         self.lib = _abi.get()
-        import os
-        self.group = int(os.environ.get("PLX_FIBRE_GROUP", "0"))
         self.dev = torch.device("cuda", torch.cuda.current_device())
         n = cfg.nfft
         # --- host side of fiber(): flag, conversions, tables (fiber.m:157-362) ---
@@ -86,6 +88,8 @@ class HotPath:
         self.ssfm = C.c_void_p()
         self.lib.call("plx_ssfm_create", C.byref(self.ssfm), C.byref(d))
         self.nplates = nplates
+        self._profiling = False
+        self._kms, self._kn = np.zeros(4), np.zeros(4, np.int64)
         if self.pmd:   # Monte-Carlo style: an independent random birefringence draw per frame (fiber.m:274-276)
             self.set_random_pmd(range(self.F))
         # --- Tx (host, once): Run_my_PDM_QPSK.m:101-117 ---
@@ -96,6 +100,19 @@ class HotPath:
         GSTATE.POWER = np.array([power])
         self.tx = torch.from_numpy(np.stack([ux, uy])).to(self.dev)          # [2, n]
         self.pat = torch.from_numpy(np.ascontiguousarray(bits.T.astype(np.uint8))).to(self.dev)   # [4, nsymb]
+        # further Tx waveforms (other de Bruijn seeds): heterogeneous batches whose frames differ in data
+        self.var_host = [(ux, uy, bits)]
+        maxseed = cfg.nsymb * (cfg.nsymb - 1) // 4
+        for v in range(1, max(1, int(cfg.variants))):
+            vx, vy, vb, vp = synth.pdm_qpsk_field(cfg.nsymb, cfg.nt, cfg.pavg_mw, (2 + 2 * v) % maxseed, (3 + 2 * v) % maxseed)
+            assert abs(vp - power) <= 1e-9 * power      # de Bruijn sequences share their symbol statistics
+            self.var_host.append((vx, vy, vb))
+        self.nvar = len(self.var_host)
+        if self.nvar > 1:
+            self.tx_var = torch.from_numpy(np.stack([np.stack([v[0], v[1]]) for v in self.var_host])).to(self.dev)   # [V, 2, n]
+            pv = np.stack([np.ascontiguousarray(v[2].T.astype(np.uint8)) for v in self.var_host])               # [V, 4, nsymb]
+            self.pat_frames = torch.from_numpy(pv[np.arange(self.F) % self.nvar].copy()).to(self.dev)          # [F, 4, nsymb]
+        self.rx_gain = None                              # per-frame receiver scale of a launch-power ladder (make_batch)
         # --- Rx plans ---
         self.Lrx = 2 * cfg.nsymb
         fs = 2 * cfg.symbolrate * 1e9                                         # Run_my_PDM_QPSK.m:66,149
@@ -113,7 +130,9 @@ class HotPath:
         self.lib.call("plx_dsp_create", C.byref(self.dsp), self.Lrx, 2, self.F, C.byref(self.dsp_p))
         # receive scale: undo the span loss and bring symbols to the 4*sqrt(P) full scale that
         # DspPdmCohQpsk divides by (DspPdmCohQpsk.m:22-23, "2* -> see receiver_cohmix")
-        self.rx_scale = 4.0 * math.sqrt(power) / math.sqrt(power / 2.0) * math.exp(0.5 * self.alphalin * cfg.length)
+        self.rx_scale = 4.0 * math.sqrt(power) / math.sqrt(power / 2.0)
+        if not cfg.rx_amp:
+            self.rx_scale *= math.exp(0.5 * self.alphalin * cfg.length)
         self.front = None
         if cfg.frontend == "cohmix":
             from . import rxfront
@@ -121,7 +140,8 @@ class HotPath:
                       lopower=cfg.lopower)
             hopt, elo, hel, post_delay, _ = rxfront._front_tables(1, rp, nfc=1)
             # in-line amplifier restoring the span loss, folded into the optical filter table (no extra sweep)
-            hopt = hopt * math.exp(0.5 * self.alphalin * cfg.length)
+            if not cfg.rx_amp:
+                hopt = hopt * math.exp(0.5 * self.alphalin * cfg.length)
             r = cfg.nt // 2                                                    # RxPdmCohQpsk.m:49-53, 2 samples/symbol
             delay = rxfront.evaldelay(cfg.oftype, cfg.obw * 0.5) + rxfront.evaldelay(cfg.eftype, cfg.ebw) + post_delay
             self.front_shifts = [rxfront._mround(-delay * cfg.nt)] * 2         # 'theory' delay, RxPdmCohQpsk.m:124-137
@@ -146,14 +166,23 @@ class HotPath:
 
     # ------------------------------------------------------------------ inputs ---
     def make_batch(self, nframes, launch_scale=None):
-        """Synthetic inputs: the Tx waveform replicated over frames -> (ux, uy), each [F, n] complex128,
-        with an optional per-frame launch-power scaling (power sweep)."""
+        """Synthetic inputs -> (ux, uy), each [F, n] complex128: frame f carries Tx waveform f % variants, with an
+        optional per-frame launch-power scaling (power sweep; the receiver then normalises each frame by its own
+        launch power, as a per-run GSTATE.POWER does in DspPdmCohQpsk.m:22-23)."""
         torch = self.torch
-        ux = self.tx[0].unsqueeze(0).repeat(nframes, 1).contiguous()
-        uy = self.tx[1].unsqueeze(0).repeat(nframes, 1).contiguous()
+        if self.nvar > 1:
+            idx = torch.arange(nframes, device=self.dev) % self.nvar
+            ux = self.tx_var[idx, 0].contiguous()
+            uy = self.tx_var[idx, 1].contiguous()
+        else:
+            ux = self.tx[0].unsqueeze(0).repeat(nframes, 1).contiguous()
+            uy = self.tx[1].unsqueeze(0).repeat(nframes, 1).contiguous()
+        self.rx_gain = None
         if launch_scale is not None:
-            k = torch.as_tensor(np.sqrt(np.asarray(launch_scale, dtype=float)), device=self.dev).reshape(-1, 1)
+            ls = np.asarray(launch_scale, dtype=float).reshape(-1)
+            k = torch.as_tensor(np.sqrt(ls), device=self.dev).reshape(-1, 1)
             ux, uy = ux * k, uy * k
+            self.rx_gain = torch.as_tensor(1.0 / np.sqrt(ls), device=self.dev).reshape(-1, 1, 1)
         return ux, uy
 
     def set_random_pmd(self, seeds):
@@ -179,24 +208,28 @@ class HotPath:
     def stream(self):
         return self.torch.cuda.current_stream().cuda_stream
 
-    def fibre(self, ux, uy, span_keys=None):
-        """ux, uy: [F, n] complex128 device tensors ([frame][channel=1][nfft]), propagated in place."""
+    def fibre(self, ux, uy, span_keys=None, inject_noise=None):
+        """ux, uy: [F, n] complex128 device tensors ([frame][channel=1][nfft]), propagated in place.
+        span_keys: per-frame keys of the amplifiers' ASE streams (realisation indices).  inject_noise: optional list,
+        one entry per amplifier, of [F, 2, n] complex128 device tensors used INSTEAD of the device generator
+        (ampliflat's options.noise, ampliflat.m:123-129: the parity route)."""
         F = ux.shape[0]
-        g = self.group or F
         self._rows = self._steps = 0
+        self._kms, self._kn = np.zeros(4), np.zeros(4, np.int64)
         cfg = self.cfg
+        namp = 0
         for span in range(cfg.nspans):
-            # frames are independent: propagating them in groups whose fields fit the 256 MiB Infinity
-            # Cache keeps the three sweeps of every step on-die instead of streaming HBM
-            for f0 in range(0, F, g):
-                n = min(g, F - f0)
-                self.lib.call("plx_ssfm_propagate_dev", self.ssfm, ux[f0:f0 + n].data_ptr(), uy[f0:f0 + n].data_ptr(), n,
-                              self.stream())
-                rows, steps = C.c_int64(), C.c_int64()
-                self.lib.call("plx_ssfm_stats", self.ssfm, C.byref(rows), C.byref(steps))
-                self._rows += rows.value
-                self._steps += steps.value
-            if span + 1 < cfg.nspans:              # in-line amplifier (ampliflat.m), stays on the device
+            self.lib.call("plx_ssfm_propagate_dev", self.ssfm, ux.data_ptr(), uy.data_ptr(), F, self.stream())
+            rows, steps = C.c_int64(), C.c_int64()
+            self.lib.call("plx_ssfm_stats", self.ssfm, C.byref(rows), C.byref(steps))
+            self._rows += rows.value
+            self._steps += steps.value
+            if self._profiling:
+                ms, nl = np.zeros(4), np.zeros(4, np.int64)
+                self.lib.call("plx_ssfm_kernel_times", self.ssfm, ms.ctypes.data, nl.ctypes.data)
+                self._kms += ms
+                self._kn += nl
+            if span + 1 < cfg.nspans or cfg.rx_amp:   # in-line amplifier (ampliflat.m), stays on the device
                 gain = math.exp(self.alphalin * cfg.length)
                 sig = None
                 if cfg.span_nf_db is not None:
@@ -205,9 +238,12 @@ class HotPath:
                 kt = None
                 if span_keys is not None:
                     kt = self.torch.as_tensor(np.asarray(list(span_keys), dtype=np.int64), device=self.dev)
+                inj = inject_noise[namp] if inject_noise is not None else None
                 self.lib.call("plx_ampliflat_dev", ux.data_ptr(), uy.data_ptr(), cfg.nfft, 1, F, gain,
-                              sig.ctypes.data if sig is not None else None, None, (20260101 + 7919 * span) & (2 ** 64 - 1),
+                              sig.ctypes.data if sig is not None else None, inj.data_ptr() if inj is not None else None,
+                              (20260101 + 7919 * span) & (2 ** 64 - 1),
                               kt.data_ptr() if kt is not None else None, 1, 1, self.stream())
+                namp += 1
 
     def receive(self, ux, uy, noise_sigma=0.0, noise_seed=None, side_stream=None, noise_keys=None):
         """Front end (2-sps pick, or receiver_cohmix + ADC + decimate), CDE, DSP, decisions.  Returns err [F,2] (device).
@@ -229,11 +265,16 @@ class HotPath:
         st = self.stream()
         rx = self.rx[:F]
         if self.front is not None:             # receiver_cohmix + ADC + decimate; ux, uy are consumed
+            if self.rx_gain is not None:       # launch-power ladder: each frame normalised by its own power
+                ux.mul_(self.rx_gain[:F, :, 0])
+                uy.mul_(self.rx_gain[:F, :, 0])
             self.front.run(ux, uy, self.front_shifts, out=rx)
         else:
             for pol, src in enumerate((ux, uy)):   # rx[f][pol][i] = scale * u_pol[f][i*half]
                 self.lib.call("plx_pick_dev", src.data_ptr(), rx.data_ptr() + pol * self.Lrx * 16, cfg.nfft, self.Lrx, 0,
                               half, self.rx_scale, F, 2 * self.Lrx, st)
+        if self.rx_gain is not None and self.front is None:   # launch-power ladder: each frame normalised by its own power
+            rx.mul_(self.rx_gain[:F])
         if noise_sigma:
             sig = np.array([float(noise_sigma)])
             kt = None
@@ -244,9 +285,30 @@ class HotPath:
                           int(noise_seed or 0) & (2 ** 64 - 1), kt.data_ptr() if kt is not None else None, 1, 0, st)
         self.lib.call("plx_cde_apply_dev", self.cde, rx.data_ptr(), self.eq.data_ptr(), self.Lrx, 2 * F, st)
         self.lib.call("plx_dsp_run_dev", self.dsp, self.eq.data_ptr(), self.sym.data_ptr(), F, st)
-        self.lib.call("plx_decide_count_dev", self.sym.data_ptr(), cfg.nsymb, 2, F, self.pat.data_ptr(), None,
-                      self.err.data_ptr(), st)
+        if self.nvar > 1:     # frames carry different sequences: each compares with its own transmitted bits
+            self.lib.call("plx_decide_count_frames_dev", self.sym.data_ptr(), cfg.nsymb, 2, F, self.pat_frames.data_ptr(),
+                          4 * cfg.nsymb, None, self.err.data_ptr(), st)
+        else:
+            self.lib.call("plx_decide_count_dev", self.sym.data_ptr(), cfg.nsymb, 2, F, self.pat.data_ptr(), None,
+                          self.err.data_ptr(), st)
         return self.err[:F]
+
+    def _count_errors(self, F, swap):
+        """err [F, 2] of the symbols now in self.sym against the transmitted bits (tributaries exchanged if swap)."""
+        torch = self.torch
+        if self.nvar > 1:
+            pat = self.pat_frames[:F]
+            if swap:
+                pat = torch.cat([pat[:, 2:], pat[:, :2]], 1).contiguous()
+            self._pat_keep = pat          # alive until the kernel has run
+            self.lib.call("plx_decide_count_frames_dev", self.sym.data_ptr(), self.cfg.nsymb, 2, F, pat.data_ptr(),
+                          4 * self.cfg.nsymb, None, self.err.data_ptr(), self.stream())
+        else:
+            pat = torch.cat([self.pat[2:], self.pat[:2]]).contiguous() if swap else self.pat
+            self._pat_keep = pat
+            self.lib.call("plx_decide_count_dev", self.sym.data_ptr(), self.cfg.nsymb, 2, F, pat.data_ptr(), None,
+                          self.err.data_ptr(), self.stream())
+        return self.err[:F].clone()
 
     def errors_resolved(self, F):
         """Per-frame bit errors after resolving what a blind receiver cannot know: the pi/2 phase
@@ -255,15 +317,12 @@ class HotPath:
         the device decision/count kernel; returns an int64 tensor [F]."""
         torch = self.torch
         base = self.sym[:F].clone()
-        pats = (self.pat, torch.cat([self.pat[2:], self.pat[:2]]).contiguous())
         best = []
-        for pat in pats:
+        for swap in (False, True):
             b = None
             for k in range(4):
                 self.sym[:F] = base * (1j ** k)
-                self.lib.call("plx_decide_count_dev", self.sym.data_ptr(), self.cfg.nsymb, 2, F, pat.data_ptr(), None,
-                              self.err.data_ptr(), self.stream())
-                e = self.err[:F].clone()
+                e = self._count_errors(F, swap)
                 b = e if b is None else torch.minimum(b, e)
             best.append(b.sum(1))
         self.sym[:F] = base
@@ -277,9 +336,7 @@ class HotPath:
         base = self.sym[:F].clone()
         for k in range(4):
             self.sym[:F] = base * (1j ** k)
-            self.lib.call("plx_decide_count_dev", self.sym.data_ptr(), self.cfg.nsymb, 2, F, self.pat.data_ptr(), None,
-                          self.err.data_ptr(), self.stream())
-            e = self.err[:F].clone()
+            e = self._count_errors(F, False)
             best = e if best is None else torch.minimum(best, e)
         self.sym[:F] = base
         return best
@@ -287,6 +344,26 @@ class HotPath:
     def run(self, ux, uy, noise_sigma=0.0, noise_seed=None):
         self.fibre(ux, uy)
         return self.receive(ux, uy, noise_sigma, noise_seed)
+
+    def profile(self, on):
+        """per-kernel HIP-event timing of the step loop (plx_ssfm_profile); read with kernel_times() after fibre()"""
+        self._profiling = bool(on)
+        self.lib.call("plx_ssfm_profile", self.ssfm, int(bool(on)))
+
+    def kernel_times(self):
+        """(ms[4], active launches[4]) of the last fibre() call: column sweep that starts a step, k_row, k_col_inv, control"""
+        return self._kms.copy(), self._kn.copy()
+
+    def last_ncycle(self, F):
+        """ncycle (fiber.m:431) of each frame of the last propagate call"""
+        nc = np.zeros(F, np.int32)
+        self.lib.call("plx_ssfm_results", self.ssfm, F, None, nc.ctypes.data)
+        return nc
+
+    def fused(self):
+        info = (C.c_int32 * 8)()
+        self.lib.call("plx_ssfm_info", self.ssfm, info)
+        return bool(info[0])
 
     def ssfm_stats(self):
         """(row-pass launches, sample-steps) of the last fibre() call, summed over its frame groups"""
@@ -296,18 +373,28 @@ class HotPath:
 class McCampaign:
     """Monte-Carlo BER over random PMD + ASE realisations (the ex20-style loop around ber_estimate,
     with ex24's random-birefringence fibre): realisation r gets its own birefringence draw and its own
-    noise, both keyed by r alone, so any sharding of the indices over GPUs gives the same counts."""
+    noise, both keyed by r alone, so any sharding of the indices over GPUs gives the same counts.
 
-    def __init__(self, cfg, frames_per_call, noise_sigma):
+    ASE: with cfg.rx_amp the span is followed by ampliflat(Gerbio,'gain',{f: cfg.span_nf_db}) as in
+    ex20_coherent_polmux.m:147-148 (device Philox stream keyed by r, or `noise_provider(indices)` -> host array
+    [n, 2, nfft] complex, the options.noise injection of ampliflat.m:123-129, for parity tests); `noise_sigma`
+    additionally (or instead) loads the 2-sps receiver samples, the cheap stand-in used by small tests."""
+
+    def __init__(self, cfg, frames_per_call, noise_sigma=0.0, noise_provider=None):
         self.hp = HotPath(cfg, frames_per_call)
         self.F = frames_per_call
         self.sigma = noise_sigma
+        self.noise_provider = noise_provider
+        self.last = None          # (indices, ncycle) of the last simulate() call, for tests
 
     @property
     def bits_per_realisation(self):
         return 4 * self.hp.cfg.nsymb
 
-    def simulate(self, indices):
+    def simulate(self, indices, keep=None):
+        """Error counts (pol swap and pi/2 ambiguities resolved, ex20_coherent_polmux.m:160-173) of the realisations
+        `indices`.  keep(i0, idx, ux, uy): optional callback after the fibre + amplifier of each batch (tests read the
+        field back there)."""
         import torch
         hp = self.hp
         out = []
@@ -317,8 +404,13 @@ class McCampaign:
             if hp.pmd:
                 hp.set_random_pmd(idx)
             ux, uy = hp.make_batch(n)
-            hp.fibre(ux, uy)
-            hp.receive(ux, uy, self.sigma, 20260101, None, idx)   # noise keyed by realisation index
+            inj = None
+            if self.noise_provider is not None:
+                inj = [torch.from_numpy(np.ascontiguousarray(self.noise_provider(idx))).to(hp.dev)]
+            hp.fibre(ux, uy, span_keys=idx, inject_noise=inj)
+            if keep is not None:
+                keep(i0, idx, ux, uy)
+            hp.receive(ux, uy, self.sigma, 20260101, None, idx)   # receiver noise keyed by realisation index
             out.append(hp.errors_resolved(n).cpu().numpy())
         return np.concatenate(out) if out else np.zeros(0, np.int64)
 

@@ -1,0 +1,243 @@
+"""BASELINE.json's configurations AS STATED (SURVEY 8d "Concrete configs"), on the MI355X through the C ABI, against
+the CPU oracle on the same inputs.  test_gpu_parity.py holds the component tests; these are the whole configurations:
+
+  C0  32 Gbaud single-polarisation QPSK, 1 x 80 km linear span 'g---', post-compensation x.dpost in the receiver
+  C1  Run_my_PDM_QPSK frame (2^16 dual-pol, 80 km 'g-s-', CDE 256/128, CMA 7 taps at mu = 1/6000, CPE)
+  C3  Monte-Carlo realisations of the C1 frame: 'gps-' with 100 random waveplates per realisation + amplifier ASE
+  C4  2^20-sample dual-pol frame, spans with in-line amplifiers, two launch powers of the ladder
+(C2, the 16-channel WDM chain, is test_wdm_16ch_multispan_chain_vs_oracle_c2 in test_gpu_parity.py.)
+
+Bars: optical field <= 1e-9 relative (stated bar 1e-6), ncycle identical, decisions bit-exact.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+FIELD_RTOL = 1e-9
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch
+    assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
+    from polmux_amd import _abi
+    b = _abi.get()
+    assert b.path.endswith("polmux_amd/lib/libpolmux_hip.so")
+    return b
+
+
+def _sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+def _rx_oracle(oracle, cfg, hp, ox, oy, keys=None, rx_noise=None):
+    """front end (pick) -> CDE_OFDE -> DspPdmCohQpsk on the oracle; returns (symbols [nsymb x 2], decided bits)"""
+    half = cfg.nt // 2
+    rx = np.stack([ox[::half], oy[::half]], 1) * hp.rx_scale
+    if rx_noise is not None:
+        rx = rx + rx_noise
+    ex, ey, _ = oracle.cde_ofde(rx[:, 0], rx[:, 1], 2 * cfg.symbolrate * 1e9, cfg.lam * 1e-9, cfg.length * cfg.nspans,
+                                cfg.disp * 1e-6, 0.0, cfg.fft_length, cfg.cde_L)
+    op = oracle.dsp_params(power_mw=hp.power_mw, applypol=True, polmethod="cma", cma_mu=cfg.cma_mu, cma_taps=cfg.cma_taps,
+                           freqavg=cfg.freqavg, phasavg=cfg.phasavg, poworder=cfg.poworder)
+    ref = oracle.dsp_pdm_coh_qpsk(np.stack([ex, ey], 1), op)
+    return ref, oracle.samp2pat_coherent(np.angle(ref))
+
+
+def _screened_equal(got_bits, ref_sym, want_bits, tol=1e-6):
+    """decisions bit-exact, except symbols whose phase sits within tol rad of a decision boundary (there the two sides'
+    1e-8 symbol difference may legitimately flip the bit)"""
+    ph = np.angle(ref_sym)
+    near = (np.abs(np.abs(ph) - np.pi / 2) < tol) | (np.abs(ph) < tol) | (np.abs(np.abs(ph) - np.pi) < tol)    # [nsymb x 2]
+    mask = np.repeat(~near, 2, axis=1)
+    np.testing.assert_array_equal(got_bits[mask], want_bits[mask])
+    assert near.mean() < 1e-3
+
+
+# ================================================================================ C1 ===
+def test_c1_end_to_end_at_the_stated_cma_step(lib, oracle):
+    """BASELINE config[1] with EVERY stated parameter (CMA taps 7, mu = 1/6000, R = [1 1], L = 1024 symbols,
+    CDE 256/128, freqavg 500, phasavg 3, poworder 2): the CMA driver runs its full pass budget here (50*ceil(1/(L*mu)) - 1
+    = 299 passes unless the 5e-5 test stops it, DspPdmCohQpsk.m:175-191).  Symbols 1e-7, decisions identical."""
+    from polmux_amd import pipeline
+    cfg = pipeline.HotPathConfig()                       # the defaults ARE config[1]
+    assert cfg.cma_mu == 1 / 6000 and cfg.cma_taps == 7 and cfg.nfft == 65536 and cfg.flag == "g-s-"
+    hp = pipeline.HotPath(cfg, max_frames=2)
+    ux, uy = hp.make_batch(2)
+    err = hp.run(ux, uy)
+    _sync()
+    gam, betat, db1 = hp._keep
+    rc, fd, nc, ox, oy = oracle.matrix_ssfm(hp.tx_host[0], hp.tx_host[1], betat, db1, cfg.dzmax, cfg.dphimax, gam, hp.alphalin,
+                                            cfg.length, 1, 0, hp.fls, [0.0], [0.0], [0.0])
+    assert hp.last_ncycle(2).tolist() == [nc, nc]
+    assert np.abs(ux[1].cpu().numpy() - ox[:, 0]).max() <= FIELD_RTOL * np.abs(ox).max()
+    assert np.abs(uy[0].cpu().numpy() - oy[:, 0]).max() <= FIELD_RTOL * np.abs(oy).max()
+    ref, want = _rx_oracle(oracle, cfg, hp, ox[:, 0], oy[:, 0])
+    sym = hp.sym[0].cpu().numpy().T
+    np.testing.assert_allclose(sym, ref, atol=1e-7)
+    e = [int((want[:, :2] != hp.bits[:, :2]).sum()), int((want[:, 2:] != hp.bits[:, 2:]).sum())]
+    assert err.cpu().numpy()[0].tolist() == e
+    assert int(hp.errors_min_over_rotations(2).sum()) == 0      # noise-free span: error-free once the pi/2 ambiguity is resolved
+    hp.close()
+
+
+# ================================================================================ C3 ===
+def test_c3_monte_carlo_realisations_pmd_and_ase_vs_oracle(lib, oracle):
+    """BASELINE config[3] (ex24_pmd.m-style PMD + ex20_coherent_polmux.m:132-175's noisy amplifier): McCampaign at the
+    C1 frame (1024 x 64), fiber('gps-') with 100 waveplates drawn per realisation (fiber.m:260-276, set_random_pmd),
+    then ampliflat(Gerbio,'gain',{f, noise}) with the ASE INJECTED (options.noise, ampliflat.m:123-129) so that the
+    oracle sees the same noise.  Four sampled realisations of a 16-realisation batch are compared with
+    oracle.matrix_ssfm + amplifier + receiver chain: field 1e-9, ncycle, symbols, decisions."""
+    from polmux_amd import pipeline
+    from polmux_amd.ampliflat import ase_sigma
+    cfg = pipeline.HotPathConfig(flag="gps-", nplates=100, dgd=0.1, rx_amp=True, span_nf_db=27.0, cma_mu=1 / 600)
+    n = cfg.nfft
+
+    def noise_of(r):
+        g = np.random.default_rng(777000 + int(r))
+        return g.standard_normal((2, n)) + 1j * g.standard_normal((2, n))
+
+    camp = pipeline.McCampaign(cfg, frames_per_call=16, noise_provider=lambda idx: np.stack([noise_of(r) for r in idx]))
+    hp = camp.hp
+    idx = list(range(40, 56))
+    kept = {}
+
+    def keep(i0, ids, ux, uy):
+        _sync()
+        kept["x"], kept["y"] = ux.cpu().numpy(), uy.cpu().numpy()
+        kept["nc"] = hp.last_ncycle(len(ids))
+    errs = camp.simulate(idx, keep=keep)
+    _sync()
+    sym_dev = hp.sym[:16].cpu().numpy()
+    gam, betat, db1 = hp._keep
+    gain = math.exp(hp.alphalin * cfg.length)
+    sigma = float(ase_sigma(cfg.span_nf_db, gain, 1)[0])
+    ncs = set()
+    for pos in (0, 5, 11, 15):
+        r = idx[pos]
+        db0, th, ep = (a[0] for a in hp.set_random_pmd([r]))           # the draw of realisation r (keyed by r alone)
+        rc, fd, nc, ox, oy = oracle.matrix_ssfm(hp.tx_host[0], hp.tx_host[1], betat, db1, cfg.dzmax, cfg.dphimax, gam, hp.alphalin,
+                                                cfg.length, cfg.nplates, 0, hp.fls, db0, th, ep)
+        assert rc == 0 and kept["nc"][pos] == nc
+        ncs.add(nc)
+        nz = noise_of(r)
+        ox = math.sqrt(gain) * ox[:, 0] + sigma * nz[0]                # ampliflat.m:78-82, 123-136
+        oy = math.sqrt(gain) * oy[:, 0] + sigma * nz[1]
+        sc = max(np.abs(ox).max(), np.abs(oy).max())
+        assert np.abs(kept["x"][pos] - ox).max() <= FIELD_RTOL * sc
+        assert np.abs(kept["y"][pos] - oy).max() <= FIELD_RTOL * sc
+        ref, want = _rx_oracle(oracle, cfg, hp, ox, oy)
+        np.testing.assert_allclose(sym_dev[pos].T, ref, atol=1e-6)
+        # the campaign's count = errors after pol-swap / pi/2 resolution (ex20:160-173): same resolution on the oracle's symbols
+        best = None
+        for swap in (False, True):
+            tx = hp.bits if not swap else np.concatenate([hp.bits[:, 2:], hp.bits[:, :2]], 1)
+            tot = 0
+            for pol in (0, 1):
+                tot += min(int((oracle.samp2pat_coherent(np.angle(ref[:, pol:pol + 1] * 1j ** k)) != tx[:, 2 * pol:2 * pol + 2]).sum())
+                           for k in range(4))
+            best = tot if best is None else min(best, tot)
+        assert int(errs[pos]) == best
+    assert 0 < errs.sum() < 16 * camp.bits_per_realisation // 8       # noise-loaded but locked
+    # the device generator (Philox keyed by the realisation index) drives the same chain when nothing is injected
+    camp.noise_provider = None
+    e2 = camp.simulate(idx[:4])
+    assert 0 <= e2.min() and e2.max() < camp.bits_per_realisation // 4
+    camp.close()
+
+
+# ================================================================================ C4 ===
+def test_c4_2pow20_frame_two_spans_two_powers_vs_oracle(lib, oracle):
+    """BASELINE config[4] at FULL frame size: 2^20-sample dual-pol frames (Nsymb 16384 x Nt 64), two 80 km 'g-s-' spans
+    with the in-line amplifier between them, at two points of the launch-power ladder (-4 dBm and +5 dBm: different step
+    counts in one batch), against the oracle loop (about a minute of CPU)."""
+    from polmux_amd import pipeline
+    cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, nspans=2)
+    assert cfg.nfft == 1 << 20
+    hp = pipeline.HotPath(cfg, max_frames=2)
+    p_mw = np.array([10 ** (-4 / 10), 10 ** (5 / 10)])
+    scale = p_mw / cfg.pavg_mw
+    ux, uy = hp.make_batch(2, scale)
+    hp.fibre(ux, uy)
+    _sync()
+    gx, gy = ux.cpu().numpy(), uy.cpu().numpy()
+    steps_dev = hp.ssfm_stats()[1] // cfg.nfft
+    gam, betat, db1 = hp._keep
+    g = math.exp(hp.alphalin * cfg.length)
+    tot = 0
+    for f in (0, 1):
+        hx, hy = hp.tx_host[0] * math.sqrt(scale[f]), hp.tx_host[1] * math.sqrt(scale[f])
+        ncs = []
+        for s in range(2):
+            rc, fd, nc, hx, hy = oracle.matrix_ssfm(hx, hy, betat, db1, cfg.dzmax, cfg.dphimax, gam, hp.alphalin, cfg.length, 1, 0,
+                                                    hp.fls, [0.0], [0.0], [0.0])
+            assert rc == 0
+            hx, hy = hx[:, 0], hy[:, 0]
+            ncs.append(nc)
+            if s == 0:
+                hx, hy = math.sqrt(g) * hx, math.sqrt(g) * hy
+        tot += sum(ncs)
+        assert hp.last_ncycle(2)[f] == ncs[1]                          # the last span's fingerprint of this frame
+        assert np.abs(gx[f] - hx).max() <= FIELD_RTOL * np.abs(hx).max()
+        assert np.abs(gy[f] - hy).max() <= FIELD_RTOL * np.abs(hy).max()
+    assert steps_dev == tot                                            # every step of both spans, both frames
+    hp.close()
+
+
+# ================================================================================ C0 ===
+def test_c0_32gbaud_single_pol_linear_span_with_post_compensation(lib, oracle):
+    """BASELINE config[0] AT ITS STATED PARAMETERS: 32 Gbaud single-polarisation QPSK, Nsymb 256 x
+    Nt 64, one 80 km span fiber(x,'g---') (D = 17, alpha = 0.2: a single exact step, fiber.m:162-165), amplifier, and
+    the receiver's own post-compensating fibre x.dpost = -D*L (receiver_cohmix.m:149-168) in front of dsp4cohdec --
+    against scalar_ssfm + front.py + dsp_pdm_coh_qpsk of the oracle.  Linear and fully compensated: no bit errors."""
+    import polmux_amd as px
+    from oracle import front
+    from polmux_amd import rxfront, synth
+    from polmux_amd.fiber import fiber_tables, parse_flag
+    from polmux_amd.gstate import GSTATE, to_host_field
+    nsymb, nt = 256, 64
+    px.reset_all(nsymb, nt, 1)
+    GSTATE.SYMBOLRATE = 32.0
+    E = px.lasersource(1.0, 1550.0, 0.4)
+    pat, patmat = synth.pattern_debruijn(nsymb, 1, 4)
+    eopt = synth.qi_modulator(E[:, 0], synth.electricsource_qpsk(patmat[:, 0], nt, 1.0, 0.2),
+                              synth.electricsource_qpsk(patmat[:, 1], nt, 1.0, 0.2))
+    px.create_field("unique", eopt.reshape(-1, 1), None, dict(power="average"))
+    tx = to_host_field(GSTATE.FIELDX)[:, 0].copy()
+    fib = dict(length=8e4, alphadB=0.2, aeff=80.0, n2=2.7e-20, disp=17.0, slope=0.0, dphimax=5e-3, dzmax=2e4)
+    fib["lambda"] = 1550.0
+    px.fiber(fib, "g---")
+    px.ampliflat(0.2 * 80.0, "gain")                                   # Gerbio = alphadB * L
+    field = to_host_field(GSTATE.FIELDX)[:, 0]
+    fls, dph, dzm = parse_flag("g---", 1, fib)
+    t = fiber_tables(fib, fls, 1, 0.0)
+    fd, nc, ou = oracle.scalar_ssfm(tx.reshape(-1, 1), t["betat"], dzm, dph, t["gam"], t["alphalin"], fib["length"], fls)
+    assert nc == 1
+    ou = ou[:, 0] * math.sqrt(10 ** (0.2 * 80.0 / 10))
+    assert np.abs(field - ou).max() <= FIELD_RTOL * np.abs(ou).max()
+    assert np.abs(field - tx).max() > 0.1 * np.abs(tx).max()           # 1360 ps/nm at 32 Gbaud: the eye is gone
+    x = dict(rec="coherent", ts=0, oftype="gauss", obw=1.9, eftype="bessel5", ebw=0.65, delay="theory", lopower=0,
+             dpost=-17.0 * 80.0, slopez=0.0)
+    x["lambda"] = 1550.0
+    p = dict(sps=nt, workatbaudrate=False, applyadc=False, adcbits=5, samplingrate=64.0, applydcf=False, applynlr=False,
+             applypol=False, modorder=2, freqavg=500, phasavg=3, poworder=2)
+    phase, amp, eye = px.dsp4cohdec(1, pat, x, p)
+    hopt, elo, hel, post_delay, _ = rxfront._front_tables(1, x)
+    cur = front.receiver_cohmix(ou, None, hopt, elo, hel, True)
+    shift = rxfront._mround(-rxfront.theory_delay(1, x, False, post_delay) * nt)
+    rx = front.rx_front(cur, False, 0, [shift], nt // 2, rxfront.fir1_lowpass(16, 2.0 / nt))
+    op = oracle.dsp_params(power_mw=float(GSTATE.POWER[0]), applypol=False, freqavg=500, phasavg=3, poworder=2)
+    ref = oracle.dsp_pdm_coh_qpsk(rx, op)
+    got = amp.cpu().numpy() * np.exp(1j * phase.cpu().numpy())
+    np.testing.assert_allclose(got, ref, atol=1e-7)
+    pat_hat = px.samp2pat(x, None, phase.cpu().numpy())
+    want = oracle.samp2pat_coherent(np.angle(ref))
+    np.testing.assert_array_equal(pat_hat, want)
+    # no noise, dispersion undone: the transmitted bits come back up to the blind phase estimate's pi/2 ambiguity
+    errs = min(int((oracle.samp2pat_coherent(np.angle(ref * 1j ** k)) != patmat).sum()) for k in range(4))
+    assert errs == 0
