@@ -1,0 +1,39 @@
+"""Assemble profiles/rNN_traffic.json from the per-counter summaries of scripts/traffic_pmc.sh.
+usage: traffic_json.py <dir> <frames>"""
+import json
+import os
+import sys
+
+d, F = sys.argv[1], int(sys.argv[2])
+samples = F * 65536
+
+
+def read(mode, counter):
+    out = {}
+    for line in open(os.path.join(d, "%s_%s.txt" % (mode, counter))):
+        k, _, rest = line.partition(" ")
+        for tok in rest.split():
+            name, _, val = tok.partition("=")
+            if name == counter:
+                out[k] = float(val)
+    return out
+
+
+res = {"_how": "scripts/traffic_pmc.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes of "
+               "`python3 bench.py --frames %d --steps 1 --warmup 0 --variants 1 --mc-rounds 0 --no-cpu-baseline --no-overlap "
+               "--no-single-frame`; mean over ACTIVE launches (counter >= half of the largest).  gfx950 correction "
+               "(MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 1/2 of wide coalesced reads -> x2; WRITE_SIZE exact; unit KB "
+               "-> x1024." % F,
+       "samples_per_launch": samples}
+for mode, key, kernels in (("fused", None, ["k_colx16", "k_row"]), ("plain", "plain_three_sweep", ["k_col_fwd", "k_row", "k_col_inv"])):
+    fe, wr = read(mode, "FETCH_SIZE"), read(mode, "WRITE_SIZE")
+    per = {k: (2 * fe[k] + wr[k]) * 1024 / samples for k in kernels if k in fe and k in wr}
+    blk = {"kernels": kernels, "fetch_kb": [fe.get(k) for k in kernels], "write_kb": [wr.get(k) for k in kernels],
+           "bytes_per_sample_by_kernel": per, "bytes_per_sample_step": sum(per.values())}
+    if key is None:
+        res.update(blk)
+        res["default_path"] = "fused column sweep k_colx16 + k_row (2 sweeps per SSFM step)"
+    else:
+        blk["selected_by"] = "PLX_SSFM_NO_FUSE=1"
+        res[key] = blk
+print(json.dumps(res, indent=1))

@@ -1,14 +1,22 @@
 #!/bin/bash
 # HBM traffic of the SSFM step kernels from the PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
-# WRITE_SIZE in SEPARATE passes, with --kernel-trace only.  Writes gpurun_out/traffic/{fetch,write}.txt
+# WRITE_SIZE in SEPARATE passes, with --kernel-trace only.  Fused (default) and three-sweep (PLX_SSFM_NO_FUSE=1) step.
+# Writes gpurun_out/traffic/{fused,plain}_{FETCH_SIZE,WRITE_SIZE}.txt and gpurun_out/traffic/traffic.json
+# (copy the latter to profiles/rNN_traffic.json).   usage: scripts/traffic_pmc.sh [frames]
 export TMPDIR=/tmp
 R=$PWD
+F=${1:-256}
 mkdir -p gpurun_out/traffic
-for c in FETCH_SIZE WRITE_SIZE; do
-  rm -rf gpurun_out/traffic/pmc_$c
-  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/traffic/pmc_$c -- python3 bench.py --frames 256 --steps 1 --warmup 0 --no-cpu-baseline --no-overlap --no-single-frame > /dev/null 2>&1
-  f=$(find gpurun_out/traffic/pmc_$c -name "*counter_collection.csv" | head -1)
-  python scripts/pmc_summary.py $f > gpurun_out/traffic/$c.txt
-  cat gpurun_out/traffic/$c.txt | grep -E "k_colx16|k_row|k_col_fwd|k_col_inv"
-  rm -rf gpurun_out/traffic/pmc_$c
+for mode in fused plain; do
+  if [ $mode = plain ]; then export PLX_SSFM_NO_FUSE=1; else unset PLX_SSFM_NO_FUSE; fi
+  for c in FETCH_SIZE WRITE_SIZE; do
+    rm -rf gpurun_out/traffic/pmc_$c
+    timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/traffic/pmc_$c -- python3 bench.py --frames $F --steps 1 --warmup 0 --variants 1 --mc-rounds 0 --no-cpu-baseline --no-overlap --no-single-frame > /dev/null 2>&1 || exit 1
+    f=$(find gpurun_out/traffic/pmc_$c -name "*counter_collection.csv" | head -1)
+    python scripts/pmc_summary.py $f > gpurun_out/traffic/${mode}_$c.txt
+    grep -E "k_colx16|k_row|k_col_fwd|k_col_inv" gpurun_out/traffic/${mode}_$c.txt
+    rm -rf gpurun_out/traffic/pmc_$c
+  done
 done
+unset PLX_SSFM_NO_FUSE
+python scripts/traffic_json.py gpurun_out/traffic $F > gpurun_out/traffic/traffic.json && cat gpurun_out/traffic/traffic.json

@@ -35,12 +35,17 @@ def _sync():
     torch.cuda.synchronize()
 
 
-def _rx_oracle(oracle, cfg, hp, ox, oy, keys=None, rx_noise=None):
-    """front end (pick) -> CDE_OFDE -> DspPdmCohQpsk on the oracle; returns (symbols [nsymb x 2], decided bits)"""
-    half = cfg.nt // 2
-    rx = np.stack([ox[::half], oy[::half]], 1) * hp.rx_scale
-    if rx_noise is not None:
-        rx = rx + rx_noise
+def _rx_oracle(oracle, cfg, hp, ox, oy):
+    """front end (2-sps pick, or receiver_cohmix + timing + decimate) -> CDE_OFDE -> DspPdmCohQpsk on the oracle;
+    returns (symbols [nsymb x 2], decided bits)"""
+    if hp.front is not None:
+        from oracle import front
+        t = hp.front_tables
+        cur = front.receiver_cohmix(ox, oy, t["hopt"], t["elo"], t["hel"], True)
+        rx = front.rx_front(cur, True, cfg.adcbits, hp.front_shifts, t["decim"], t["fir"])
+    else:
+        half = cfg.nt // 2
+        rx = np.stack([ox[::half], oy[::half]], 1) * hp.rx_scale
     ex, ey, _ = oracle.cde_ofde(rx[:, 0], rx[:, 1], 2 * cfg.symbolrate * 1e9, cfg.lam * 1e-9, cfg.length * cfg.nspans,
                                 cfg.disp * 1e-6, 0.0, cfg.fft_length, cfg.cde_L)
     op = oracle.dsp_params(power_mw=hp.power_mw, applypol=True, polmethod="cma", cma_mu=cfg.cma_mu, cma_taps=cfg.cma_taps,
@@ -91,11 +96,14 @@ def test_c3_monte_carlo_realisations_pmd_and_ase_vs_oracle(lib, oracle):
     """BASELINE config[3] (ex24_pmd.m-style PMD + ex20_coherent_polmux.m:132-175's noisy amplifier): McCampaign at the
     C1 frame (1024 x 64), fiber('gps-') with 100 waveplates drawn per realisation (fiber.m:260-276, set_random_pmd),
     then ampliflat(Gerbio,'gain',{f, noise}) with the ASE INJECTED (options.noise, ampliflat.m:123-129) so that the
-    oracle sees the same noise.  Four sampled realisations of a 16-realisation batch are compared with
-    oracle.matrix_ssfm + amplifier + receiver chain: field 1e-9, ncycle, symbols, decisions."""
+    oracle sees the same noise, then the reference's own front end (receiver_cohmix gauss 1.9 / bessel5 0.65 + timing +
+    decimate: the white ASE of the 1.8 THz simulation band must be filtered; no ADC, as in ex20) -> CDE_OFDE -> CMA + CPE.
+    Four sampled realisations of a 16-realisation batch are compared with oracle.matrix_ssfm + amplifier + receiver
+    chain: field 1e-9, ncycle, symbols, error counts."""
     from polmux_amd import pipeline
     from polmux_amd.ampliflat import ase_sigma
-    cfg = pipeline.HotPathConfig(flag="gps-", nplates=100, dgd=0.1, rx_amp=True, span_nf_db=27.0, cma_mu=1 / 600)
+    cfg = pipeline.HotPathConfig(flag="gps-", nplates=100, dgd=0.1, rx_amp=True, span_nf_db=31.0, cma_mu=1 / 600,
+                                 frontend="cohmix", adcbits=0)
     n = cfg.nfft
 
     def noise_of(r):
