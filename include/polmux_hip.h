@@ -162,6 +162,17 @@ int plx_easiadaptivefilter(const double *xr, const double *xi, int32_t Mdim, dou
                            double *h2r, double *h2i, double Ntap, double mu, double sps, double *yr,
                            double *yi);
 
+/* The .m TWINS of the two filters -- what MATLAB runs when the MEX files are not compiled (comp_mex.m not run; the
+ * name then resolves to the .m, fastexp.m:6-7) -- with the semantics the twins really have, which differ from the C:
+ * cmaadaptivefilter.m:52-72 updates at EVERY sample (no sps gate), has no odd-taps check and RETURNS the updated taps;
+ * easiadaptivefilter.m:51-84 forms the error matrix from the complex outputs (abs(), complex denominators) and
+ * recombines ALL taps of the complex h1, h2.  ntap = size(h1,1); h1/h2 are updated in place (the shim returns them in
+ * plhs[1..2], so the unchanged drivers take their any(any(h1_new)) branch, DspPdmCohQpsk.m:183-186).                */
+int plx_cmaadaptivefilter_m(const double *xr, const double *xi, int32_t Mdim, double *h1r, double *h1i,
+                            double *h2r, double *h2i, int32_t ntap, double mu, const double *R, double *yr, double *yi);
+int plx_easiadaptivefilter_m(const double *xr, const double *xi, int32_t Mdim, double *h1r, double *h1i,
+                             double *h2r, double *h2i, int32_t ntap, double mu, double *yr, double *yi);
+
 /* resident, batched pol-demux driver: cmapolardemux / easipolardemux
  * (DspPdmCohQpsk.m:142-244 == dsp4cohdec.m:374-478): cyclic extension, centre-tap
  * init from M, pass loop with the 5e-5 convergence test, all on the device.
@@ -170,6 +181,7 @@ int plx_easiadaptivefilter(const double *xr, const double *xi, int32_t Mdim, dou
  * d_passes (optional out): int32 [frame].                                          */
 #define PLX_DEMUX_CMA 1
 #define PLX_DEMUX_EASI 2
+#define PLX_DEMUX_EASI_M 3   /* easipolardemux around the .m twin of the filter (easiadaptivefilter.m:51-84) */
 int plx_poldemux_dev(int method, const double *d_x, double *d_y, int64_t L, int nframes, int32_t taps,
                      double mu, const double *R /* host [2], CMA only */, const double *d_M,
                      double *d_h, int32_t *d_passes, void *stream);
@@ -191,6 +203,11 @@ typedef struct plx_dsp_params {
     int32_t easi_txpolars;
     double easi_phizero;
     int32_t modorder, freqavg, phasavg, poworder;
+    /* params.mat: explicit initial centre-tap matrix (DspPdmCohQpsk.m:148-149, :201-202), row-major 2x2 complex (re,im) */
+    int32_t cma_has_mat, easi_has_mat;
+    double cma_mat[8], easi_mat[8];
+    int32_t mfile_twins;    /* 1: the drivers call the .m twins of the filters (no MEX compiled) */
+    int32_t reserved_;
 } plx_dsp_params;
 
 typedef struct plx_dsp plx_dsp;

@@ -103,6 +103,10 @@ void plxo_easifilter(const double *xr, const double *xi, int Ndim, double *h1r,
 /* gateway argument checks (cmaadaptivefilter.c:118-133): 0 ok,
  * 1 "Ntaps should be an ODD INTEGER.", 2 "Samples x symbol should be either 1 or 2." */
 int plxo_cma_gateway_check(double Ntap, double sps, int check_odd);
+/* the .m twins (cmaadaptivefilter.m:52-72, easiadaptivefilter.m:51-84): xx [2][Ndim], h [2][ntap], y [2][Ndim-ntap+1] */
+void plxo_cmafilter_m(const plxo_c *xx, int Ndim, plxo_c *h1, plxo_c *h2, int ntap, double mu,
+                      const double *R, plxo_c *y);
+void plxo_easifilter_m(const plxo_c *xx, int Ndim, plxo_c *h1, plxo_c *h2, int ntap, double mu, plxo_c *y);
 
 /* ---- DspPdmCohQpsk.m drivers (x: [L x 2] column-major complex) ---- */
 /* M: 2x2 complex initial centre-tap matrix, row-major M[0]=M(1,1) M[1]=M(1,2)...
@@ -112,6 +116,8 @@ int plxo_cmapolardemux(const plxo_c *x, long L, const plxo_c *M, int taps,
                        plxo_c *h2);
 int plxo_easipolardemux(const plxo_c *x, long L, const plxo_c *M, double mu,
                         plxo_c *y, plxo_c *h1, plxo_c *h2);
+int plxo_easipolardemux_m(const plxo_c *x, long L, const plxo_c *M, double mu,
+                          plxo_c *y, plxo_c *h1, plxo_c *h2);
 
 typedef struct {
     int workatbaudrate;   /* DspPdmCohQpsk.m:12 */
@@ -130,6 +136,10 @@ typedef struct {
     int easi_txpolars;
     double easi_phizero;
     int modorder, freqavg, phasavg, poworder;
+    /* params.mat (DspPdmCohQpsk.m:148-149, :201-202): row-major 2x2 complex (re,im) */
+    int cma_has_mat, easi_has_mat;
+    double cma_mat[8], easi_mat[8];
+    int mfile_twins;      /* 1: the drivers run the .m twins of the filters (no MEX compiled) */
 } plxo_dsp_params;
 
 /* in: [Lin x ncol] (ncol 1 or 2); out: [Lout x ncol], Lout = ceil(Lin/2) unless

@@ -268,6 +268,32 @@ def easiadaptivefilter(xx, h1, h2, taps, mu, sps):
     return yr + 1j * yi, h1r + 1j * h1i, h2r + 1j * h2i
 
 
+def _twin_args(xx, h1, h2):
+    xx = np.asarray(xx, dtype=np.complex128)
+    x = np.ascontiguousarray(xx.T)                      # [2][Ndim]
+    g1 = np.array(np.asarray(h1, dtype=np.complex128).reshape(-1, 2).T, order="C", copy=True)   # [2][ntap], never aliasing the caller's
+    g2 = np.array(np.asarray(h2, dtype=np.complex128).reshape(-1, 2).T, order="C", copy=True)
+    ntap = g1.shape[1]
+    y = np.zeros((2, x.shape[1] - ntap + 1), dtype=np.complex128)
+    return x, g1, g2, ntap, y
+
+
+def cmaadaptivefilter_m(xx, h1, h2, taps, mu, R, sps=1):
+    """The .m twin (cmaadaptivefilter.m:1,52-72): [Y h1 h2]; `taps` and `sps` are ignored there (size(h1,1) rules,
+    every sample updates).  Returns (Y [L x 2], h1 [ntap x 2], h2 [ntap x 2])."""
+    x, g1, g2, ntap, y = _twin_args(xx, h1, h2)
+    R = _d(np.atleast_1d(R))
+    lib().plxo_cmafilter_m(_p(x), C.c_int(x.shape[1]), _p(g1), _p(g2), C.c_int(ntap), C.c_double(mu), _p(R), _p(y))
+    return y.T.copy(), g1.T.copy(), g2.T.copy()
+
+
+def easiadaptivefilter_m(xx, h1, h2, taps, mu, sps=1):
+    """The .m twin (easiadaptivefilter.m:1,51-84): complex error matrix, all taps recombined."""
+    x, g1, g2, ntap, y = _twin_args(xx, h1, h2)
+    lib().plxo_easifilter_m(_p(x), C.c_int(x.shape[1]), _p(g1), _p(g2), C.c_int(ntap), C.c_double(mu), _p(y))
+    return y.T.copy(), g1.T.copy(), g2.T.copy()
+
+
 def cmapolardemux(x, M, taps, mu, R):
     x = _c(x)
     L = x.shape[0]
@@ -292,6 +318,18 @@ def easipolardemux(x, M, mu):
     return y, h1, h2, n
 
 
+def easipolardemux_m(x, M, mu):
+    """easipolardemux (DspPdmCohQpsk.m:195-244) around the .m twin of the filter (no MEX compiled)."""
+    x = _c(x)
+    L = x.shape[0]
+    M = np.ascontiguousarray(np.asarray(M, dtype=np.complex128))
+    y = np.zeros((L, 2), dtype=np.complex128, order="F")
+    h1 = np.zeros((1, 2), dtype=np.complex128, order="F")
+    h2 = np.zeros((1, 2), dtype=np.complex128, order="F")
+    n = lib().plxo_easipolardemux_m(_p(x), C.c_long(L), _p(M), C.c_double(mu), _p(y), _p(h1), _p(h2))
+    return y, h1, h2, n
+
+
 # --------------------------------------------------------------------- DSP ---
 class DspParams(C.Structure):
     _fields_ = [("workatbaudrate", C.c_int), ("applynlr", C.c_int), ("nlralpha", C.c_double),
@@ -299,7 +337,9 @@ class DspParams(C.Structure):
                 ("cma_R", C.c_double * 2), ("cma_mu", C.c_double), ("cma_taps", C.c_int),
                 ("cma_txpolars", C.c_int), ("cma_phizero", C.c_double), ("easi_mu", C.c_double),
                 ("easi_txpolars", C.c_int), ("easi_phizero", C.c_double), ("modorder", C.c_int),
-                ("freqavg", C.c_int), ("phasavg", C.c_int), ("poworder", C.c_int)]
+                ("freqavg", C.c_int), ("phasavg", C.c_int), ("poworder", C.c_int),
+                ("cma_has_mat", C.c_int), ("easi_has_mat", C.c_int), ("cma_mat", C.c_double * 8),
+                ("easi_mat", C.c_double * 8), ("mfile_twins", C.c_int)]
 
 
 _POLMETHOD = {"singlepol": 0, "cma": 1, "easi": 2, "combo": 3}
@@ -308,8 +348,14 @@ _POLMETHOD = {"singlepol": 0, "cma": 1, "easi": 2, "combo": 3}
 def dsp_params(power_mw, workatbaudrate=False, applynlr=False, nlralpha=0.0, applypol=False,
                polmethod="cma", cma_R=(1.0, 1.0), cma_mu=1 / 6000, cma_taps=7, cma_txpolars=2,
                cma_phizero=0.0, easi_mu=1 / 6000, easi_txpolars=2, easi_phizero=0.0, modorder=2,
-               freqavg=500, phasavg=3, poworder=2):
+               freqavg=500, phasavg=3, poworder=2, cma_mat=None, easi_mat=None, mfile_twins=False):
     p = DspParams()
+    for m, has, dst in ((cma_mat, "cma_has_mat", p.cma_mat), (easi_mat, "easi_has_mat", p.easi_mat)):
+        if m is not None:
+            setattr(p, has, 1)
+            for k, v in enumerate(np.asarray(m, dtype=np.complex128).reshape(-1)):
+                dst[2 * k], dst[2 * k + 1] = v.real, v.imag
+    p.mfile_twins = int(bool(mfile_twins))
     p.workatbaudrate, p.applynlr, p.nlralpha, p.power_mw = int(workatbaudrate), int(applynlr), nlralpha, power_mw
     p.applypol, p.polmethod = int(applypol), _POLMETHOD[polmethod.lower()]
     p.cma_R[0], p.cma_R[1] = cma_R

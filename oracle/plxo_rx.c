@@ -159,6 +159,63 @@ int plxo_cma_gateway_check(double Ntap, double sps, int check_odd)
     return 0;
 }
 
+/* ============ the .m twins, used when no MEX is compiled ============
+ * cmaadaptivefilter.m:52-72: every sample updates (no sps gate), the updated taps are RETURNED.
+ * easiadaptivefilter.m:51-84: complex a, b, abs(), ALL taps of the complex h are recombined.
+ * Layout: xx [2][Ndim], h1/h2 [2][ntap] (column p of the MATLAB matrix at offset p*rows), y [2][L]. */
+static plxo_c colsum2(const plxo_c *xx, int Ndim, int k, const plxo_c *h, int ntap)
+{ /* sum(sum(xx(nindex,:).*h)): MATLAB sums each column over the taps first, then the two column sums */
+    plxo_c s[2];
+    for (int p = 0; p < 2; p++) {
+        s[p] = 0;
+        for (int t = 0; t < ntap; t++) s[p] = s[p] + cmul(xx[p * Ndim + k + t], h[p * ntap + t]);
+    }
+    return s[0] + s[1];
+}
+
+void plxo_cmafilter_m(const plxo_c *xx, int Ndim, plxo_c *h1, plxo_c *h2, int ntap, double mu,
+                      const double *R, plxo_c *y)
+{
+    int L = Ndim - ntap + 1; /* :54 */
+    for (int k = 0; k < L; k++) { /* :60-69 */
+        plxo_c Y1 = colsum2(xx, Ndim, k, h1, ntap), Y2 = colsum2(xx, Ndim, k, h2, ntap);
+        y[k] = Y1; y[L + k] = Y2;
+        double a1 = hypot(creal(Y1), cimag(Y1)), a2 = hypot(creal(Y2), cimag(Y2));
+        double m1 = R[0] - a1 * a1, m2 = R[1] - a2 * a2;            /* errorfuncma :74-75: X.*(M - abs(X).^2) */
+        plxo_c e1 = (mu * (creal(Y1) * m1)) + I * (mu * (cimag(Y1) * m1));
+        plxo_c e2 = (mu * (creal(Y2) * m2)) + I * (mu * (cimag(Y2) * m2));
+        for (int p = 0; p < 2; p++)
+            for (int t = 0; t < ntap; t++) {
+                plxo_c xc = conj(xx[p * Ndim + k + t]);
+                h1[p * ntap + t] = h1[p * ntap + t] + cmul(e1, xc);  /* :64-67 */
+                h2[p * ntap + t] = h2[p * ntap + t] + cmul(e2, xc);
+            }
+    }
+}
+
+void plxo_easifilter_m(const plxo_c *xx, int Ndim, plxo_c *h1, plxo_c *h2, int ntap, double mu, plxo_c *y)
+{
+    int L = Ndim - ntap + 1;
+    for (int k = 0; k < L; k++) { /* :51-69 */
+        plxo_c a = colsum2(xx, Ndim, k, h1, ntap), b = colsum2(xx, Ndim, k, h2, ntap);
+        y[k] = a; y[L + k] = b;
+        double aa = hypot(creal(a), cimag(a)), ab = hypot(creal(b), cimag(b));
+        double den1 = 1 + mu * (aa * aa + ab * ab);                  /* errorfun :78-84, lambda = mu */
+        plxo_c den2 = 1 + mu * (a * aa + b * ab);
+        plxo_c p = cmul(a, b);
+        double E11 = (aa * aa - 1) / den1, E22 = (ab * ab - 1) / den1;
+        plxo_c E12 = p / den1 + (p * (aa * aa - ab * ab)) / den2;
+        plxo_c E21 = p / den1 + (p * (ab * ab - aa * aa)) / den2;
+        for (int t = 0; t < ntap; t++) {                            /* :58-66, all taps, both columns */
+            for (int c = 0; c < 2; c++) {
+                plxo_c g1 = h1[c * ntap + t], g2 = h2[c * ntap + t];
+                h1[c * ntap + t] = (1 - mu * E11) * g1 + cmul(-mu * E12, g2);
+                h2[c * ntap + t] = cmul(-mu * E21, g1) + (1 - mu * E22) * g2;
+            }
+        }
+    }
+}
+
 /* ================================= DspPdmCohQpsk.m:142-244 pol-demux drivers === */
 static int poldemux_driver(const plxo_c *x, long L, const plxo_c *M, int taps,
                            double mu, const double *R, int is_easi, plxo_c *y,
@@ -192,7 +249,17 @@ static int poldemux_driver(const plxo_c *x, long L, const plxo_c *M, int taps,
         memcpy(o1r, h1r, sizeof(double) * nh); memcpy(o1i, h1i, sizeof(double) * nh);
         memcpy(o2r, h2r, sizeof(double) * nh); memcpy(o2i, h2i, sizeof(double) * nh);
         /* MEX mutates h1,h2 in place and returns zeros, which the driver keeps (:183-186) */
-        if (is_easi) plxo_easifilter(xr, xi, Ndim, h1r, h1i, h2r, h2i, taps, mu, yr, yi, 1);
+        if (is_easi == 2) { /* no MEX: the .m twin returns the updated (complex) taps, which the driver takes (:232-235) */
+            plxo_c *xx = (plxo_c *)malloc(sizeof(plxo_c) * 2 * Ndim), *yy = (plxo_c *)malloc(sizeof(plxo_c) * 2 * L);
+            plxo_c g1[2], g2[2];
+            for (int i = 0; i < 2 * Ndim; i++) xx[i] = xr[i] + I * xi[i];
+            for (int j = 0; j < 2; j++) { g1[j] = h1r[j] + I * h1i[j]; g2[j] = h2r[j] + I * h2i[j]; }
+            plxo_easifilter_m(xx, Ndim, g1, g2, 1, mu, yy);
+            for (int j = 0; j < 2; j++) { h1r[j] = creal(g1[j]); h1i[j] = cimag(g1[j]); h2r[j] = creal(g2[j]); h2i[j] = cimag(g2[j]); }
+            for (long i = 0; i < 2 * L; i++) { yr[i] = creal(yy[i]); yi[i] = cimag(yy[i]); }
+            free(xx); free(yy);
+        }
+        else if (is_easi) plxo_easifilter(xr, xi, Ndim, h1r, h1i, h2r, h2i, taps, mu, yr, yi, 1);
         else plxo_cmafilter(xr, xi, Ndim, h1r, h1i, h2r, h2i, taps, mu, R, yr, yi, 1);
         double mx = 0; /* :187 max(max(abs([h1_old-h1 h2_old-h2]))) */
         for (size_t t = 0; t < nh; t++) {
@@ -222,6 +289,12 @@ int plxo_easipolardemux(const plxo_c *x, long L, const plxo_c *M, double mu,
                         plxo_c *y, plxo_c *h1, plxo_c *h2)
 {
     return poldemux_driver(x, L, M, 1, mu, NULL, 1, y, h1, h2);
+}
+
+int plxo_easipolardemux_m(const plxo_c *x, long L, const plxo_c *M, double mu,
+                          plxo_c *y, plxo_c *h1, plxo_c *h2)
+{ /* easipolardemux around the .m twin of the filter */
+    return poldemux_driver(x, L, M, 1, mu, NULL, 2, y, h1, h2);
 }
 
 /* ============================================ helpers: fastshift, nmod, unwrap === */
@@ -332,9 +405,11 @@ static plxo_c mean_ratio(const plxo_c *x, long L)
 }
 
 /* initial centre-tap matrix of cmapolardemux/easipolardemux, :148-159 / :201-212 */
-static void init_matrix(const plxo_c *x, long L, int txpolars, double phizero, plxo_c *M)
+static void init_matrix(const plxo_c *x, long L, int txpolars, double phizero, plxo_c *M, int has_mat, const double *mat)
 {
-    if (txpolars != 2) {
+    if (has_mat) { /* M = params.mat  :148-149 */
+        for (int k = 0; k < 4; k++) M[k] = mat[2 * k] + I * mat[2 * k + 1];
+    } else if (txpolars != 2) {
         plxo_c Mr[4];
         rotpolar_matrix(mean_ratio(x, L), Mr); /* M = rotpolar(1,r).' */
         M[0] = Mr[0]; M[1] = Mr[2]; M[2] = Mr[1]; M[3] = Mr[3];
@@ -385,13 +460,14 @@ long plxo_dsp_pdm_coh_qpsk(const plxo_c *in, long Lin, int ncol,
             memcpy(s, t, sizeof(plxo_c) * 2 * L);
         }
         if (p->polmethod == 2 || p->polmethod == 3) {
-            init_matrix(s, L, p->easi_txpolars, p->easi_phizero, M);
-            plxo_easipolardemux(s, L, M, p->easi_mu, t, h1, h2);
+            init_matrix(s, L, p->easi_txpolars, p->easi_phizero, M, p->easi_has_mat, p->easi_mat);
+            if (p->mfile_twins) plxo_easipolardemux_m(s, L, M, p->easi_mu, t, h1, h2);
+            else plxo_easipolardemux(s, L, M, p->easi_mu, t, h1, h2);
             memcpy(s, t, sizeof(plxo_c) * 2 * L);
         }
         if (p->polmethod == 1 || p->polmethod == 3) {
             if (p->cma_taps > 31) { free(s); free(t); return -1; }
-            init_matrix(s, L, p->cma_txpolars, p->cma_phizero, M);
+            init_matrix(s, L, p->cma_txpolars, p->cma_phizero, M, p->cma_has_mat, p->cma_mat);
             plxo_cmapolardemux(s, L, M, p->cma_taps, p->cma_mu, p->cma_R, t, h1, h2);
             memcpy(s, t, sizeof(plxo_c) * 2 * L);
         }

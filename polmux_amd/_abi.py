@@ -37,7 +37,9 @@ class DspParams(C.Structure):
                 ("cma_R", C.c_double * 2), ("cma_mu", C.c_double), ("cma_taps", C.c_int32),
                 ("cma_txpolars", C.c_int32), ("cma_phizero", C.c_double), ("easi_mu", C.c_double),
                 ("easi_txpolars", C.c_int32), ("easi_phizero", C.c_double), ("modorder", C.c_int32),
-                ("freqavg", C.c_int32), ("phasavg", C.c_int32), ("poworder", C.c_int32)]
+                ("freqavg", C.c_int32), ("phasavg", C.c_int32), ("poworder", C.c_int32),
+                ("cma_has_mat", C.c_int32), ("easi_has_mat", C.c_int32), ("cma_mat", C.c_double * 8),
+                ("easi_mat", C.c_double * 8), ("mfile_twins", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class FrontDesc(C.Structure):
@@ -78,6 +80,8 @@ SIGNATURES = {
     "plx_cde_ofde": [_vp, _vp, _vp, _vp, _i64, _dbl, _dbl, _dbl, _dbl, _dbl, _i64, _i64, _vp, _vp, _vp, _vp],
     "plx_cmaadaptivefilter": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _dbl, _dbl, _vp, _dbl, _vp, _vp],
     "plx_easiadaptivefilter": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _vp, _vp],
+    "plx_cmaadaptivefilter_m": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _dbl, _vp, _vp, _vp],
+    "plx_easiadaptivefilter_m": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _dbl, _vp, _vp],
     "plx_poldemux_dev": [C.c_int, _vp, _vp, _i64, C.c_int, _i32, _dbl, _vp, _vp, _vp, _vp, _vp],
     "plx_dsp_create": [C.POINTER(_vp), _i64, _i32, _i32, C.POINTER(DspParams)],
     "plx_dsp_destroy": [_vp],

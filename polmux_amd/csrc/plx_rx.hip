@@ -356,6 +356,75 @@ __global__ __launch_bounds__(64) void k_easi(DemuxArgs a)
     if (a.passes) a.passes[f] = npass;
 }
 
+// The .m twin of easifilter (easiadaptivefilter.m:51-84), what the drivers run when no MEX is compiled: the error
+// matrix is formed from the COMPLEX outputs a, b (abs(), complex denominators) and ALL taps of the complex h1, h2 are
+// recombined (:58-66) -- not the real-parts-of-tap-0 update of the C file.  One lane per frame, taps in global memory
+// (hh [2][2*taps]: h1(:,1) h1(:,2) | h2(:,1) h2(:,2)); the driver's taps == 1 keeps them in registers in effect.
+__device__ __forceinline__ cplx cdiv(cplx a, cplx b)
+{
+    const double d = b.x * b.x + b.y * b.y;
+    return make_double2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+__global__ __launch_bounds__(64) void k_easi_m(DemuxArgs a)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= a.nframes) return;
+    const int64_t L = a.L;
+    const int taps = a.taps;
+    const cplx *x1 = a.x + (size_t)f * 2 * L, *x2 = x1 + L;
+    cplx *y1 = a.y + (size_t)f * 2 * L, *y2 = y1 + L;
+    cplx *hh = a.h + (size_t)f * 4 * taps;
+    if (!a.single_pass) {
+        const cplx *M = a.M + (size_t)f * a.m_stride;
+        hh[0] = M[0]; hh[1] = M[1]; hh[2] = M[2]; hh[3] = M[3];
+    }
+    const int64_t nout = a.single_pass ? L - taps + 1 : L;
+    const double mu = a.mu;
+    int c = 1, npass = 0;
+    bool conv = false;
+    while (!conv && c < a.max_passes) {
+        cplx o[4];
+        if (taps == 1) { o[0] = hh[0]; o[1] = hh[1]; o[2] = hh[2]; o[3] = hh[3]; }
+        for (int64_t i = 0; i < nout; i++) {
+            cplx A = make_double2(0, 0), B = A;      // sum(sum(xx(nindex,:).*h)): column sums, then their sum (:53-54)
+            for (int p = 0; p < 2; p++) {
+                const cplx *xp = p ? x2 : x1;
+                cplx s1 = make_double2(0, 0), s2 = s1;
+                for (int t = 0; t < taps; t++) {
+                    const cplx xv = xp[i + t];
+                    s1 = cadd(s1, cmul(xv, hh[p * taps + t]));
+                    s2 = cadd(s2, cmul(xv, hh[2 * taps + p * taps + t]));
+                }
+                A = cadd(A, s1); B = cadd(B, s2);
+            }
+            y1[i] = A; y2[i] = B;
+            const double aa = hypot(A.x, A.y), ab = hypot(B.x, B.y);
+            const double den1 = 1 + mu * (aa * aa + ab * ab);                                    // errorfun :78-84
+            const cplx den2 = make_double2(1 + mu * (A.x * aa + B.x * ab), mu * (A.y * aa + B.y * ab));
+            const cplx pr = cmul(A, B);
+            const double E11 = (aa * aa - 1) / den1, E22 = (ab * ab - 1) / den1;
+            const cplx q = make_double2(pr.x / den1, pr.y / den1);
+            const cplx E12 = cadd(q, cdiv(cscale(pr, aa * aa - ab * ab), den2));
+            const cplx E21 = cadd(q, cdiv(cscale(pr, ab * ab - aa * aa), den2));
+            const cplx m12 = cscale(E12, -mu), m21 = cscale(E21, -mu);
+            const double d1 = 1 - mu * E11, d2 = 1 - mu * E22;
+            for (int t = 0; t < taps; t++)
+                for (int col = 0; col < 2; col++) {                                              // :58-66
+                    const cplx g1 = hh[col * taps + t], g2 = hh[2 * taps + col * taps + t];
+                    hh[col * taps + t] = cadd(cscale(g1, d1), cmul(m12, g2));
+                    hh[2 * taps + col * taps + t] = cadd(cmul(m21, g1), cscale(g2, d2));
+                }
+        }
+        npass++;
+        if (a.single_pass) break;
+        double d = 0;                                                                            // :236 (taps == 1 in the driver)
+        for (int k = 0; k < 4; k++) { const double e = hypot(o[k].x - hh[k].x, o[k].y - hh[k].y); d = e > d ? e : d; }
+        if (d < 5e-5) conv = true;
+        c++;
+    }
+    if (a.passes) a.passes[f] = npass;
+}
+
 // ================================================== DspPdmCohQpsk front part ======
 struct PreArgs {
     const cplx *in; // [frame][ncol][Lin]
@@ -800,6 +869,9 @@ static int launch_demux(int method, DemuxArgs &a, void *stream)
         const int frames_per_block = 256 / G;
         const unsigned gx = (unsigned)((a.nframes + frames_per_block - 1) / frames_per_block);
         PLX_LAUNCH(k_cma, dim3(gx), dim3(256), 0, stream, a);
+    } else if (method == PLX_DEMUX_EASI_M) {
+        const unsigned gx = (unsigned)((a.nframes + 63) / 64);
+        PLX_LAUNCH(k_easi_m, dim3(gx), dim3(64), 0, stream, a);
     } else {
         const unsigned gx = (unsigned)((a.nframes + 63) / 64);
         PLX_LAUNCH(k_easi, dim3(gx), dim3(64), 0, stream, a);
@@ -813,7 +885,8 @@ extern "C" int plx_poldemux_dev(int method, const double *d_x, double *d_y, int6
                                 void *stream)
 {
     if (!d_x || !d_y || !d_M) PLX_FAIL(PLX_ERR_ARG, "plx_poldemux_dev: null argument");
-    if (method != PLX_DEMUX_CMA && method != PLX_DEMUX_EASI) PLX_FAIL(PLX_ERR_ARG, "plx_poldemux_dev: unknown method");
+    if (method != PLX_DEMUX_CMA && method != PLX_DEMUX_EASI && method != PLX_DEMUX_EASI_M)
+        PLX_FAIL(PLX_ERR_ARG, "plx_poldemux_dev: unknown method");
     if (L < 1 || nframes < 1 || taps < 1 || !(mu > 0)) PLX_FAIL(PLX_ERR_ARG, "plx_poldemux_dev: bad size");
     DemuxArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -842,12 +915,14 @@ extern "C" int plx_poldemux_dev(int method, const double *d_x, double *d_y, int6
 // gateway forms: one call of the MEX function on host arrays -----------------------
 static int gateway_filter(int method, const double *xr, const double *xi, int32_t Mdim, double *h1r, double *h1i,
                           double *h2r, double *h2i, double Ntap, double mu, const double *R, double sps, double *yr,
-                          double *yi)
+                          double *yi, bool twin = false)
 {
     if (!xr || !h1r || !h2r || !yr || !yi) PLX_FAIL(PLX_ERR_ARG, "adaptive filter gateway: null argument");
     const int taps = (int)Ntap;
-    if (method == PLX_DEMUX_CMA && taps % 2 == 0) PLX_FAIL(PLX_ERR_ARG, "Ntaps should be an ODD INTEGER.");
-    if ((int)sps != 1 && (int)sps != 2) PLX_FAIL(PLX_ERR_ARG, "Samples x symbol should be either 1 or 2.");
+    // the .m twins have neither check (cmaadaptivefilter.m:52-54 sizes everything from h1; sps is unused)
+    if (!twin && method == PLX_DEMUX_CMA && taps % 2 == 0) PLX_FAIL(PLX_ERR_ARG, "Ntaps should be an ODD INTEGER.");
+    if (!twin && (int)sps != 1 && (int)sps != 2) PLX_FAIL(PLX_ERR_ARG, "Samples x symbol should be either 1 or 2.");
+    if (twin && (!h1i || !h2i)) PLX_FAIL(PLX_ERR_ARG, "adaptive filter gateway: the .m twins return complex taps (h1i, h2i required)");
     if (taps < 1 || Mdim < taps) PLX_FAIL(PLX_ERR_ARG, "adaptive filter gateway: input shorter than the filter");
     if (method == PLX_DEMUX_CMA && taps > 64) PLX_FAIL(PLX_ERR_UNSUPPORTED, "pol-demux: at most 64 taps are supported");
     const int dimY = Mdim - taps + 1;
@@ -875,7 +950,7 @@ static int gateway_filter(int method, const double *xr, const double *xi, int32_
     std::memset(&a, 0, sizeof(a));
     a.x = (const cplx *)dx; a.y = (cplx *)dy; a.h = (cplx *)dh; a.L = Mdim; a.nframes = 1; a.taps = taps;
     a.halftaps = 0; a.mu = mu; a.single_pass = 1; a.max_passes = 2;
-    a.dontskip = ((int)sps == 1) ? 1 : 0;
+    a.dontskip = (twin || (int)sps == 1) ? 1 : 0;   // the .m twin updates at every sample (cmaadaptivefilter.m:60-69)
     a.skipk = ((taps - 1) / 2) % 2; // cmaadaptivefilter.c:64
     if (R) { a.R1 = R[0]; a.R2 = R[1]; }
     int rc = launch_demux(method, a, nullptr);
@@ -911,6 +986,20 @@ extern "C" int plx_easiadaptivefilter(const double *xr, const double *xi, int32_
                                       double *yi)
 {
     return gateway_filter(PLX_DEMUX_EASI, xr, xi, Mdim, h1r, h1i, h2r, h2i, Ntap, mu, nullptr, sps, yr, yi);
+}
+
+extern "C" int plx_cmaadaptivefilter_m(const double *xr, const double *xi, int32_t Mdim, double *h1r, double *h1i,
+                                       double *h2r, double *h2i, int32_t ntap, double mu, const double *R, double *yr,
+                                       double *yi)
+{
+    if (!R) PLX_FAIL(PLX_ERR_ARG, "plx_cmaadaptivefilter_m: R is required");
+    return gateway_filter(PLX_DEMUX_CMA, xr, xi, Mdim, h1r, h1i, h2r, h2i, (double)ntap, mu, R, 1.0, yr, yi, true);
+}
+
+extern "C" int plx_easiadaptivefilter_m(const double *xr, const double *xi, int32_t Mdim, double *h1r, double *h1i,
+                                        double *h2r, double *h2i, int32_t ntap, double mu, double *yr, double *yi)
+{
+    return gateway_filter(PLX_DEMUX_EASI_M, xr, xi, Mdim, h1r, h1i, h2r, h2i, (double)ntap, mu, nullptr, 1.0, yr, yi, true);
 }
 
 // ===================================================================== DSP host ===
@@ -962,10 +1051,16 @@ extern "C" int plx_dsp_create(plx_dsp **out, int64_t Lin, int32_t ncol, int32_t 
         std::vector<cplx> M((size_t)2 * max_frames * 4);
         for (int m = 0; m < 2; m++) {
             const double phi = m == 0 ? p->cma_phizero : p->easi_phizero;
+            const bool has = m == 0 ? p->cma_has_mat != 0 : p->easi_has_mat != 0;
+            const double *mat = m == 0 ? p->cma_mat : p->easi_mat;
             for (int f = 0; f < max_frames; f++) {
                 cplx *q = &M[((size_t)m * max_frames + f) * 4];
-                q[0] = make_double2(cos(phi), 0); q[1] = make_double2(sin(phi), 0);
-                q[2] = make_double2(-sin(phi), 0); q[3] = make_double2(cos(phi), 0);
+                if (has) { // M = params.mat  (DspPdmCohQpsk.m:148-149, :201-202)
+                    for (int k = 0; k < 4; k++) q[k] = make_double2(mat[2 * k], mat[2 * k + 1]);
+                } else {
+                    q[0] = make_double2(cos(phi), 0); q[1] = make_double2(sin(phi), 0);
+                    q[2] = make_double2(-sin(phi), 0); q[3] = make_double2(cos(phi), 0);
+                }
             }
         }
         ok = hipMalloc((void **)&P->d_Mrot, M.size() * sizeof(cplx)) == hipSuccess &&
@@ -983,16 +1078,16 @@ static int demux_stage(plx_dsp *P, int method, cplx *src, cplx *dst, int nframes
 {
     const plx_dsp_params &p = P->p;
     const int txpol = method == PLX_DEMUX_CMA ? p.cma_txpolars : p.easi_txpolars;
-    const double phi = method == PLX_DEMUX_CMA ? p.cma_phizero : p.easi_phizero;
+    const bool has_mat = method == PLX_DEMUX_CMA ? p.cma_has_mat != 0 : p.easi_has_mat != 0;
     const cplx *Min = P->d_M;
-    if (txpol == 2) { // M = [cos sin; -sin cos]  :155-156 (constant, uploaded once at plan creation)
-        (void)phi;
+    if (txpol == 2 || has_mat) { // M = params.mat, or [cos sin; -sin cos]  :148-156 (constant, uploaded once at plan creation)
         Min = P->d_Mrot + (size_t)(method == PLX_DEMUX_CMA ? 0 : 1) * P->max_frames * 4;
     } else {
         PLX_LAUNCH(k_rotpolar, dim3((unsigned)nframes), dim3(256), 16 * sizeof(double), stream, (const cplx *)src,
                    (cplx *)nullptr, P->d_M, P->L, 0);
     }
-    return plx_poldemux_dev(method, (const double *)src, (double *)dst, P->L, nframes,
+    const int kmethod = (method == PLX_DEMUX_EASI && p.mfile_twins) ? PLX_DEMUX_EASI_M : method;   // no MEX compiled: the .m twin
+    return plx_poldemux_dev(kmethod, (const double *)src, (double *)dst, P->L, nframes,
                             method == PLX_DEMUX_CMA ? p.cma_taps : 1, method == PLX_DEMUX_CMA ? p.cma_mu : p.easi_mu,
                             p.cma_R, (const double *)Min, (double *)P->d_h, nullptr, stream);
 }

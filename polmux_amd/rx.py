@@ -146,6 +146,41 @@ def easiadaptivefilter(xx, h1, h2, taps, mu, sps):
     return _filter_gateway("easi", xx, h1, h2, taps, mu, None, sps)
 
 
+def _twin_gateway(name, xx, h1, h2, mu, R):
+    """The .m twins (no MEX compiled): [Y h1 h2] with the UPDATED taps returned (cmaadaptivefilter.m:1,
+    easiadaptivefilter.m:1); taps/sps arguments are unused there."""
+    lib = _abi.get()
+    xx = np.asarray(xx)
+    Mdim = xx.shape[0]
+    xr, xi = _split(xx)
+    g1 = np.asarray(h1, dtype=np.complex128).reshape(-1, 2)
+    g2 = np.asarray(h2, dtype=np.complex128).reshape(-1, 2)
+    ntap = g1.shape[0]
+    h1r, h1i = (np.asfortranarray(g1.real.copy()), np.asfortranarray(g1.imag.copy()))
+    h2r, h2i = (np.asfortranarray(g2.real.copy()), np.asfortranarray(g2.imag.copy()))
+    dimY = max(Mdim - ntap + 1, 0)
+    yr, yi = np.zeros((dimY, 2), order="F"), np.zeros((dimY, 2), order="F")
+    if name == "cma":
+        Rv = np.ascontiguousarray(np.atleast_1d(R), dtype=float)
+        lib.call("plx_cmaadaptivefilter_m", xr.ctypes.data, xi.ctypes.data, Mdim, h1r.ctypes.data, h1i.ctypes.data,
+                 h2r.ctypes.data, h2i.ctypes.data, ntap, float(mu), Rv.ctypes.data, yr.ctypes.data, yi.ctypes.data)
+    else:
+        lib.call("plx_easiadaptivefilter_m", xr.ctypes.data, xi.ctypes.data, Mdim, h1r.ctypes.data, h1i.ctypes.data,
+                 h2r.ctypes.data, h2i.ctypes.data, ntap, float(mu), yr.ctypes.data, yi.ctypes.data)
+    return yr + 1j * yi, h1r + 1j * h1i, h2r + 1j * h2i
+
+
+def cmaadaptivefilter_m(xx, h1, h2, taps, mu, R, sps=1):
+    """[Y h1 h2] = cmaadaptivefilter(...) as the .m twin computes it (cmaadaptivefilter.m:52-72): every sample updates,
+    the updated taps are returned."""
+    return _twin_gateway("cma", xx, h1, h2, mu, R)
+
+
+def easiadaptivefilter_m(xx, h1, h2, taps, mu, sps=1):
+    """[Y h1 h2] = easiadaptivefilter(...) as the .m twin computes it (easiadaptivefilter.m:51-84)."""
+    return _twin_gateway("easi", xx, h1, h2, mu, None)
+
+
 # ------------------------------------------------------------- DspPdmCohQpsk ---
 _POLMETHOD = {"singlepol": 0, "cma": 1, "easi": 2, "combo": 3}
 
@@ -178,9 +213,17 @@ def dsp_params_struct(dspParams, power_mw):
     p.easi_mu = float(_g(easi, "mu", 1 / 6000))
     p.easi_txpolars = int(_g(easi, "txpolars", 2))
     p.easi_phizero = float(_g(easi, "phizero", 0.0))
-    if _g(cma, "mat") is not None or _g(easi, "mat") is not None:
-        raise NotImplementedError("params.mat (explicit initial matrix, DspPdmCohQpsk.m:148-149) goes through "
-                                  "plx_poldemux_dev, not the fused DspPdmCohQpsk plan")
+    for prm, has, dst in ((cma, "cma_has_mat", p.cma_mat), (easi, "easi_has_mat", p.easi_mat)):
+        m = _g(prm, "mat")                                                   # explicit initial matrix, DspPdmCohQpsk.m:148-149
+        if m is not None:
+            m = np.asarray(m, dtype=np.complex128)
+            if m.shape != (2, 2):
+                raise ValueError("params.mat must be a 2x2 matrix")
+            setattr(p, has, 1)
+            for k, v in enumerate(m.reshape(-1)):
+                dst[2 * k], dst[2 * k + 1] = v.real, v.imag
+    # no MEX compiled (comp_mex.m not run): MATLAB resolves the filter names to the .m twins, whose EASI differs
+    p.mfile_twins = int(bool(_g(dspParams, "mfiletwins", False)))
     p.modorder = int(_g(dspParams, "modorder", 2))
     p.freqavg = int(_g(dspParams, "freqavg", 0))
     p.phasavg = int(_g(dspParams, "phasavg", 0))

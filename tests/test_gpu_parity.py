@@ -445,6 +445,82 @@ def test_dsp_chain_vs_oracle_symbols_bit_exact(lib, oracle, kw):
     assert mask.mean() > 0.99
 
 
+@pytest.mark.parametrize("taps,sps", [(1, 1), (4, 1), (7, 2), (15, 1)])
+def test_cma_mfile_twin_gateway(lib, oracle, taps, sps):
+    """the .m twin of the CMA filter (cmaadaptivefilter.m:52-72: every sample updates whatever sps is,
+    no odd-taps check, the updated taps are RETURNED and the inputs left alone) through plx_cmaadaptivefilter_m."""
+    from polmux_amd.rx import cmaadaptivefilter_m
+    xx, _ = _mixed_qpsk(300 + taps - 1, 21 + taps)
+    h1 = np.zeros((taps, 2), complex); h1[taps // 2, 0] = 1
+    h2 = np.zeros((taps, 2), complex); h2[taps // 2, 1] = 1
+    k1, k2 = h1.copy(), h2.copy()
+    y, g1, g2 = cmaadaptivefilter_m(xx, h1, h2, taps, 1e-3, [1.0, 1.0], sps)
+    ry, r1, r2 = oracle.cmaadaptivefilter_m(xx, h1, h2, taps, 1e-3, [1.0, 1.0], sps)
+    np.testing.assert_array_equal(h1, k1); np.testing.assert_array_equal(h2, k2)
+    np.testing.assert_allclose(y, ry, atol=1e-11)
+    np.testing.assert_allclose(g1, r1, atol=1e-11)
+    np.testing.assert_allclose(g2, r2, atol=1e-11)
+    assert np.abs(g1 - h1).max() > 1e-4
+
+
+@pytest.mark.parametrize("taps", [1, 3])
+def test_easi_mfile_twin_gateway(lib, oracle, taps):
+    """The .m twin of the EASI filter (easiadaptivefilter.m:51-84): complex error matrix, all taps of the complex h1, h2
+    recombined -- NOT the real-parts-of-tap-0 update of easiadaptivefilter.c (tested by test_easiadaptivefilter_gateway)."""
+    from polmux_amd.rx import easiadaptivefilter_m
+    xx, _ = _mixed_qpsk(200 + taps - 1, 31 + taps)
+    r = np.random.default_rng(3)
+    h1 = 0.1 * (r.standard_normal((taps, 2)) + 1j * r.standard_normal((taps, 2))); h1[0, 0] += 1
+    h2 = 0.1 * (r.standard_normal((taps, 2)) + 1j * r.standard_normal((taps, 2))); h2[0, 1] += 1
+    y, g1, g2 = easiadaptivefilter_m(xx, h1, h2, taps, 2e-3, 1)
+    ry, r1, r2 = oracle.easiadaptivefilter_m(xx, h1, h2, taps, 2e-3, 1)
+    np.testing.assert_allclose(y, ry, atol=1e-11)
+    np.testing.assert_allclose(g1, r1, atol=1e-11)
+    np.testing.assert_allclose(g2, r2, atol=1e-11)
+    assert np.abs(g1.imag - h1.imag).max() > 1e-5          # imaginary parts and every tap move: the C filter keeps them
+    cy, c1, c2 = oracle.easiadaptivefilter(xx, h1.copy(order="F"), h2.copy(order="F"), taps, 2e-3, 1)
+    assert np.abs(c1 - g1).max() > 1e-4                      # the twins are not equivalent (SURVEY 8a a17)
+
+
+@pytest.mark.parametrize("kw", [dict(polmethod="cma", cmaparams=dict(R=[1, 1], mu=1 / 600, taps=7, txpolars=2, phizero=0, mat="rot")),
+                                dict(polmethod="easi", easiparams=dict(mu=1 / 600, txpolars=1, phizero=0, mat="rot")),
+                                dict(polmethod="easi", mfiletwins=True), dict(polmethod="combo", mfiletwins=True, freqavg=0)])
+def test_dsp_plan_params_mat_and_mfile_twins(lib, oracle, kw):
+    """params.mat (explicit initial demux matrix, DspPdmCohQpsk.m:148-149, :201-202) through the fused DSP plan, and the
+    plan running easipolardemux around the .m twin of the filter (mfiletwins: no MEX compiled): symbols vs the oracle."""
+    from polmux_amd import DspPdmCohQpsk
+    from polmux_amd.gstate import GSTATE
+    L = 256
+    GSTATE.POWER = np.array([2.0])
+    rot = np.array([[np.cos(0.35), np.sin(0.35) * 1j], [1j * np.sin(0.35), np.cos(0.35)]])
+    p = dict(workatbaudrate=False, applynlr=False, nlralpha=0.0, applypol=True, polmethod="cma",
+             cmaparams=dict(R=[1, 1], mu=1 / 600, taps=7, txpolars=2, phizero=0),
+             easiparams=dict(mu=1 / 600, txpolars=2, phizero=0), modorder=2, freqavg=20, phasavg=3, poworder=2)
+    okw = dict(cma_mu=1 / 600, cma_taps=7, easi_mu=1 / 600)
+    for k, v in kw.items():
+        if isinstance(v, dict):
+            v = dict(v)
+            if v.get("mat") == "rot":
+                v["mat"] = rot
+                okw["cma_mat" if k == "cmaparams" else "easi_mat"] = rot
+            if k == "easiparams":
+                okw["easi_txpolars"] = v["txpolars"]
+        p[k] = v
+    _, s = _mixed_qpsk(L, 78, noise=0.03)
+    x = np.zeros((2 * L, 2), complex)
+    x[::2] = s * 4 * np.sqrt(2.0)
+    out = DspPdmCohQpsk(x, p, 1)
+    op = oracle.dsp_params(power_mw=2.0, applypol=True, polmethod=p["polmethod"], modorder=2, freqavg=p["freqavg"], phasavg=3,
+                           poworder=2, mfile_twins=bool(p.get("mfiletwins")), **okw)
+    ref = oracle.dsp_pdm_coh_qpsk(x, op)
+    np.testing.assert_allclose(out, ref, atol=1e-8)
+    # and the option matters: without it the symbols are different ones
+    base = oracle.dsp_pdm_coh_qpsk(x, oracle.dsp_params(power_mw=2.0, applypol=True, polmethod=p["polmethod"], modorder=2,
+                                                        freqavg=p["freqavg"], phasavg=3, poworder=2, cma_mu=1 / 600, cma_taps=7,
+                                                        easi_mu=1 / 600))
+    assert np.abs(base - ref).max() > 1e-6
+
+
 def test_decide_count_device(lib, oracle):
     import torch
     r = np.random.default_rng(4)

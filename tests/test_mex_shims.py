@@ -217,3 +217,36 @@ def test_easi_shim_six_inputs_in_place_real_parts():
     assert _np(out[1]).tolist() == [[0.0]] and _np(out[2]).tolist() == [[0.0]]
     rc, _, err = _call(lib, 3, _mx(lib, xx), mh1, mh2, _mx(lib, [[1]]), _mx(lib, [[1e-2]]))
     assert rc == 1 and err == "Six inputs required."
+
+
+@pytest.mark.gpu
+def test_mfile_twin_shims_return_the_updated_taps():
+    """The shims with the semantics of the .m twins (cmaadaptivefilter.m:52-72, easiadaptivefilter.m:51-84): the taps come
+    back in plhs[1..2] (non-zero, so the unchanged drivers take them, DspPdmCohQpsk.m:183-186), the inputs are untouched,
+    sps = 2 still updates every sample, an even number of taps is accepted."""
+    from oracle import plxo as oracle
+    r = np.random.default_rng(6)
+    taps, L = 4, 120
+    a = np.exp(1j * (np.pi / 4 + np.pi / 2 * r.integers(0, 4, (L + taps - 1, 2))))
+    xx = a @ np.array([[np.cos(0.3), np.sin(0.3)], [-np.sin(0.3), np.cos(0.3)]])
+    h1 = np.zeros((taps, 2), complex); h1[1, 0] = 1
+    h2 = np.zeros((taps, 2), complex); h2[1, 1] = 1
+    lib = _load("plx_cmaadaptivefilter_m_mex")
+    mh1, mh2 = _mx(lib, h1), _mx(lib, h2)
+    rc, out, err = _call(lib, 3, _mx(lib, xx), mh1, mh2, _mx(lib, [[taps]]), _mx(lib, [[5e-3]]), _mx(lib, [[1.0, 1.0]]), _mx(lib, [[2]]))
+    assert rc == 0, err
+    y, g1, g2 = oracle.cmaadaptivefilter_m(xx, h1, h2, taps, 5e-3, [1.0, 1.0])
+    np.testing.assert_allclose(_np(out[0]), y, atol=1e-11)
+    np.testing.assert_allclose(_np(out[1]), g1, atol=1e-11)
+    np.testing.assert_allclose(_np(out[2]), g2, atol=1e-11)
+    np.testing.assert_array_equal(_np(mh1), h1)                   # inputs untouched
+    lib = _load("plx_easiadaptivefilter_m_mex")
+    k1 = np.array([[0.9 + 0.1j, 0.2 - 0.3j]]); k2 = np.array([[-0.2 + 0.05j, 1.1 + 0.2j]])
+    x1 = xx[:L]
+    rc, out, err = _call(lib, 3, _mx(lib, x1), _mx(lib, k1), _mx(lib, k2), _mx(lib, [[1]]), _mx(lib, [[1e-2]]), _mx(lib, [[1]]))
+    assert rc == 0, err
+    y, g1, g2 = oracle.easiadaptivefilter_m(x1, k1, k2, 1, 1e-2)
+    np.testing.assert_allclose(_np(out[0]), y, atol=1e-11)
+    np.testing.assert_allclose(_np(out[1]), g1, atol=1e-11)
+    np.testing.assert_allclose(_np(out[2]), g2, atol=1e-11)
+    assert np.abs(_np(out[1]).imag - k1.imag).max() > 1e-5

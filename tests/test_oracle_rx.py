@@ -317,3 +317,79 @@ def test_mc_estimate_vector_mode_and_limits(oracle):
         lo, hi = out["varlim"][:, nind - 1]
         assert lo < out["var"][nind - 1] < hi
     assert cond.all()
+
+
+# ============================================================ the .m twins ===
+def test_cma_mfile_twin_is_the_c_filter_at_one_sample_per_symbol_and_differs_at_two(oracle):
+    """cmaadaptivefilter.m:52-72 updates at EVERY sample: with sps = 1 it is the C filter (same recurrence, MATLAB's
+    column-then-row summation order: 1e-13), with sps = 2 the C filter skips every other update (cmaadaptivefilter.c:64,85)
+    and the twins part ways.  The twin returns the updated taps and leaves its inputs alone."""
+    r = np.random.default_rng(11)
+    L, taps = 300, 5
+    a = np.exp(1j * (np.pi / 4 + np.pi / 2 * r.integers(0, 4, (L + taps - 1, 2))))
+    xx = a @ np.array([[np.cos(0.4), np.sin(0.4)], [-np.sin(0.4), np.cos(0.4)]])
+    h1 = np.zeros((taps, 2), complex); h1[2, 0] = 1
+    h2 = np.zeros((taps, 2), complex); h2[2, 1] = 1
+    k1, k2 = h1.copy(), h2.copy()
+    y, g1, g2 = oracle.cmaadaptivefilter_m(xx, h1, h2, taps, 2e-3, [1.0, 1.0])
+    np.testing.assert_array_equal(h1, k1); np.testing.assert_array_equal(h2, k2)
+    yc, c1, c2 = oracle.cmaadaptivefilter(xx, h1.copy(order="F"), h2.copy(order="F"), taps, 2e-3, [1.0, 1.0], 1)
+    np.testing.assert_allclose(y, yc, atol=1e-13); np.testing.assert_allclose(g1, c1, atol=1e-13); np.testing.assert_allclose(g2, c2, atol=1e-13)
+    y2, d1, d2 = oracle.cmaadaptivefilter(xx, h1.copy(order="F"), h2.copy(order="F"), taps, 2e-3, [1.0, 1.0], 2)
+    assert np.abs(d1 - g1).max() > 1e-4                      # half the updates are missing in the C filter at sps = 2
+    # an even number of taps is fine for the twin (the odd check is in the C gateway only, cmaadaptivefilter.c:118-119)
+    y4, _, _ = oracle.cmaadaptivefilter_m(xx, h1[:4], h2[:4], 4, 2e-3, [1.0, 1.0])
+    assert y4.shape == (L + taps - 1 - 4 + 1, 2)
+
+
+def test_easi_mfile_twin_reduces_to_the_c_filter_on_real_data_and_is_complex_otherwise(oracle):
+    """easiadaptivefilter.m:51-84 uses complex a, b and recombines all taps; easiadaptivefilter.c:81-90 uses Re(y) and
+    touches the real parts of tap 0.  On REAL inputs with one REAL tap the two coincide exactly (every imaginary part is
+    zero) -- that pins the twin's restatement to the C one; on complex inputs they differ ("the twins are
+    not equivalent").  First update checked against the formula written out."""
+    r = np.random.default_rng(12)
+    L = 200
+    xr = r.standard_normal((L, 2))
+    h1 = np.array([[0.9, 0.1]], complex); h2 = np.array([[-0.1, 0.9]], complex)
+    y, g1, g2 = oracle.easiadaptivefilter_m(xr, h1, h2, 1, 1e-3)
+    yc, c1, c2 = oracle.easiadaptivefilter(xr.astype(complex), h1.copy(order="F"), h2.copy(order="F"), 1, 1e-3, 1)
+    np.testing.assert_array_equal(y, yc); np.testing.assert_array_equal(g1, c1); np.testing.assert_array_equal(g2, c2)
+    xc = xr + 1j * r.standard_normal((L, 2))
+    y, g1, g2 = oracle.easiadaptivefilter_m(xc, h1, h2, 1, 1e-3)
+    yc, c1, c2 = oracle.easiadaptivefilter(xc, h1.copy(order="F"), h2.copy(order="F"), 1, 1e-3, 1)
+    assert np.abs(g1 - c1).max() > 1e-4 and np.abs(g1.imag).max() > 1e-4
+    # one sample by hand (errorfun :78-84, update :58-66)
+    mu = 1e-3
+    a = xc[0] @ h1[0]; b = xc[0] @ h2[0]
+    d1 = 1 + mu * (abs(a) ** 2 + abs(b) ** 2); d2 = 1 + mu * (a * abs(a) + b * abs(b))
+    E = np.array([[(abs(a) ** 2 - 1) / d1, a * b / d1 + a * b * (abs(a) ** 2 - abs(b) ** 2) / d2],
+                  [a * b / d1 + a * b * (abs(b) ** 2 - abs(a) ** 2) / d2, (abs(b) ** 2 - 1) / d1]])
+    n1 = (1 - mu * E[0, 0]) * h1 + (-mu * E[0, 1]) * h2
+    n2 = (-mu * E[1, 0]) * h1 + (1 - mu * E[1, 1]) * h2
+    y1, f1, f2 = oracle.easiadaptivefilter_m(xc[:1], h1, h2, 1, mu)
+    np.testing.assert_allclose(y1[0], [a, b], atol=1e-15)
+    np.testing.assert_allclose(f1, n1, atol=1e-15); np.testing.assert_allclose(f2, n2, atol=1e-15)
+
+
+def test_params_mat_and_mfile_twin_driver(oracle):
+    """cmapolardemux / easipolardemux start from params.mat when it is given (DspPdmCohQpsk.m:148-149, :201-202), whatever
+    txpolars says; with the .m twin of the EASI filter the driver takes the returned taps (:232-235)."""
+    r = np.random.default_rng(13)
+    L = 256
+    a = np.exp(1j * (np.pi / 4 + np.pi / 2 * r.integers(0, 4, (L, 2))))
+    th = 0.5
+    Rm = np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]])
+    x = (a @ Rm) * 4.0                                           # DspPdmCohQpsk divides by 4 sqrt(P), P = 1
+    x2 = np.repeat(x, 2, axis=0)                                 # 2 samples per symbol
+    base = dict(power_mw=1.0, applypol=True, polmethod="cma", cma_mu=1 / 500, cma_taps=3, freqavg=0, phasavg=0)
+    s0 = oracle.dsp_pdm_coh_qpsk(x2, oracle.dsp_params(**base))
+    # y_r = sum_p x_p h_r(p) with h_r = M(r,:) (:160-167): M = Rm undoes x = a*Rm exactly (Rm*Rm.' = I)
+    s1 = oracle.dsp_pdm_coh_qpsk(x2, oracle.dsp_params(cma_mat=Rm, **base))
+    assert np.abs(np.abs(s1) - 1).max() < 1e-12                  # already demultiplexed: the CMA has nothing to do
+    assert 1e-6 < np.abs(np.abs(s0) - 1).max() < 0.2             # from phizero = 0 it has to converge first
+    e = dict(base, polmethod="easi", easi_mu=1 / 500)
+    t0 = oracle.dsp_pdm_coh_qpsk(x2, oracle.dsp_params(**e))
+    t1 = oracle.dsp_pdm_coh_qpsk(x2, oracle.dsp_params(mfile_twins=True, **e))
+    assert np.abs(t0 - t1).max() > 1e-3                          # the C filter and its .m twin separate differently
+    y, h1, h2, n = oracle.easipolardemux_m(x / 4.0, np.eye(2), 1 / 500)
+    assert n >= 1 and np.abs(h1.imag).max() + np.abs(h2.imag).max() > 0
