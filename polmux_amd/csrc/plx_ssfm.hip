@@ -727,8 +727,26 @@ __device__ __noinline__ void kerr_full_range(int j, int t, double gamleff, int m
 // k_colx16: the fused column sweep for the 256 x (8+8) tile with both column transforms held in
 // REGISTERS (16 points per thread, r16_* + lvl2_*256): per tile one LDS exchange per transform instead
 // of four read+write passes, the Kerr step on registers (the other polarisation of a sample sits in
-// lane t^8: one DPP row rotation), and the next tile's 16 loads per thread in flight meanwhile.
+// lane t^8: one DPP row rotation).  The kernel sits at the VGPR cap (16 FP64 complex points per lane), so
+// the NEXT tile is staged by LDS-DMA (global_load_lds_dwordx4: no register destination) straight into the
+// exchange buffer as soon as the current tile has left it, and is in flight during the last register
+// transform and the stores of the current tile.
 // Thread = (j = tid>>4, t = tid&15): t < 8 -> column t of ux, t >= 8 -> column t-8 of uy.
+// LDS image of a tile: s[row][16] (256 B per row: 8 columns of ux | 8 of uy); one LDS-DMA instruction of a wave
+// fills 4 consecutive rows (64 lanes x 16 B = 1 KiB, lane-linear), wave w owns rows 64w .. 64w+63 -- exactly the
+// rows its own threads read first, so the landing needs the wave's own vmcnt wait and no workgroup barrier.
+#ifdef PLX_EMU
+__device__ __forceinline__ void glds16(const cplx *src, cplx *lds_wave_base, int lane) { lds_wave_base[lane] = *src; }
+__device__ __forceinline__ void glds_landed() {}
+#else
+__device__ __forceinline__ void glds16(const cplx *src, cplx *lds_wave_base, int)
+{
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void glds_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#endif
+
 __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf, int total)
 {
     PLX_DYN_LDS(lds);
@@ -743,102 +761,124 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     cplx *const fld = (t < 8) ? a.ux : a.uy;
     const int colt = t & 7;
     const bool isx = t < 8;
-    for (int tl = blockIdx.x; tl < total; tl += gridDim.x) {
+    const int lane = tid & 63, row0 = (tid >> 6) * 64;     // this wave stages rows row0 .. row0+63
+    // stage(tl, live): start the asynchronous copy of tile tl into s (live: the tile exists and its frame is still
+    // running -- read by the caller ahead of time, so that no load sits between the decision and the copy)
+    auto frame_live = [&](int tl) -> int {
+        if (tl >= total) return 0;
+        return a.ctl[(tl / tiles_x) / a.nfc].done ? 0 : 1;
+    };
+    auto stage = [&](int tl, int live) -> bool {
+        if (!live) return false;
+        const int fc = tl / tiles_x, bx = tl - fc * tiles_x;
+        // (lane & 15 == t: the lane stages a piece of the same column of the same polarisation it later works on)
+        const cplx *src = fld + ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt + (size_t)(row0 + (lane >> 4)) * N2;
+#pragma unroll
+        for (int i = 0; i < 16; i++) glds16(src + (size_t)(4 * i) * N2, s + (size_t)(row0 + 4 * i) * 16, lane);
+        return true;
+    };
+    int tl = blockIdx.x;
+    bool cur = stage(tl, frame_live(tl));
+    __syncthreads();                       // twiddles staged
+    while (tl < total) {
+        const int nxt = tl + gridDim.x;
         const int fc = tl / tiles_x, bx = tl - fc * tiles_x, f = fc / a.nfc, c = fc - f * a.nfc;
-        const bool cur = !a.ctl[f].done;
+        int nxt_live = frame_live(nxt);    // (a frame's flag cannot change before THIS workgroup has met its barrier)
+        if (!cur) { cur = stage(nxt, nxt_live); tl = nxt; continue; }   // (s is free here: every path below ends past its last read of s)
         const size_t cbase = ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt;
-        bool started = false;
-        if (cur) {
-            started = a.ctl[f].started != 0;
-            // the frame's leader takes the step-control record along now: at barrier time it is one LDS read away
-            if (tid == 0 && tl % tiles_pf == 0) *lctl = a.ctl[f];
+        const bool started = a.ctl[f].started != 0;
+        // the frame's leader takes the step-control record along now: at barrier time it is one LDS read away
+        if (tid == 0 && tl % tiles_pf == 0) *lctl = a.ctl[f];
+        glds_landed();                     // this wave's own rows of the tile are in LDS
+        pin(nxt_live);
+        {
             cplx x[16];
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = fld[cbase + (size_t)(16 * j + k) * N2];
-            if (started) r16_dit(x);       // rows 16j .. 16j+15 of the (bit-reversed) column spectrum
+            for (int k = 0; k < 16; k++) x[k] = s[((16 * j + k) << 4) + t];
+            if (started) {                 // rows 16j .. 16j+15 of the (bit-reversed) column spectrum
+                r16_dit(x);
 #pragma unroll
-            for (int k = 0; k < 16; k++) s[((16 * j + k) << 4) + t] = x[k];
+                for (int k = 0; k < 16; k++) s[((16 * j + k) << 4) + t] = x[k];
+            }
         }
         __syncthreads();
-        if (cur) {
-            cplx y[16];                    // point j + 16k
+        cplx y[16];                        // point j + 16k
 #pragma unroll
-            for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
-            double sc = 1.0;
-            if (started) {                 // finish step s: ifft (1/N), attenuation (:531-532)
-                lvl2_dit256(y, j, tw);
-                sc = a.ctl[f].att * a.invN;
-            }
-            double m = 0;
+        for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
+        double sc = 1.0;
+        if (started) {                     // finish step s: ifft (1/N), attenuation (:531-532)
+            lvl2_dit256(y, j, tw);
+            sc = a.ctl[f].att * a.invN;
+        }
+        double m = 0;
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                y[k] = cscale(y[k], sc);
-                // the other polarisation of the same sample lives in lane t^8: |ux|^2 + |uy|^2 from the two lanes' own
-                // powers (the same instructions on both, and a + b == b + a: the pair agrees to the bit)
-                const double po = fma(y[k].y, y[k].y, y[k].x * y[k].x);
-                const double p = po + lane_xchg<8>(po);
-                m = fmax(p, m);
-            }
-            m = wave_max(m);
-            if ((tid & 63) == 0) red[tid >> 6] = m;
-            __syncthreads();
-            // Frame barrier (dz of the next step needs the frame-wide maximum, fiber.m:694-698).  One launch = one round,
-            // so kernel boundaries order the rounds and the protocol needs no read-modify-write at all: every member
-            // stores its tile maximum into its own slot and polls ONE word; the leader (workgroup of the frame's first
-            // tile) polls the slots with a whole wave, runs the step controller and publishes Leff (or -1: finished) in
-            // the word of this launch's parity, having reset the slots and the other parity's word for the next round.
-            {
-                const int ti = tl % tiles_pf;
-                const unsigned par = (unsigned)a.round & 1u;
-                unsigned long long *slots = a.slots + (size_t)f * tiles_pf;
-                unsigned long long *pubw = a.pubw + 2 * (size_t)f;
-                if (ti != 0) {
-                    if (tid == 0) {
-                        double mm = red[0];
-                        for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
-                        st_agent(slots + ti, (unsigned long long)__double_as_longlong(mm));
-                        unsigned long long v = ~0ull;
-                        unsigned spins = 0;
-                        bool dead = false;
-                        const long long t0 = plx_clock();
-                        while ((v = ld_agent(pubw + par)) == ~0ull) {
-                            if (a.exp & 1) { v = (unsigned long long)__double_as_longlong(a.round > 60 ? -1.0 : 1500.0); break; }
-                            nap();
-                            if ((++spins & 255u) == 0 && (ld_agent((const unsigned *)a.ndone + 1) != 0 || plx_clock() - t0 > a.spin_ticks)) {
-                                st_agent((unsigned *)a.ndone + 1, 1u);   // the frame's partners are not co-resident: abort, store nothing
-                                dead = true;
-                                break;
-                            }
-                        }
-                        const double pv = __longlong_as_double((long long)v);
-                        red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm; red[19] = dead ? 1.0 : 0.0;
-                    }
-                } else if (tid < 64) {
+        for (int k = 0; k < 16; k++) {
+            y[k] = cscale(y[k], sc);
+            // the other polarisation of the same sample lives in lane t^8: |ux|^2 + |uy|^2 from the two lanes' own
+            // powers (the same instructions on both, and a + b == b + a: the pair agrees to the bit)
+            const double po = fma(y[k].y, y[k].y, y[k].x * y[k].x);
+            const double p = po + lane_xchg<8>(po);
+            m = fmax(p, m);
+        }
+        m = wave_max(m);
+        if ((tid & 63) == 0) red[tid >> 6] = m;
+        __syncthreads();
+        // Frame barrier (dz of the next step needs the frame-wide maximum, fiber.m:694-698).  One launch = one round,
+        // so kernel boundaries order the rounds and the protocol needs no read-modify-write at all: every member
+        // stores its tile maximum into its own slot and polls ONE word; the leader (workgroup of the frame's first
+        // tile) polls the slots with a whole wave, runs the step controller and publishes Leff (or -1: finished) in
+        // the word of this launch's parity, having reset the slots and the other parity's word for the next round.
+        {
+            const int ti = tl % tiles_pf;
+            const unsigned par = (unsigned)a.round & 1u;
+            unsigned long long *slots = a.slots + (size_t)f * tiles_pf;
+            unsigned long long *pubw = a.pubw + 2 * (size_t)f;
+            if (ti != 0) {
+                if (tid == 0) {
                     double mm = red[0];
                     for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
-                    double pm;
+                    st_agent(slots + ti, (unsigned long long)__double_as_longlong(mm));
+                    unsigned long long v = ~0ull;
                     unsigned spins = 0;
                     bool dead = false;
                     const long long t0 = plx_clock();
-                    for (;;) {
-                        bool all = true;
-                        pm = (tid == 0) ? a.gam[c] * mm : -INFINITY;       // the leader's own tile (channel c of tile 0)
-                        for (int i = 1 + tid; i < tiles_pf; i += 64) {
-                            const unsigned long long b = ld_agent(slots + i);
-                            if (b == ~0ull) all = false;
-                            else { const double gp = a.gam[i / tiles_x] * __longlong_as_double((long long)b); pm = gp > pm ? gp : pm; }
-                        }
-                        if (__all(all) || (a.exp & 1)) break;
+                    while ((v = ld_agent(pubw + par)) == ~0ull) {
                         nap();
-                        if ((++spins & 255u) == 0) {           // (wave-uniform: every lane evaluates the same test)
-                            const int late = ld_agent((const unsigned *)a.ndone + 1) != 0 || plx_clock() - t0 > a.spin_ticks;
-                            if (__any(late)) { dead = true; break; }
+                        if ((++spins & 255u) == 0 && (ld_agent((const unsigned *)a.ndone + 1) != 0 || plx_clock() - t0 > a.spin_ticks)) {
+                            st_agent((unsigned *)a.ndone + 1, 1u);   // the frame's partners are not co-resident: abort, store nothing
+                            dead = true;
+                            break;
                         }
                     }
-                    pm = wave_max(pm);
-                    if (dead) {
-                        if (tid == 0) { st_agent((unsigned *)a.ndone + 1, 1u); red[19] = 1.0; }
-                    } else {
+                    const double pv = __longlong_as_double((long long)v);
+                    red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm; red[19] = dead ? 1.0 : 0.0;
+                }
+            } else if (tid < 64) {
+                double mm = red[0];
+                for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
+                double pm;
+                unsigned spins = 0;
+                bool dead = false;
+                const long long t0 = plx_clock();
+                for (;;) {
+                    bool all = true;
+                    pm = (tid == 0) ? a.gam[c] * mm : -INFINITY;       // the leader's own tile (channel c of tile 0)
+                    for (int i = 1 + tid; i < tiles_pf; i += 64) {
+                        const unsigned long long b = ld_agent(slots + i);
+                        if (b == ~0ull) all = false;
+                        else { const double gp = a.gam[i / tiles_x] * __longlong_as_double((long long)b); pm = gp > pm ? gp : pm; }
+                    }
+                    if (__all(all)) break;
+                    nap();
+                    if ((++spins & 255u) == 0) {           // (wave-uniform: every lane evaluates the same test)
+                        const int late = ld_agent((const unsigned *)a.ndone + 1) != 0 || plx_clock() - t0 > a.spin_ticks;
+                        if (__any(late)) { dead = true; break; }
+                    }
+                }
+                pm = wave_max(pm);
+                if (dead) {
+                    if (tid == 0) { st_agent((unsigned *)a.ndone + 1, 1u); red[19] = 1.0; }
+                } else {
                     for (int i = 1 + tid; i < tiles_pf; i += 64) st_agent(slots + i, ~0ull);
                     if (tid == 0) {
                         const double pv = ctrl_core_call(a.dphimax, a.alphalin, a.dzmax, a.dz0, a.zdone0, a.Lf, a.lcorr,
@@ -848,27 +888,28 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                         a.ctl[f] = *lctl;                            // ... before the record goes back (k_row reads it)
                         red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm; red[19] = 0.0;
                     }
-                    }
                 }
             }
-            __syncthreads();
-            if (red[19] != 0.0) return;    // barrier timed out (uniform over the workgroup): no store, no control update
-            const double leff = red[16];
-            const bool finished = red[17] != 0.0;
-            if (finished) {                // the frame has reached the fibre end: write the field out
+        }
+        __syncthreads();
+        if (red[19] != 0.0) return;        // barrier timed out (uniform over the workgroup): no store, no control update
+        const double leff = red[16];
+        const bool finished = red[17] != 0.0;
+        if (finished) {                    // the frame has reached the fibre end: write the field out
+            cur = stage(nxt, nxt_live);    // (every thread is past its reads of s: the barrier above)
 #pragma unroll
-                for (int k = 0; k < 16; k++) fld[cbase + (size_t)(j + 16 * k) * N2] = y[k];
-            } else {
-                if (a.spm) {               // Kerr step of step s+1 (:832-852) on registers
-                    const double gamleff = a.gam[c] * leff;
-                    // |gamleff*P| <= gamleff * (tile maximum): a few mrad under the step controller, so the
-                    // Taylor form applies to the whole tile; otherwise ('--s-' exact single step) the rare
-                    // full-range path goes through LDS, one thread per polarisation pair.
-                    const double sgn = isx ? 1.0 : -1.0;
-                    if (fabs(gamleff) * red[18] < 0.0625) {
-                        // (one loop per equation: a uniform branch inside the unrolled body would cut it into 32 basic blocks)
-                        auto kerr16 = [&](auto cn) {
-                            constexpr bool CNLSE = decltype(cn)::value;
+            for (int k = 0; k < 16; k++) fld[cbase + (size_t)(j + 16 * k) * N2] = y[k];
+        } else {
+            if (a.spm) {                   // Kerr step of step s+1 (:832-852) on registers
+                const double gamleff = a.gam[c] * leff;
+                // |gamleff*P| <= gamleff * (tile maximum): a few mrad under the step controller, so the
+                // Taylor form applies to the whole tile; otherwise ('--s-' exact single step) the rare
+                // full-range path goes through LDS, one thread per polarisation pair.
+                const double sgn = isx ? 1.0 : -1.0;
+                if (fabs(gamleff) * red[18] < 0.0625) {
+                    // (one loop per equation: a uniform branch inside the unrolled body would cut it into 32 basic blocks)
+                    auto kerr16 = [&](auto cn) {
+                        constexpr bool CNLSE = decltype(cn)::value;
 #pragma unroll
                         for (int k = 0; k < 16; k++) {
                             // own / oth = this lane's and its partner's polarisation of the sample.  Everything the two
@@ -892,32 +933,33 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                             }
                             y[k] = A;
                         }
-                        };
-                        if (a.manakov) kerr16(std::false_type{}); else kerr16(std::true_type{});
-                    } else {
+                    };
+                    if (a.manakov) kerr16(std::false_type{}); else kerr16(std::true_type{});
+                } else {
 #pragma unroll
-                        for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
-                        __syncthreads();
-                        if (isx) kerr_full_range(j, t, gamleff, a.manakov);
-                        __syncthreads();
+                    for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
+                    __syncthreads();
+                    if (isx) kerr_full_range(j, t, gamleff, a.manakov);
+                    __syncthreads();
 #pragma unroll
-                        for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
-                        __syncthreads();
-                    }
+                    for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
+                    __syncthreads();
                 }
-                lvl2_dif256(y, j, tw);
-#pragma unroll
-                for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
-                __syncthreads();
-                cplx x[16];
-#pragma unroll
-                for (int k = 0; k < 16; k++) x[k] = s[((16 * j + k) << 4) + t];
-                r16_dif(x);
-#pragma unroll
-                for (int k = 0; k < 16; k++) fld[cbase + (size_t)(16 * j + k) * N2] = x[k];
             }
+            lvl2_dif256(y, j, tw);
+#pragma unroll
+            for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
+            __syncthreads();
+            cplx x[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = s[((16 * j + k) << 4) + t];
+            __syncthreads();               // the exchange buffer is free: the next tile may land in it ...
+            cur = stage(nxt, nxt_live);
+            r16_dif(x);                    // ... during the last register transform and the stores of this one
+#pragma unroll
+            for (int k = 0; k < 16; k++) fld[cbase + (size_t)(16 * j + k) * N2] = x[k];
         }
-        __syncthreads();
+        tl = nxt;
     }
 }
 
