@@ -65,7 +65,6 @@ struct SsfmArgs {
     unsigned long long *umax;      // [F][nfc] bit pattern of max |u|^2 (>= 0)
     int *ndone;                    // [0] frames that have reached the fibre end, [1] sticky abort word (a frame barrier timed out)
     long long spin_ticks;          // frame-barrier timeout in ticks of plx_clock() (10 ns)
-    int exp;                       // TEMPORARY experiment bits (PLX_SSFM_EXP)
     unsigned long long *slots;     // [F][tiles per frame] per-tile max |u|^2 of the current round (k_colx16), ~0 = not arrived
     unsigned long long *pubw;      // [F][2] published Leff (or -1: frame finished) of the round, by launch parity, ~0 = not yet
     int round;                     // launch index of the fused sweep within this propagate call
@@ -1054,7 +1053,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, exp = 0, wg_per_cu = 0;
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0;
     double barrier_timeout_ms = 500.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -1066,8 +1065,6 @@ struct Tune {
         row_threads = geti("PLX_SSFM_ROW_THREADS", -1);
         col_threads = geti("PLX_SSFM_COL_THREADS", -1);
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
-        exp = geti("PLX_SSFM_EXP", 0);
-        wg_per_cu = geti("PLX_SSFM_FUSE_WG_PER_CU", 0);
         if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
     }
 };
@@ -1149,7 +1146,6 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     a.lcorr = desc->length / desc->nplates; // fiber.m:507
     a.invN = 1.0 / (double)N;
     a.spin_ticks = (long long)(tune.barrier_timeout_ms * 1e5);
-    a.exp = tune.exp;
 
     // ---- tables: spectral multipliers in the order the row pass sees them ----
     std::vector<double> bt((size_t)nfc * N), d1;
@@ -1227,9 +1223,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
                 ncu = v;
         }
         const int tiles_pf = nfc * (N2 / a.W);
-        int bpc = blocks_per_cu(k_colx16, 256, P->lds_col);
-        if (tune.wg_per_cu > 0 && tune.wg_per_cu < bpc) bpc = tune.wg_per_cu;
-        const int cap = ncu * bpc;
+        const int cap = ncu * blocks_per_cu(k_colx16, 256, P->lds_col);
         if (tiles_pf <= cap) {
             P->fused = 1;
             P->tiles_pf = tiles_pf;
