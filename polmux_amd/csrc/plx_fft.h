@@ -220,7 +220,35 @@ __device__ __forceinline__ void lvl2_dif256(cplx *y, int j, const cplx *tw)
     }
 }
 
+// Twiddle tables of the row transforms.  Plain: the half table W_M^k, k < M/2 (8 bytes of LDS per point of the row).
+// COMPACT (long rows, M >= 4096, where that table would cost a second workgroup per CU): W_M^{4k}, k < M/8, followed
+// by the four fine factors W_M^0..3; only the outermost radix-4 stage has odd exponents and pays one more complex
+// product per twiddle, every other stage reads W_M^{4k} directly.
+template <bool COMPACT> __device__ __forceinline__ cplx row_tw(const cplx *tw, int k, int halfM)
+{   // W_M^k, k < M/2
+    if (!COMPACT) return tw[k];
+    return cmul(tw[k >> 2], tw[(halfM >> 2) + (k & 3)]);
+}
+template <bool COMPACT> __device__ __forceinline__ cplx row_tw3(const cplx *tw, int k3, int halfM)
+{   // W_M^{k3}, k3 < 3M/4: W^{k+M/2} = -W^k
+    const cplx w = row_tw<COMPACT>(tw, k3 & (halfM - 1), halfM);
+    const bool neg = k3 >= halfM;
+    return make_double2(neg ? -w.x : w.x, neg ? -w.y : w.y);
+}
+template <bool COMPACT> __device__ __forceinline__ cplx row_tw4(const cplx *tw, int k, int halfM)
+{   // W_M^k for k a multiple of 4 (every stage but the outermost)
+    return COMPACT ? tw[k >> 2] : tw[k];
+}
+template <bool COMPACT> __device__ __forceinline__ cplx row_tw4_3(const cplx *tw, int k3, int halfM)
+{
+    const cplx w = row_tw4<COMPACT>(tw, k3 & (halfM - 1), halfM);
+    const bool neg = k3 >= halfM;
+    return make_double2(neg ? -w.x : w.x, neg ? -w.y : w.y);
+}
+
 // T = 1<<logT padded rows of M = 1<<logM (M >= 16) points each, row t at s + t*row_pitch(M).
+// (COMPACT tables: logM even, >= 6, so that the head stage is the radix-4 stage with sh = 0.)
+template <bool COMPACT = false>
 __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
 {
     const int M = 1 << logM, halfM = M >> 1, T = 1 << logT, TSp = row_pitch(M);
@@ -249,9 +277,16 @@ __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const c
             cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
             const int k = j << sh;
             cplx y0 = cadd(t0, t2), y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
-            y1 = cmul(y1, tw[k]);      // (no guard for k = 0: it diverges inside every wave and splits the basic block)
-            y2 = cmul(y2, tw[2 * k]);
-            y3 = cmul(y3, tw3(tw, 3 * k, halfM));
+            // (no guard for k = 0: it diverges inside every wave and splits the basic block)
+            if (COMPACT && sh == 0) {  // outermost stage: odd exponents (uniform branch)
+                y1 = cmul(y1, row_tw<COMPACT>(tw, k, halfM));
+                y2 = cmul(y2, row_tw<COMPACT>(tw, 2 * k, halfM));
+                y3 = cmul(y3, row_tw3<COMPACT>(tw, 3 * k, halfM));
+            } else {
+                y1 = cmul(y1, row_tw4<COMPACT>(tw, k, halfM));
+                y2 = cmul(y2, row_tw4<COMPACT>(tw, 2 * k, halfM));
+                y3 = cmul(y3, row_tw4_3<COMPACT>(tw, 3 * k, halfM));
+            }
             p[0] = y0; p[qs] = y2; p[2 * qs] = y1; p[3 * qs] = y3;
         }
         __syncthreads();
@@ -272,6 +307,7 @@ __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const c
     }
 }
 
+template <bool COMPACT = false>
 __device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
 {
     const int M = 1 << logM, halfM = M >> 1, T = 1 << logT, TSp = row_pitch(M);
@@ -300,9 +336,15 @@ __device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const c
             cplx *p = s + t * TSp + row_phys(base);
             cplx c0 = p[0], c2 = p[qs], c1 = p[2 * qs], c3 = p[3 * qs];
             const int k = j << sh;
-            c1 = cmulc(c1, tw[k]);
-            c2 = cmulc(c2, tw[2 * k]);
-            c3 = cmulc(c3, tw3(tw, 3 * k, halfM));
+            if (COMPACT && sh == 0) {
+                c1 = cmulc(c1, row_tw<COMPACT>(tw, k, halfM));
+                c2 = cmulc(c2, row_tw<COMPACT>(tw, 2 * k, halfM));
+                c3 = cmulc(c3, row_tw3<COMPACT>(tw, 3 * k, halfM));
+            } else {
+                c1 = cmulc(c1, row_tw4<COMPACT>(tw, k, halfM));
+                c2 = cmulc(c2, row_tw4<COMPACT>(tw, 2 * k, halfM));
+                c3 = cmulc(c3, row_tw4_3<COMPACT>(tw, 3 * k, halfM));
+            }
             cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
             p[0] = cadd(s0, s2); p[qs] = cadd(s1, s3); p[2 * qs] = csub(s0, s2); p[3 * qs] = csub(s1, s3);
         }

@@ -121,6 +121,7 @@ extern "C" int plx_pmdinv_create(plx_pmdinv **out, int64_t nfft, int max_frames)
     std::memset(&sd, 0, sizeof(sd));
     sd.nfft = nfft; sd.nfc = 1; sd.dual_pol = 1; sd.max_frames = max_frames;
     sd.dzmaxt = 1; sd.dphimaxt = 1; sd.length = 1; sd.nplates = 1; sd.gam = &gam0; sd.betat = zeros.data();
+    sd.fls[1] = 1;   // a PMD-type plan: the matrix multiplier needs both polarisations of a bin in one row workgroup
     int rc = plx_ssfm_create(&P->fft, &sd);
     if (rc != PLX_OK) { pmdinv_free(P); return rc; }
     if (hipMalloc((void **)&P->d_u, sizeof(cplx) * 3 * (size_t)nfft * max_frames) != hipSuccess) {

@@ -505,7 +505,9 @@ __device__ __forceinline__ void pmd_trunks(cplx &x, cplx &y, double btf, double 
 // transform, all on one LDS-resident row set (padded layout, see plx_fft.h).
 #define ROW_THREADS 128
 #define ROW_CH 4
-__global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
+// TWC: compact twiddle table (plx_fft.h, row_tw): 4096-point rows, where the plain half table would cost the second
+// workgroup of a CU.
+template <bool TWC> __global__ __launch_bounds__(1024) void k_row_t(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
@@ -516,7 +518,7 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     const int N2 = 1 << a.p2, R = a.R, TSp = row_pitch(N2);
     cplx *s = (cplx *)lds;                       // [npol*R][TSp]
     cplx *tw = s + (size_t)(a.dual ? 2 : 1) * R * TSp;
-    lds_load_twiddles(tw, a.tw2, N2 >> 1, tid, nthr);
+    lds_load_twiddles(tw, a.tw2, TWC ? (N2 >> 3) + 4 : N2 >> 1, tid, nthr);
     const size_t N = (size_t)1 << (a.p1 + a.p2);
     const size_t base = (size_t)fc * N;
     const int j0 = blockIdx.x * R;
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         }
     }
     __syncthreads();
-    row_fft_dif(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
+    row_fft_dif<TWC>(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     const double cur = a.force ? a.f_cur : ctl->cur;
     if (!a.dual) {
         for (int e = tid; e < nel; e += nthr) { // Hf = fastexp(-betat*dz) :771
@@ -615,7 +617,7 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         }
     }
     __syncthreads();
-    row_fft_dit(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
+    row_fft_dit<TWC>(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     if (keep_tw) {
 #pragma unroll
         for (int k = 0; k < ROW_CH; k++) {
@@ -633,6 +635,8 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         if (a.dual) a.uy[base + rowbase + e] = cmulc(s[o + R * TSp], t);
     }
 }
+
+#define k_row (k_row_t<false>)
 
 // ------------------------------------------------------ pass 3: inverse columns ---
 // Completes ifft (1/N), applies the attenuation of the step (:531-532) and feeds
@@ -986,6 +990,7 @@ struct plx_ssfm {
     int row_threads = ROW_THREADS; // workgroup size of k_row
     int row_split = 0, rs_threads = 0; // long rows without PMD: one polarisation per workgroup (scalar row pass twice)
     size_t rs_lds = 0;
+    int tw_compact = 0;            // 4096-point rows: compact twiddle table in d_tw2 (k_row_t<true>)
     double *h_brf[2] = {nullptr, nullptr}; // pinned staging of the waveplate tables
     hipEvent_t brf_ev[2] = {nullptr, nullptr};
     int brf_slot = 0;
@@ -1099,7 +1104,11 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         const int npol = desc->dual_pol ? 2 : 1;
         logW = desc->dual_pol ? 3 : 4;                       // 8 (dual) / 16 (scalar) columns per tile (measured best)
         int p1 = 12 - (logW + (npol == 2 ? 1 : 0));          // N1 * T = 4096 complex = 64 KiB
-        const int p2max = 11;
+        // 2^20-sample dual-polarisation frames without PMD keep the 256-row tile of the fused column sweep and take
+        // 4096-point rows instead (one polarisation per row workgroup, compact twiddle table: two workgroups per CU);
+        // everything else stops at 2048-point rows and gets taller column tiles
+        const bool long_rows = desc->dual_pol && !desc->fls[1] && desc->nfc == 1 && !tune.no_fuse && !tune.no_row_split;
+        const int p2max = long_rows ? 12 : 11;
         if (p - p1 > p2max) p1 = p - p2max;                  // large frames: taller tiles instead
         if (p1 > p - 4) p1 = p - 4;                          // keep N2 >= 16
         if (p1 < 2) p1 = 2;
@@ -1135,10 +1144,15 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     // Long rows leave room for a single dual-polarisation workgroup per CU.  Without PMD the two polarisations only
     // share the multiplier, so each gets its own workgroup (the scalar form of the row pass, R = 1): half the LDS,
     // 2-3 workgroups per CU.
-    if (a.dual && N2 >= 2048 && !tune.no_row_split) {   // measured: 2^20 frames 74 -> 66 ms; at N2 = 1024 it loses (47 -> 52)
+    P->tw_compact = P->p2 >= 12 ? 1 : 0;
+    if (a.dual && (N2 >= 2048 && !tune.no_row_split)) {   // measured: 2^20 frames 74 -> 66 ms; at N2 = 1024 it loses (47 -> 52)
         P->row_split = 1;
         P->rs_threads = N2 / 8 < ROW_THREADS ? ROW_THREADS : (N2 / 8 > 1024 ? 1024 : N2 / 8);
-        P->rs_lds = ((size_t)(N2 + N2 / 16) + N2 / 2) * sizeof(cplx);
+        P->rs_lds = ((size_t)(N2 + N2 / 16) + (P->tw_compact ? N2 / 8 + 4 : N2 / 2)) * sizeof(cplx);
+    }
+    if (P->tw_compact && (!P->row_split || a.pmd)) {
+        free_plan(P);
+        PLX_FAIL(PLX_ERR_UNSUPPORTED, "plx_ssfm_create: 4096-point rows need the one-polarisation row pass (no PMD)");
     }
     a.spm = desc->fls[2]; a.xpm = desc->fls[3]; a.manakov = desc->manakov ? 1 : 0; a.pmd = desc->fls[1] ? 1 : 0;
     a.nplates = desc->nplates;
@@ -1169,7 +1183,16 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     }
     std::vector<cplx> t1, t2;
     half_table(t1, N1);
-    half_table(t2, N2);
+    if (P->tw_compact) {   // W_N2^{4k}, k < N2/8, then W_N2^0..3 (plx_fft.h, row_tw)
+        t2.resize(N2 / 8 + 4);
+        for (int k = 0; k < N2 / 8 + 4; k++) {
+            const int e = k < N2 / 8 ? 4 * k : k - N2 / 8;
+            long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)e / (long double)N2;
+            t2[k] = make_double2((double)cosl(ang), (double)sinl(ang));
+        }
+    } else {
+        half_table(t2, N2);
+    }
     std::vector<double> gam(nfc);
     for (int c = 0; c < nfc; c++) gam[c] = (a.dual && a.manakov) ? desc->gam[c] * 8 / 9 : desc->gam[c]; // :499-501
 
@@ -1205,7 +1228,9 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
                                                             // 256 by 3-12 %; tall tiles of large frames: one workgroup per CU, 16 waves
     if (tune.col_threads == 128 || tune.col_threads == 256 || tune.col_threads == 512 || tune.col_threads == 1024) P->col_threads = tune.col_threads;
     if (allow_lds(k_colx16, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
-        allow_lds(k_col_inv, P->lds_col) != hipSuccess || allow_lds(k_row, P->lds_row > P->rs_lds ? P->lds_row : P->rs_lds) != hipSuccess) {
+        allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
+        (!P->tw_compact && allow_lds(k_row, P->lds_row > P->rs_lds ? P->lds_row : P->rs_lds) != hipSuccess) ||
+        (P->tw_compact && allow_lds((k_row_t<true>), P->rs_lds) != hipSuccess)) {
         free_plan(P);
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
     }
@@ -1307,6 +1332,25 @@ extern "C" int plx_ssfm_set_birefringence_dev(plx_ssfm *P, const double *db0, co
     return set_brf(P, db0, theta, epsilon, nsets, (hipStream_t)stream, false);
 }
 
+// The row pass of one step / filter pass: one launch over both polarisations, or -- long rows without PMD -- the
+// one-polarisation form twice (the polarisations only share the multiplier there).
+static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t st)
+{
+    const int N1 = 1 << a.p1;
+    if (P->row_split && a.dual && !a.pmd) {
+        SsfmArgs b = a;
+        b.dual = 0; b.R = 1; b.logR = 0;
+        const dim3 gs((unsigned)N1, FC), bs((unsigned)P->rs_threads);
+        for (int pol = 0; pol < 2; pol++) {
+            if (pol) b.ux = a.uy;
+            if (P->tw_compact) PLX_LAUNCH((k_row_t<true>), gs, bs, P->rs_lds, st, b);
+            else PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
+        }
+        return;
+    }
+    PLX_LAUNCH(k_row, dim3((unsigned)(N1 / a.R), FC), dim3((unsigned)P->row_threads), P->lds_row, st, a);
+}
+
 extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, int nframes, void *stream)
 {
     if (!P || !d_ux) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: null argument");
@@ -1375,7 +1419,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
                 emu::g_concurrency = 1;
 #endif
                 PLX_MARK(1, steps + sidx);
-                PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
+                launch_row(P, a, FC, st);
                 P->row_launches++;
                 continue;
             }
@@ -1389,15 +1433,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
             PLX_MARK(0, steps + sidx);
             PLX_LAUNCH(k_col_fwd, gcol, bcol, P->lds_col, st, a);
             PLX_MARK(1, steps + sidx);
-            if (P->row_split && !a.pmd) {
-                SsfmArgs b = a;
-                b.dual = 0; b.R = 1; b.logR = 0;
-                const dim3 gs((unsigned)N1, FC), bs((unsigned)P->rs_threads);
-                PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
-                b.ux = a.uy;
-                PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
-            }
-            else PLX_LAUNCH(k_row, grow, dim3((unsigned)rowthr), P->lds_row, st, a);
+            launch_row(P, a, FC, st);
             PLX_MARK(2, steps + sidx);
             PLX_LAUNCH(k_col_inv, gcol, bcol, P->lds_col, st, a);
             P->row_launches++;
@@ -1512,7 +1548,8 @@ int plx_ssfm_filter_dev(plx_ssfm *P, cplx *d_ux, cplx *d_uy, const cplx *d_hmul,
     PLX_HIP(hipMemsetAsync(P->d_ndone, 0, 64, st));
     const dim3 gcol((unsigned)(N2 / b.W), FC), grow((unsigned)(N1 / b.R), FC);
     PLX_LAUNCH(k_col_fwd, gcol, dim3((unsigned)P->col_threads), P->lds_col, st, b);
-    PLX_LAUNCH(k_row, grow, dim3((unsigned)P->row_threads), P->lds_row, st, b);
+    if (d_umat) PLX_LAUNCH(k_row, grow, dim3((unsigned)P->row_threads), P->lds_row, st, b);   // matrix tables couple the polarisations
+    else launch_row(P, b, FC, st);
     PLX_LAUNCH(k_col_inv, gcol, dim3((unsigned)P->col_threads), P->lds_col, st, b);
     PLX_HIP(hipGetLastError());
     return PLX_OK;

@@ -323,6 +323,32 @@ def test_emu_sweep_variants(emu, oracle, monkeypatch):
             assert np.abs(gy[f] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
 
 
+def test_emu_long_rows_compact_twiddles(emu, oracle, monkeypatch):
+    """4096-point rows (the row pass of 2^20-sample frames: one polarisation per workgroup, compact twiddle table W^{4k} +
+    four fine factors, plx_fft.h row_tw) on a 16 x 4096 split of a 2^16 frame: field and step count against the oracle."""
+    n, nt, L = 65536, 64, 1.2e3
+    fls = [1, 0, 1, 0]
+    betat, db1 = _tables(n, nt, fls, 1)
+    f = _qpsk_field(n, nt, 6.0)
+    monkeypatch.setenv("PLX_SSFM_P1", "4")
+    d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=1)
+    plan = C.c_void_p()
+    emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+    monkeypatch.delenv("PLX_SSFM_P1")
+    info = (C.c_int32 * 8)()
+    emu.call("plx_ssfm_info", plan, info)
+    assert list(info)[:3] == [0, 4, 12] and info[7] == 1          # three sweeps, 16 x 4096, one polarisation per row workgroup
+    ux = _il(f[0][None]); uy = _il(f[1][None])
+    emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 1, None)
+    nc = np.zeros(1, np.int32)
+    emu.call("plx_ssfm_results", plan, 1, None, _vp(nc))
+    emu.call("plx_ssfm_destroy", plan)
+    rc, fd, onc, ox, oy = oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0])
+    assert nc[0] == onc
+    assert np.abs(ux.view(np.complex128).reshape(n) - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
+    assert np.abs(uy.view(np.complex128).reshape(n) - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
+
+
 def test_emu_frame_barrier_timeout_aborts_cleanly(emu, monkeypatch):
     """A fused-sweep frame whose workgroups are not co-resident (here: the emulator runs ONE workgroup at a time) must
     end in a clean error, never a hang: the barrier times out (wall clock), raises the sticky abort word, nothing is
