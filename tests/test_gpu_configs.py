@@ -249,3 +249,40 @@ def test_c0_32gbaud_single_pol_linear_span_with_post_compensation(lib, oracle):
     # no noise, dispersion undone: the transmitted bits come back up to the blind phase estimate's pi/2 ambiguity
     errs = min(int((oracle.samp2pat_coherent(np.angle(ref * 1j ** k)) != patmat).sum()) for k in range(4))
     assert errs == 0
+
+
+# ===================================================== data-dependent trip counts in one batch ===
+def test_power_ladder_batch_every_frame_keeps_the_reference_step_count(lib, oracle):
+    """fiber.m:518,534: the number of steps depends on the frame's own peak power.  A batch whose 64 frames sit on BASELINE
+    config[4]'s launch-power ladder (-4...+8 dBm, different de Bruijn sequences as well) advances in lock-step launches;
+    EVERY frame must leave with the oracle's ncycle and firstdz, sampled frames with the oracle's field -- whatever the
+    other frames of the batch are doing (finished frames drop out of the launches, fuzz_batch.py's check as a test)."""
+    from polmux_amd import pipeline
+    cfg = pipeline.HotPathConfig(nsymb=256, nt=64, variants=4, length=8e4)
+    F = 64
+    hp = pipeline.HotPath(cfg, max_frames=F)
+    assert hp.fused()
+    dbm = -4.0 + 12.0 * np.arange(F) / 63.0
+    scale = 10 ** (dbm / 10) / cfg.pavg_mw
+    ux, uy = hp.make_batch(F, scale)
+    hp.fibre(ux, uy)
+    _sync()
+    nc = hp.last_ncycle(F)
+    fd = np.zeros(F)
+    hp.lib.call("plx_ssfm_results", hp.ssfm, F, fd.ctypes.data, None)
+    gam, betat, db1 = hp._keep
+    gx, gy = ux.cpu().numpy(), uy.cpu().numpy()
+    want = []
+    for f in range(F):
+        vx, vy, _ = hp.var_host[f % hp.nvar]
+        rc, ofd, onc, ox, oy = oracle.matrix_ssfm(vx * math.sqrt(scale[f]), vy * math.sqrt(scale[f]), betat, db1, cfg.dzmax, cfg.dphimax,
+                                                  gam, hp.alphalin, cfg.length, 1, 0, hp.fls, [0.0], [0.0], [0.0])
+        want.append(onc)
+        assert abs(fd[f] - ofd) <= 1e-12 * ofd
+        if f in (0, 17, 40, 63):
+            assert np.abs(gx[f] - ox[:, 0]).max() <= FIELD_RTOL * np.abs(ox).max()
+            assert np.abs(gy[f] - oy[:, 0]).max() <= FIELD_RTOL * np.abs(oy).max()
+    assert nc.tolist() == want
+    assert max(want) >= 4 * min(want)                                # the ladder really spreads the trip counts
+    assert hp.ssfm_stats()[1] == sum(want) * cfg.nfft
+    hp.close()

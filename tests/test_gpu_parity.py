@@ -450,7 +450,7 @@ def test_cma_mfile_twin_gateway(lib, oracle, taps, sps):
     """the .m twin of the CMA filter (cmaadaptivefilter.m:52-72: every sample updates whatever sps is,
     no odd-taps check, the updated taps are RETURNED and the inputs left alone) through plx_cmaadaptivefilter_m."""
     from polmux_amd.rx import cmaadaptivefilter_m
-    xx, _ = _mixed_qpsk(300 + taps - 1, 21 + taps)
+    _, xx = _mixed_qpsk(300 + taps - 1, 21 + taps)
     h1 = np.zeros((taps, 2), complex); h1[taps // 2, 0] = 1
     h2 = np.zeros((taps, 2), complex); h2[taps // 2, 1] = 1
     k1, k2 = h1.copy(), h2.copy()
@@ -468,7 +468,7 @@ def test_easi_mfile_twin_gateway(lib, oracle, taps):
     """The .m twin of the EASI filter (easiadaptivefilter.m:51-84): complex error matrix, all taps of the complex h1, h2
     recombined -- NOT the real-parts-of-tap-0 update of easiadaptivefilter.c (tested by test_easiadaptivefilter_gateway)."""
     from polmux_amd.rx import easiadaptivefilter_m
-    xx, _ = _mixed_qpsk(200 + taps - 1, 31 + taps)
+    _, xx = _mixed_qpsk(200 + taps - 1, 31 + taps)
     r = np.random.default_rng(3)
     h1 = 0.1 * (r.standard_normal((taps, 2)) + 1j * r.standard_normal((taps, 2))); h1[0, 0] += 1
     h2 = 0.1 * (r.standard_normal((taps, 2)) + 1j * r.standard_normal((taps, 2))); h2[0, 1] += 1
