@@ -310,6 +310,7 @@ def main():
     errs, resolved = [], []
     fib_ms, rx_ms, row_launches, sample_steps = [], [], 0, 0
     k_ms, k_n = np.zeros(4), np.zeros(4, np.int64)
+    util = np.zeros(3, np.int64)
     for i in range(a.warmup):
         ux, uy = get_batch(i)
         hp.run(ux, uy, noise_sigma=a.noise, noise_seed=1000 * rank + i)
@@ -344,6 +345,7 @@ def main():
         row_launches += rl; sample_steps += ss
         km, kn = hp.kernel_times()
         k_ms += km; k_n += kn
+        util += np.array(hp.utilisation(), np.int64)
     sync_all()
     dt = time.perf_counter() - t0
     for e in errs:
@@ -441,9 +443,12 @@ def main():
                        "tx_variants": hp.nvar, "power_ladder": bool(a.power_ladder),
                        "ssfm_steps_per_frame": sample_steps / (a.steps * F * n),
                        "ssfm_steps_min_max": [int(ncyc.min()), int(ncyc.max())] if len(ncyc) else None,
-                       # lock-step launches: share of the launched frame slots that still had a step to do (finished frames
-                       # cost an early-exit, not a sweep)
-                       "active_frame_utilisation": float(ncyc.sum() / (F * ncyc.max())) if len(ncyc) else None,
+                       # lock-step launches over frames with different trip counts (fiber.m:518): frame-steps with work / frame
+                       # slots the workgroups iterated over (device active list, rebuilt before every step) / frame slots the
+                       # host's grids covered (its view lags: surplus workgroups exit at once) / without any compaction
+                       "active_frame_utilisation": float(util[0] / max(1, util[1])),
+                       "launched_slot_utilisation": float(util[0] / max(1, util[2])),
+                       "utilisation_without_compaction": float(ncyc.sum() / (F * ncyc.max())) if len(ncyc) else None,
                        "rx_noise_sigma": a.noise,
                        "fibre_ms_per_step": fib / a.steps, "rxdsp_ms_per_step": rxm / a.steps,
                        "frames_per_s": float(world) * a.steps * F / dt, "fresh_pmd_per_realisation": bool(a.mc),

@@ -112,6 +112,11 @@ int plx_ssfm_stats(plx_ssfm *plan, int64_t *row_pass_launches, int64_t *sample_s
  * summed duration and count of the ACTIVE launches (those issued before the slowest frame had finished) of kernel
  * class k: 0 = column sweep that starts a step (fused k_colx16, or k_col_fwd), 1 = k_row, 2 = k_col_inv,
  * 3 = step control / row sums / read-backs.  Both arrays have 4 entries.                                         */
+/* Lock-step accounting of the last propagate (frames of a batch need different numbers of steps, fiber.m:518): the
+ * frame-steps that had work to do; the frame slots of the device's active list summed over the steps (what the
+ * workgroups iterated over: the list is rebuilt before every step, so this equals the first figure); the frame slots the
+ * host's launches covered (its view of the list lags by up to two chunks of 8 steps; surplus workgroups exit at once). */
+int plx_ssfm_utilisation(plx_ssfm *plan, int64_t *frame_steps, int64_t *slots_listed, int64_t *slots_launched);
 /* How the plan runs a step (for reports): info[0] 1 = fused column sweep (two sweeps per step), 0 = three sweeps;
  * [1] log2 N1, [2] log2 N2 of the four-step split; [3] grid of the fused sweep; [4] column tiles per frame;
  * [5] threads per column workgroup, [6] per row workgroup; [7] 1 = one polarisation per row workgroup.  8 entries. */

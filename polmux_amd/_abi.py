@@ -67,6 +67,7 @@ SIGNATURES = {
     "plx_ssfm_results": [_vp, C.c_int, _vp, _vp],
     "plx_ssfm_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
     "plx_ssfm_info": [_vp, _vp],
+    "plx_ssfm_utilisation": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
     "plx_ssfm_profile": [_vp, C.c_int],
     "plx_ssfm_kernel_times": [_vp, _vp, _vp],
     "plx_matrix_ssfm": [_vp, _vp, _vp, _vp, C.POINTER(SsfmDesc), _vp, _vp, _vp, C.POINTER(_dbl),

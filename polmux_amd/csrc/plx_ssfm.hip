@@ -64,6 +64,8 @@ struct SsfmArgs {
     FrameCtl *ctl;
     unsigned long long *umax;      // [F][nfc] bit pattern of max |u|^2 (>= 0)
     int *ndone;                    // [0] frames that have reached the fibre end, [1] sticky abort word (a frame barrier timed out)
+    const int *active;             // [nframes] frames still propagating, in frame order (k_compact); nullptr: all of them
+    int *nactive;                  // [0] length of the list, [1] running sum of it over the steps (utilisation accounting)
     long long spin_ticks;          // frame-barrier timeout in ticks of plx_clock() (10 ns)
     unsigned long long *slots;     // [F][tiles per frame] per-tile max |u|^2 of the current round (k_colx16), ~0 = not arrived
     unsigned long long *pubw;      // [F][2] published Leff (or -1: frame finished) of the round, by launch parity, ~0 = not yet
@@ -93,6 +95,16 @@ __device__ __forceinline__ double wave_max(double v)
 // Every kernel of the step loop returns at once when all frames of the call are done, or after a frame barrier of the
 // fused sweep has timed out (sticky: nothing is stored or advanced any more, the host reports the error).
 template <class ARGS> __device__ __forceinline__ bool all_done_or_aborted(const ARGS &a) { return a.ndone[0] >= a.nframes || a.ndone[1] != 0; }
+
+// Frames leave the step loop one by one (data-dependent trip count, fiber.m:518): the launches of a step cover the
+// frames of the ACTIVE list only.  slot -> frame; false when the slot lies beyond the list.
+__device__ __forceinline__ bool slot_frame(const SsfmArgs &a, int slot, int &f)
+{
+    if (!a.active) { f = slot; return slot < a.nframes; }
+    if (slot >= a.nactive[0]) return false;
+    f = a.active[slot];
+    return true;
+}
 
 // exp(i a) for the Kerr step.  The step controller bounds |a| by dphimax (fiber.m:699), a few
 // mrad, so the Taylor branch (|a| < 2^-4, truncation < 1e-25, ~1 ulp) is the one that runs;
@@ -302,6 +314,30 @@ __global__ void k_ctrl(SsfmArgs a, int nframes)
     ctrl_step<false>(a, f);
 }
 
+// The active list: frames that have not reached the fibre end, in frame order (one workgroup; a block scan over
+// contiguous chunks of frames).  Runs once per step, in front of the step's sweeps.
+__global__ __launch_bounds__(1024) void k_compact(const FrameCtl *ctl, int nframes, int *active, int *nactive)
+{
+    PLX_DYN_LDS(lds);
+    int *cnt = (int *)lds;                         // [1024]
+    const int tid = threadIdx.x, per = (nframes + 1023) / 1024;
+    const int f0 = tid * per, f1 = min(nframes, f0 + per);
+    int n = 0;
+    for (int f = f0; f < f1; f++) n += ctl[f].done ? 0 : 1;
+    cnt[tid] = n;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {           // inclusive scan
+        const int v = tid >= d ? cnt[tid - d] : 0;
+        __syncthreads();
+        cnt[tid] += v;
+        __syncthreads();
+    }
+    int o = cnt[tid] - n;
+    for (int f = f0; f < f1; f++)
+        if (!ctl[f].done) active[o++] = f;
+    if (tid == 1023) { nactive[0] = cnt[1023]; nactive[1] += cnt[1023]; }
+}
+
 // -------------------------------------------- adaptive scheme: element-wise pieces ---
 // nl_step (fiber.m:776-804) followed by the attenuation of the half/quarter step (:973,:979,...), scalar fields.
 __global__ __launch_bounds__(256) void k_nl_att(cplx *u, const double *gam, size_t N, int nfc, int spm, int xpm,
@@ -378,7 +414,10 @@ __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_fwd(SsfmArgs a)
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
+    const int slot = blockIdx.y / a.nfc, c = blockIdx.y - slot * a.nfc;
+    int f;
+    if (!slot_frame(a, slot, f)) return;
+    const int fc = f * a.nfc + c;
     const FrameCtl *ctl = a.ctl + f;
     if (ctl->done) return;
     const int N1 = 1 << a.p1, N2 = 1 << a.p2, T = a.T, W = a.W;
@@ -512,7 +551,10 @@ template <bool TWC> __global__ __launch_bounds__(1024) void k_row_t(SsfmArgs a)
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int fc = blockIdx.y, f = fc / a.nfc, c = fc - f * a.nfc;
+    const int slot = blockIdx.y / a.nfc, c = blockIdx.y - slot * a.nfc;
+    int f;
+    if (!slot_frame(a, slot, f)) return;
+    const int fc = f * a.nfc + c;
     const FrameCtl *ctl = a.ctl + f;
     if (ctl->done) return;
     const int N2 = 1 << a.p2, R = a.R, TSp = row_pitch(N2);
@@ -646,7 +688,10 @@ __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_inv(SsfmArgs a)
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int fc = blockIdx.y, f = fc / a.nfc;
+    const int slot = blockIdx.y / a.nfc;
+    int f;
+    if (!slot_frame(a, slot, f)) return;
+    const int fc = f * a.nfc + (blockIdx.y - slot * a.nfc);
     const FrameCtl *ctl = a.ctl + f;
     if (ctl->done) return;
     const int N1 = 1 << a.p1, N2 = 1 << a.p2, T = a.T, W = a.W;
@@ -750,7 +795,7 @@ __device__ __forceinline__ void glds16(const cplx *src, cplx *lds_wave_base, int
 __device__ __forceinline__ void glds_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 
-__global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf, int total)
+__global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf)
 {
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
@@ -767,13 +812,14 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     const int lane = tid & 63, row0 = (tid >> 6) * 64;     // this wave stages rows row0 .. row0+63
     // stage(tl, live): start the asynchronous copy of tile tl into s (live: the tile exists and its frame is still
     // running -- read by the caller ahead of time, so that no load sits between the decision and the copy)
-    auto frame_live = [&](int tl) -> int {
-        if (tl >= total) return 0;
-        return a.ctl[(tl / tiles_x) / a.nfc].done ? 0 : 1;
-    };
+    // tile tl = (slot of the active list, tile of the frame): every listed frame is live for the whole launch (a frame's
+    // flag cannot change before THIS workgroup has met its barrier), so no control word is read to decide
+    const int total = a.nactive[0] * tiles_pf;
+    auto frame_live = [&](int tl) -> int { return tl < total ? 1 : 0; };
     auto stage = [&](int tl, int live) -> bool {
         if (!live) return false;
-        const int fc = tl / tiles_x, bx = tl - fc * tiles_x;
+        const int slot = tl / tiles_pf, ti = tl - slot * tiles_pf;
+        const int fc = a.active[slot] * a.nfc + ti / tiles_x, bx = ti % tiles_x;
         // (lane & 15 == t: the lane stages a piece of the same column of the same polarisation it later works on)
         const cplx *src = fld + ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt + (size_t)(row0 + (lane >> 4)) * N2;
 #pragma unroll
@@ -785,13 +831,14 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     __syncthreads();                       // twiddles staged
     while (tl < total) {
         const int nxt = tl + gridDim.x;
-        const int fc = tl / tiles_x, bx = tl - fc * tiles_x, f = fc / a.nfc, c = fc - f * a.nfc;
-        int nxt_live = frame_live(nxt);    // (a frame's flag cannot change before THIS workgroup has met its barrier)
+        const int slot = tl / tiles_pf, ti = tl - slot * tiles_pf;
+        const int f = a.active[slot], c = ti / tiles_x, bx = ti - c * tiles_x, fc = f * a.nfc + c;
+        int nxt_live = frame_live(nxt);
         if (!cur) { cur = stage(nxt, nxt_live); tl = nxt; continue; }   // (s is free here: every path below ends past its last read of s)
         const size_t cbase = ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt;
         const bool started = a.ctl[f].started != 0;
         // the frame's leader takes the step-control record along now: at barrier time it is one LDS read away
-        if (tid == 0 && tl % tiles_pf == 0) *lctl = a.ctl[f];
+        if (tid == 0 && ti == 0) *lctl = a.ctl[f];
         glds_landed();                     // this wave's own rows of the tile are in LDS
         pin(nxt_live);
         {
@@ -832,7 +879,6 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         // tile) polls the slots with a whole wave, runs the step controller and publishes Leff (or -1: finished) in
         // the word of this launch's parity, having reset the slots and the other parity's word for the next round.
         {
-            const int ti = tl % tiles_pf;
             const unsigned par = (unsigned)a.round & 1u;
             unsigned long long *slots = a.slots + (size_t)f * tiles_pf;
             unsigned long long *pubw = a.pubw + 2 * (size_t)f;
@@ -978,8 +1024,9 @@ struct plx_ssfm {
     cplx *d_tpass = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
     FrameCtl *d_ctl = nullptr;
     unsigned long long *d_umax = nullptr;
-    int *d_ndone = nullptr;   // [0] frames done, [1] abort word
-    int *h_ndone = nullptr;   // pinned copy of the two words
+    int *d_ndone = nullptr;   // [0] frames done, [1] abort word, [2] frames in the active list, [3] its running sum over the steps
+    int *h_ndone = nullptr;   // pinned copy of the four words
+    int *d_active = nullptr;  // [max_frames] active list (k_compact)
     hipEvent_t ev = nullptr;  // completion of the last read-back of d_ndone
     std::vector<FrameCtl> h_ctl;
     int brf_sets = 0;
@@ -995,6 +1042,7 @@ struct plx_ssfm {
     hipEvent_t brf_ev[2] = {nullptr, nullptr};
     int brf_slot = 0;
     int64_t row_launches = 0, sample_steps = 0;
+    int64_t slots_launched = 0, slots_listed = 0, frame_steps = 0;   // utilisation accounting of the last propagate
     // optional per-kernel timing of the step loop (plx_ssfm_profile): one event between consecutive launches
     int profile = 0;
     std::vector<hipEvent_t> evpool;
@@ -1017,7 +1065,7 @@ static void free_plan(plx_ssfm *P)
     if (!P) return;
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
-    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_pubw);
+    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_pubw); hipFree(P->d_active);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     if (P->ev) hipEventDestroy(P->ev);
     for (hipEvent_t e : P->evpool) hipEventDestroy(e);
@@ -1214,6 +1262,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     bool ok = hipMalloc((void **)&P->d_ctl, sizeof(FrameCtl) * F) == hipSuccess &&
               hipMalloc((void **)&P->d_umax, sizeof(unsigned long long) * F * nfc) == hipSuccess &&
               hipMalloc((void **)&P->d_ndone, 64) == hipSuccess &&
+              hipMalloc((void **)&P->d_active, sizeof(int) * (size_t)F) == hipSuccess &&
               hipHostMalloc((void **)&P->h_ndone, 64, hipHostMallocDefault) == hipSuccess &&
               hipEventCreateWithFlags(&P->ev, hipEventDisableTiming) == hipSuccess;
     if (ok && !a.dual && a.xpm) ok = hipMalloc((void **)&P->d_psum, sizeof(double) * (size_t)F * N) == hipSuccess;
@@ -1363,11 +1412,14 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     a.ux = (cplx *)d_ux;
     a.uy = (cplx *)d_uy;
     a.nframes = nframes;
+    a.active = P->d_active;
+    a.nactive = P->d_ndone + 2;
     const int nfc = a.nfc, N1 = 1 << a.p1, N2 = 1 << a.p2;
-    const unsigned FC = (unsigned)nframes * nfc;
+    unsigned FC = (unsigned)nframes * nfc;      // frame-channels launched: shrinks with the host's (lagging) view of the active list
     PLX_HIP(hipMemsetAsync(P->d_ctl, 0, sizeof(FrameCtl) * nframes, st));
     PLX_HIP(hipMemsetAsync(P->d_umax, 0, sizeof(unsigned long long) * FC, st));
     PLX_HIP(hipMemsetAsync(P->d_ndone, 0, 64, st));
+    P->slots_launched = 0;
     const bool fused = P->fused != 0;
     if (fused) { // the first fused launch also forms nextstep's initial maximum
         PLX_HIP(hipMemsetAsync(P->d_slots, 0xFF, sizeof(unsigned long long) * (size_t)nframes * P->tiles_pf, st));   // ~0 = "not arrived"
@@ -1377,13 +1429,15 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
         if (gx > 64) gx = 64;
         PLX_LAUNCH(k_umax, dim3(gx, FC), dim3(256), 16 * sizeof(double), st, a);
     }
-    const dim3 gcol((unsigned)(N2 / a.W), FC), grow((unsigned)(N1 / a.R), FC), blk(256);
+    const dim3 blk(256);
     const dim3 gctl((unsigned)((nframes + 63) / 64)), bctl(64);
     const dim3 bcol((unsigned)P->col_threads);
     const int rowthr = P->row_threads;
     P->row_launches = 0;
     // Data-dependent trip count (fiber.m:518): steps are enqueued in chunks; the completed-frame counter and the
     // abort word of chunk k are read back while chunk k+1 executes.
+    // The sweeps of a step cover the frames of the active list (k_compact, once per step); their grids follow the
+    // host's last read-back of its length, an upper bound (frames only ever leave), workgroups beyond the list exit.
     int chunk = 4, steps = 0;
     const int kMaxSteps = 1 << 22;
     bool pending = false, aborted = false;
@@ -1405,16 +1459,20 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
 #define PLX_MARK(cls, step) do { int rc_ = mark((cls), (step)); if (rc_) return rc_; } while (0)
     for (;;) {
         for (int sidx = 0; sidx < chunk; sidx++) {
+            const dim3 gcol((unsigned)(N2 / a.W), FC);
+            P->slots_launched += FC / nfc;
             if (fused) {
                 const int tcx = (int)gcol.x, tct = (int)(gcol.x * FC);
                 const dim3 gx((unsigned)(tct < P->fused_grid ? tct : P->fused_grid));
+                PLX_MARK(3, steps + sidx);
+                PLX_LAUNCH(k_compact, dim3(1), dim3(1024), 1024 * sizeof(int), st, (const FrameCtl *)P->d_ctl, nframes, P->d_active, P->d_ndone + 2);
 #ifdef PLX_EMU
                 // the emulator must keep one frame's workgroups alive together (PLX_EMU_STARVE: a test starves the barrier)
                 emu::g_concurrency = getenv("PLX_EMU_STARVE") ? 1 : P->tiles_pf;
 #endif
                 a.round = steps + sidx;
                 PLX_MARK(0, steps + sidx);
-                PLX_LAUNCH(k_colx16, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf, tct);
+                PLX_LAUNCH(k_colx16, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
 #endif
@@ -1425,6 +1483,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
             }
             PLX_MARK(3, steps + sidx);
             PLX_LAUNCH(k_ctrl, gctl, bctl, 0, st, a, nframes);
+            PLX_LAUNCH(k_compact, dim3(1), dim3(1024), 1024 * sizeof(int), st, (const FrameCtl *)P->d_ctl, nframes, P->d_active, P->d_ndone + 2);
             if (!a.dual && a.xpm) {
                 unsigned gx = (unsigned)((P->N + 255) / 256);
                 if (gx > 256) gx = 256;
@@ -1444,23 +1503,28 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
             PLX_HIP(hipEventSynchronize(P->ev));
             if (P->h_ndone[1]) { aborted = true; break; }
             if (P->h_ndone[0] >= nframes) break;
+            const unsigned live = (unsigned)(nframes - P->h_ndone[0]) * nfc;   // as of the previous chunk: an upper bound
+            if (live < FC) FC = live;
         }
-        PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         PLX_HIP(hipEventRecord(P->ev, st));
         pending = true;
-        if (chunk < 16) chunk *= 2;
+        if (chunk < 8) chunk *= 2;
         if (steps > kMaxSteps) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate");
     }
     PLX_HIP(hipMemcpyAsync(P->h_ctl.data(), P->d_ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost, st));
-    PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     PLX_HIP(hipStreamSynchronize(st));
+    P->slots_listed = P->h_ndone[3];
     if (aborted || P->h_ndone[1])
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: frame barrier timed out (the workgroups of a frame were not co-resident: "
                               "another kernel holds the GPU); nothing was stored after the timeout -- create the plan with "
                               "PLX_SSFM_NO_FUSE=1 to share the device");
     P->sample_steps = 0;
+    P->frame_steps = 0;
     int maxnc = 0;
     for (int f = 0; f < nframes; f++) {
+        P->frame_steps += P->h_ctl[f].ncycle + (fused ? 1 : 0);   // (the fused sweep's last round writes the field out)
         if (!P->h_ctl[f].done) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: a frame did not reach the fibre end");
         P->sample_steps += (int64_t)P->h_ctl[f].ncycle * (int64_t)P->N * nfc;
         if (P->h_ctl[f].ncycle > maxnc) maxnc = P->h_ctl[f].ncycle;
@@ -1482,6 +1546,15 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     }
 #undef PLX_MARK
     PLX_HIP(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_utilisation(plx_ssfm *P, int64_t *frame_steps, int64_t *slots_listed, int64_t *slots_launched)
+{
+    if (!P) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_utilisation: null plan");
+    if (frame_steps) *frame_steps = P->frame_steps;
+    if (slots_listed) *slots_listed = P->slots_listed;
+    if (slots_launched) *slots_launched = P->slots_launched;
     return PLX_OK;
 }
 

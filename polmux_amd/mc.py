@@ -225,15 +225,39 @@ class ShardedBer:
         return None, 0, 1
 
     def run(self, max_realisations=1 << 30):
+        """Rounds of per_rank_per_round realisations per rank until the reference's stop rule fires.  When the simulator
+        offers launch()/collect() (pipeline.McCampaign) the NEXT round is already enqueued while this round's counts are
+        reduced and replayed: a round computed past the stop is simply discarded, the statistics are unchanged."""
         import torch
         dist, rank, world = self._dist()
+        sim = self.simulate
+        owner = getattr(sim, "__self__", None)
+        launch = getattr(owner, "launch", None) if owner is not None and getattr(sim, "__name__", "") == "simulate" else None
+        collect = getattr(owner, "collect", None) if launch is not None else None
+
+        def plan(start):
+            n_round = min(self.w * world, max_realisations - start)
+            return n_round, shard_indices(start, n_round, rank, world)
+
         start = 0
         result = None
         cond = True
+        pending = None          # (start, n_round, mine, handle) of the round in flight
+        if launch is not None and start < max_realisations:
+            n_round, mine = plan(start)
+            pending = (start, n_round, mine, launch(mine) if mine else None)
         while cond and start < max_realisations:
-            n_round = min(self.w * world, max_realisations - start)
-            mine = shard_indices(start, n_round, rank, world)
-            local = np.asarray(self.simulate(mine), dtype=np.int64) if mine else np.zeros(0, np.int64)
+            if launch is not None:
+                start, n_round, mine, handle = pending
+                nxt = start + n_round
+                pending = None
+                if nxt < max_realisations:          # speculative: enqueue the next round before looking at this one
+                    n2, m2 = plan(nxt)
+                    pending = (nxt, n2, m2, launch(m2) if m2 else None)
+                local = np.asarray(collect(handle), dtype=np.int64) if mine else np.zeros(0, np.int64)
+            else:
+                n_round, mine = plan(start)
+                local = np.asarray(sim(mine), dtype=np.int64) if mine else np.zeros(0, np.int64)
             # one exchange step: every rank contributes its slots of the round's count vector
             vec = torch.zeros(n_round, dtype=torch.int64, device=self.device or "cpu")
             if mine:
@@ -251,4 +275,6 @@ class ShardedBer:
                     cond = False
                     break
             start += n_round
+        if pending is not None and pending[3] is not None:   # a speculative round past the stop: wait for it, drop it
+            collect(pending[3])
         return result

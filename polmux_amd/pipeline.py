@@ -360,6 +360,13 @@ class HotPath:
         self.lib.call("plx_ssfm_results", self.ssfm, F, None, nc.ctypes.data)
         return nc
 
+    def utilisation(self):
+        """(frame-steps with work, frame slots of the device's active list, frame slots the launches covered) of the last
+        propagate call"""
+        v = [C.c_int64(), C.c_int64(), C.c_int64()]
+        self.lib.call("plx_ssfm_utilisation", self.ssfm, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
+
     def fused(self):
         info = (C.c_int32 * 8)()
         self.lib.call("plx_ssfm_info", self.ssfm, info)
@@ -385,18 +392,21 @@ class McCampaign:
         self.F = frames_per_call
         self.sigma = noise_sigma
         self.noise_provider = noise_provider
-        self.last = None          # (indices, ncycle) of the last simulate() call, for tests
+        self._rx_stream = None
 
     @property
     def bits_per_realisation(self):
         return 4 * self.hp.cfg.nsymb
 
-    def simulate(self, indices, keep=None):
-        """Error counts (pol swap and pi/2 ambiguities resolved, ex20_coherent_polmux.m:160-173) of the realisations
-        `indices`.  keep(i0, idx, ux, uy): optional callback after the fibre + amplifier of each batch (tests read the
-        field back there)."""
+    def launch(self, indices, keep=None):
+        """Enqueue the realisations `indices` and return a handle WITHOUT waiting for the receiver: the fibre runs on the
+        current stream (plx_ssfm_propagate_dev returns when its data-dependent step loop has ended), the receiver and the
+        error counts go to a second stream, so the receiver of this batch overlaps the fibre of the next one (the CMA is
+        latency-bound: ~25 ms whatever the batch size).  collect(handle) -> int64 error counts."""
         import torch
         hp = self.hp
+        if self._rx_stream is None:
+            self._rx_stream = torch.cuda.Stream()
         out = []
         for i0 in range(0, len(indices), self.F):
             idx = list(indices[i0:i0 + self.F])
@@ -410,9 +420,20 @@ class McCampaign:
             hp.fibre(ux, uy, span_keys=idx, inject_noise=inj)
             if keep is not None:
                 keep(i0, idx, ux, uy)
-            hp.receive(ux, uy, self.sigma, 20260101, None, idx)   # receiver noise keyed by realisation index
-            out.append(hp.errors_resolved(n).cpu().numpy())
-        return np.concatenate(out) if out else np.zeros(0, np.int64)
+            hp.receive(ux, uy, self.sigma, 20260101, self._rx_stream, idx)   # receiver noise keyed by realisation index
+            with torch.cuda.stream(self._rx_stream):
+                out.append(hp.errors_resolved(n))
+                ux.record_stream(self._rx_stream); uy.record_stream(self._rx_stream)
+        return out
+
+    def collect(self, handle):
+        return np.concatenate([h.cpu().numpy() for h in handle]) if handle else np.zeros(0, np.int64)
+
+    def simulate(self, indices, keep=None):
+        """Error counts (pol swap and pi/2 ambiguities resolved, ex20_coherent_polmux.m:160-173) of the realisations
+        `indices`.  keep(i0, idx, ux, uy): optional callback after the fibre + amplifier of each batch (tests read the
+        field back there)."""
+        return self.collect(self.launch(indices, keep))
 
     def close(self):
         self.hp.close()

@@ -82,3 +82,111 @@ def test_shard_indices():
     assert shard_indices(0, 8, 1, 4) == [1, 5]
     assert shard_indices(8, 8, 0, 4) == [8, 12]
     assert sum(len(shard_indices(0, 1024, r, 8)) for r in range(8)) == 1024
+
+
+class _FakeCampaign:
+    """the launch()/collect() face of pipeline.McCampaign (the next round is enqueued before the current one is read)"""
+
+    def __init__(self):
+        self.launched = []
+
+    def launch(self, idx):
+        self.launched.append(list(idx))
+        return list(idx)
+
+    def collect(self, handle):
+        return _errors_of(handle)
+
+    def simulate(self, idx):
+        return self.collect(self.launch(idx))
+
+
+def test_pipelined_rounds_give_the_sequential_statistics():
+    """With a simulator that offers launch()/collect(), ShardedBer enqueues round k+1 before it reduces round k; the round
+    computed past the stop is discarded: avgber / nruns / stdber still equal the one-realisation-at-a-time loop bit for bit."""
+    sys.path.insert(0, ROOT)
+    from polmux_amd import mc
+    x = dict(stop=(0.05, 95), nmin=10)
+    ref, nseq = _sequential(x, 4096.0, 5000)
+    camp = _FakeCampaign()
+    runner = mc.ShardedBer(camp.simulate, 4096, x, per_rank_per_round=4)
+    res = runner.run(max_realisations=5000)
+    assert len(runner.counts) == nseq
+    for got, want in zip(res, ref):
+        np.testing.assert_array_equal(np.asarray(got, dtype=float), np.asarray(want, dtype=float))
+    assert len(camp.launched) == runner.rounds + 1                 # exactly one speculative round beyond the stop
+    # a campaign that ends on max_realisations has no speculative round left over
+    camp2 = _FakeCampaign()
+    r2 = mc.ShardedBer(camp2.simulate, 4096, dict(stop=(1e-9, 95), nmin=10), per_rank_per_round=4)
+    r2.run(max_realisations=12)
+    assert len(r2.counts) == 12 and len(camp2.launched) == 3
+
+
+def _gpu_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PLX_SSFM_NO_FUSE"] = "1"       # the ranks of this rehearsal share ONE GPU: barrier-free sweeps
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from polmux_amd import mc, pipeline
+    torch.cuda.set_device(0)
+    cfg = pipeline.HotPathConfig(nsymb=256, nt=16, flag="gps-", nplates=10, dgd=0.2, length=4e4, pavg_mw=1.0, cma_mu=1 / 600,
+                                 freqavg=50, dphimax=2e-2)
+    camp = pipeline.McCampaign(cfg, frames_per_call=4, noise_sigma=0.28)
+    runner = mc.ShardedBer(camp.simulate, camp.bits_per_realisation, dict(stop=(0.5, 68), nmin=20), per_rank_per_round=4)
+    res = runner.run(max_realisations=64)
+    q.put((rank, [np.asarray(v, dtype=float).tolist() for v in res], list(runner.counts)))
+    camp.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_real_campaign_on_two_ranks_equals_one_rank():
+    """The real McCampaign (random PMD + noise keyed by the realisation index) sharded over two ranks -- both on cuda:0,
+    collectives over gloo: the rehearsal form of the N-GPU run -- gives the one-rank campaign's counts and statistics
+    bit for bit."""
+    ctx = mp.get_context("spawn")
+    outs = {}
+    for world in (1, 2):
+        q = ctx.Queue()
+        port = 29500 + (os.getpid() + 13 * world) % 2000
+        procs = [ctx.Process(target=_gpu_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = [q.get(timeout=300) for _ in range(world)]
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        outs[world] = got
+    ref = outs[1][0]
+    for rank, res, counts in outs[2]:
+        assert counts == ref[2]
+        for a, b in zip(res, ref[1]):
+            np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+    assert len(ref[2]) >= 8 and sum(ref[2]) > 0
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`bench.py --gpus 2` with no launcher around it starts two ranks itself (fresh child processes, before any GPU call);
+    on this one-GPU box as a rehearsal (both on cuda:0, gloo).  One JSON line, n_gpus 2, frames of both ranks counted, the
+    Monte-Carlo leg through ShardedBer with its all-reduce."""
+    import json
+    import subprocess
+    env = dict(os.environ, PLX_BENCH_REHEARSAL="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--frames", "8",
+                          "--nsymb", "256", "--nt", "32", "--variants", "2", "--mc-rounds", "2", "--mc-frames", "4", "--no-cpu-baseline",
+                          "--no-single-frame"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rehearsal_all_ranks_on_one_gpu"] is True
+    assert d["config"]["bits"] == 2 * 8 * 4 * 256
+    assert d["mc"]["realisations"] == 2 * 2 * 4 and d["mc"]["rounds"] == 2 and "gloo" in d["mc"]["exchange"]
+    # without a rehearsal switch and without that many devices it refuses instead of silently running on one GPU
+    env.pop("PLX_BENCH_REHEARSAL")
+    if torch.cuda.device_count() < 2:
+        bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+        assert bad.returncode != 0 and "device(s) visible" in bad.stderr
