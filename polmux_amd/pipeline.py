@@ -422,12 +422,19 @@ class McCampaign:
                 keep(i0, idx, ux, uy)
             hp.receive(ux, uy, self.sigma, 20260101, self._rx_stream, idx)   # receiver noise keyed by realisation index
             with torch.cuda.stream(self._rx_stream):
-                out.append(hp.errors_resolved(n))
+                e = hp.errors_resolved(n)
                 ux.record_stream(self._rx_stream); uy.record_stream(self._rx_stream)
+                done = torch.cuda.Event()
+                done.record(self._rx_stream)
+            out.append((e, done))
         return out
 
     def collect(self, handle):
-        return np.concatenate([h.cpu().numpy() for h in handle]) if handle else np.zeros(0, np.int64)
+        res = []
+        for e, done in handle or []:
+            done.synchronize()             # the counts were formed on the receiver's stream
+            res.append(e.cpu().numpy())
+        return np.concatenate(res) if res else np.zeros(0, np.int64)
 
     def simulate(self, indices, keep=None):
         """Error counts (pol swap and pi/2 ambiguities resolved, ex20_coherent_polmux.m:160-173) of the realisations
