@@ -133,7 +133,7 @@ def _gpu_worker(rank, world, port, q):
     cfg = pipeline.HotPathConfig(nsymb=256, nt=16, flag="gps-", nplates=10, dgd=0.2, length=4e4, pavg_mw=1.0, cma_mu=1 / 600,
                                  freqavg=50, dphimax=2e-2)
     camp = pipeline.McCampaign(cfg, frames_per_call=4, noise_sigma=0.28)
-    runner = mc.ShardedBer(camp.simulate, camp.bits_per_realisation, dict(stop=(0.3, 95), nmin=50), per_rank_per_round=4)
+    runner = mc.ShardedBer(camp.simulate, camp.bits_per_realisation, dict(stop=(0.01, 99), nmin=50), per_rank_per_round=4)
     res = runner.run(max_realisations=48)
     q.put((rank, [np.asarray(v, dtype=float).tolist() for v in res], list(runner.counts)))
     camp.close()
@@ -163,7 +163,7 @@ def test_real_campaign_on_two_ranks_equals_one_rank():
         assert counts == ref[2]
         for a, b in zip(res, ref[1]):
             np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
-    assert len(ref[2]) >= 8 and len(ref[2]) % 8 in (0, 1, 2, 3, 4, 5, 6, 7) and sum(ref[2]) > 0
+    assert len(ref[2]) >= 8 and sum(ref[2]) > 0
 
 
 @pytest.mark.gpu
