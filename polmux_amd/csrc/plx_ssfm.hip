@@ -316,7 +316,8 @@ __global__ void k_ctrl(SsfmArgs a, int nframes)
 
 // The active list: frames that have not reached the fibre end, in frame order (one workgroup; a block scan over
 // contiguous chunks of frames).  Runs once per step, in front of the step's sweeps.
-__global__ __launch_bounds__(1024) void k_compact(const FrameCtl *ctl, int nframes, int *active, int *nactive)
+// `serves`: the number of steps this list will be used for (utilisation accounting).
+__global__ __launch_bounds__(1024) void k_compact(const FrameCtl *ctl, int nframes, int *active, int *nactive, int serves)
 {
     PLX_DYN_LDS(lds);
     int *cnt = (int *)lds;                         // [1024]
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(1024) void k_compact(const FrameCtl *ctl, int nfram
     int o = cnt[tid] - n;
     for (int f = f0; f < f1; f++)
         if (!ctl[f].done) active[o++] = f;
-    if (tid == 1023) { nactive[0] = cnt[1023]; nactive[1] += cnt[1023]; }
+    if (tid == 1023) { nactive[0] = cnt[1023]; nactive[1] += cnt[1023] * serves; }
 }
 
 // -------------------------------------------- adaptive scheme: element-wise pieces ---
@@ -812,10 +813,14 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     const int lane = tid & 63, row0 = (tid >> 6) * 64;     // this wave stages rows row0 .. row0+63
     // stage(tl, live): start the asynchronous copy of tile tl into s (live: the tile exists and its frame is still
     // running -- read by the caller ahead of time, so that no load sits between the decision and the copy)
-    // tile tl = (slot of the active list, tile of the frame): every listed frame is live for the whole launch (a frame's
-    // flag cannot change before THIS workgroup has met its barrier), so no control word is read to decide
+    // tile tl = (slot of the active list, tile of the frame).  The list may be a few steps old (small batches rebuild it
+    // once per chunk of steps), so a listed frame is still checked; its flag cannot change before THIS workgroup has met
+    // the frame's barrier, and the check for the next tile is read one tile ahead
     const int total = a.nactive[0] * tiles_pf;
-    auto frame_live = [&](int tl) -> int { return tl < total ? 1 : 0; };
+    auto frame_live = [&](int tl) -> int {
+        if (tl >= total) return 0;
+        return a.ctl[a.active[tl / tiles_pf]].done ? 0 : 1;
+    };
     auto stage = [&](int tl, int live) -> bool {
         if (!live) return false;
         const int slot = tl / tiles_pf, ti = tl - slot * tiles_pf;
@@ -1438,6 +1443,9 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     // abort word of chunk k are read back while chunk k+1 executes.
     // The sweeps of a step cover the frames of the active list (k_compact, once per step); their grids follow the
     // host's last read-back of its length, an upper bound (frames only ever leave), workgroups beyond the list exit.
+    // (the list is rebuilt before every step for batches of 64 frames and more, once per chunk for small ones, whose
+    // steps are launch-bound: the sweeps skip a listed frame that has finished meanwhile)
+    const bool compact_every_step = nframes >= 64;
     int chunk = 4, steps = 0;
     const int kMaxSteps = 1 << 22;
     bool pending = false, aborted = false;
@@ -1464,8 +1472,11 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
             if (fused) {
                 const int tcx = (int)gcol.x, tct = (int)(gcol.x * FC);
                 const dim3 gx((unsigned)(tct < P->fused_grid ? tct : P->fused_grid));
-                PLX_MARK(3, steps + sidx);
-                PLX_LAUNCH(k_compact, dim3(1), dim3(1024), 1024 * sizeof(int), st, (const FrameCtl *)P->d_ctl, nframes, P->d_active, P->d_ndone + 2);
+                if (compact_every_step || sidx == 0) {
+                    PLX_MARK(3, steps + sidx);
+                    PLX_LAUNCH(k_compact, dim3(1), dim3(1024), 1024 * sizeof(int), st, (const FrameCtl *)P->d_ctl, nframes, P->d_active, P->d_ndone + 2,
+                               compact_every_step ? 1 : chunk);
+                }
 #ifdef PLX_EMU
                 // the emulator must keep one frame's workgroups alive together (PLX_EMU_STARVE: a test starves the barrier)
                 emu::g_concurrency = getenv("PLX_EMU_STARVE") ? 1 : P->tiles_pf;
@@ -1483,7 +1494,9 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
             }
             PLX_MARK(3, steps + sidx);
             PLX_LAUNCH(k_ctrl, gctl, bctl, 0, st, a, nframes);
-            PLX_LAUNCH(k_compact, dim3(1), dim3(1024), 1024 * sizeof(int), st, (const FrameCtl *)P->d_ctl, nframes, P->d_active, P->d_ndone + 2);
+            if (compact_every_step || sidx == 0)
+                PLX_LAUNCH(k_compact, dim3(1), dim3(1024), 1024 * sizeof(int), st, (const FrameCtl *)P->d_ctl, nframes, P->d_active, P->d_ndone + 2,
+                               compact_every_step ? 1 : chunk);
             if (!a.dual && a.xpm) {
                 unsigned gx = (unsigned)((P->N + 255) / 256);
                 if (gx > 256) gx = 256;
