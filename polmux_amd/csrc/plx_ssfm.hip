@@ -317,17 +317,18 @@ __global__ void k_ctrl(SsfmArgs a, int nframes)
 // The active list: frames that have not reached the fibre end, in frame order (one workgroup; a block scan over
 // contiguous chunks of frames).  Runs once per step, in front of the step's sweeps.
 // `serves`: the number of steps this list will be used for (utilisation accounting).
-__global__ __launch_bounds__(1024) void k_compact(const FrameCtl *ctl, int nframes, int *active, int *nactive, int serves)
+#define COMPACT_THREADS 256
+__global__ __launch_bounds__(COMPACT_THREADS) void k_compact(const FrameCtl *ctl, int nframes, int *active, int *nactive, int serves)
 {
     PLX_DYN_LDS(lds);
-    int *cnt = (int *)lds;                         // [1024]
-    const int tid = threadIdx.x, per = (nframes + 1023) / 1024;
+    int *cnt = (int *)lds;                         // [COMPACT_THREADS]
+    const int tid = threadIdx.x, per = (nframes + COMPACT_THREADS - 1) / COMPACT_THREADS;
     const int f0 = tid * per, f1 = min(nframes, f0 + per);
     int n = 0;
     for (int f = f0; f < f1; f++) n += ctl[f].done ? 0 : 1;
     cnt[tid] = n;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {           // inclusive scan
+    for (int d = 1; d < COMPACT_THREADS; d <<= 1) { // inclusive scan
         const int v = tid >= d ? cnt[tid - d] : 0;
         __syncthreads();
         cnt[tid] += v;
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(1024) void k_compact(const FrameCtl *ctl, int nfram
     int o = cnt[tid] - n;
     for (int f = f0; f < f1; f++)
         if (!ctl[f].done) active[o++] = f;
-    if (tid == 1023) { nactive[0] = cnt[1023]; nactive[1] += cnt[1023] * serves; }
+    if (tid == COMPACT_THREADS - 1) { nactive[0] = cnt[tid]; nactive[1] += cnt[tid] * serves; }
 }
 
 // -------------------------------------------- adaptive scheme: element-wise pieces ---
@@ -1474,7 +1475,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
                 const dim3 gx((unsigned)(tct < P->fused_grid ? tct : P->fused_grid));
                 if (compact_every_step || sidx == 0) {
                     PLX_MARK(3, steps + sidx);
-                    PLX_LAUNCH(k_compact, dim3(1), dim3(1024), 1024 * sizeof(int), st, (const FrameCtl *)P->d_ctl, nframes, P->d_active, P->d_ndone + 2,
+                    PLX_LAUNCH(k_compact, dim3(1), dim3(COMPACT_THREADS), COMPACT_THREADS * sizeof(int), st, (const FrameCtl *)P->d_ctl, nframes, P->d_active, P->d_ndone + 2,
                                compact_every_step ? 1 : chunk);
                 }
 #ifdef PLX_EMU
@@ -1495,7 +1496,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
             PLX_MARK(3, steps + sidx);
             PLX_LAUNCH(k_ctrl, gctl, bctl, 0, st, a, nframes);
             if (compact_every_step || sidx == 0)
-                PLX_LAUNCH(k_compact, dim3(1), dim3(1024), 1024 * sizeof(int), st, (const FrameCtl *)P->d_ctl, nframes, P->d_active, P->d_ndone + 2,
+                PLX_LAUNCH(k_compact, dim3(1), dim3(COMPACT_THREADS), COMPACT_THREADS * sizeof(int), st, (const FrameCtl *)P->d_ctl, nframes, P->d_active, P->d_ndone + 2,
                                compact_every_step ? 1 : chunk);
             if (!a.dual && a.xpm) {
                 unsigned gx = (unsigned)((P->N + 255) / 256);

@@ -325,19 +325,23 @@ def test_emu_sweep_variants(emu, oracle, monkeypatch):
 
 def test_emu_long_rows_compact_twiddles(emu, oracle, monkeypatch):
     """4096-point rows (the row pass of 2^20-sample frames: one polarisation per workgroup, compact twiddle table W^{4k} +
-    four fine factors, plx_fft.h row_tw) on a 16 x 4096 split of a 2^16 frame: field and step count against the oracle."""
-    n, nt, L = 65536, 64, 1.2e3
+    four fine factors, plx_fft.h row_tw) on a 4 x 4096 split of a 2^14 frame: field and step count against the oracle."""
+    n, nt, L = 16384, 64, 6e2                       # 4 x 4096 split, two steps
     fls = [1, 0, 1, 0]
     betat, db1 = _tables(n, nt, fls, 1)
     f = _qpsk_field(n, nt, 6.0)
-    monkeypatch.setenv("PLX_SSFM_P1", "4")
+    monkeypatch.setenv("PLX_SSFM_P1", "2")
+    monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")   # (fewer, wider column workgroups: fewer emulated threads)
+    monkeypatch.setenv("PLX_SSFM_LOGW", "6")
     d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=1)
     plan = C.c_void_p()
     emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
     monkeypatch.delenv("PLX_SSFM_P1")
+    monkeypatch.delenv("PLX_SSFM_COL_THREADS")
+    monkeypatch.delenv("PLX_SSFM_LOGW")
     info = (C.c_int32 * 8)()
     emu.call("plx_ssfm_info", plan, info)
-    assert list(info)[:3] == [0, 4, 12] and info[7] == 1          # three sweeps, 16 x 4096, one polarisation per row workgroup
+    assert list(info)[:3] == [0, 2, 12] and info[7] == 1          # three sweeps, 4 x 4096, one polarisation per row workgroup
     ux = _il(f[0][None]); uy = _il(f[1][None])
     emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 1, None)
     nc = np.zeros(1, np.int32)
