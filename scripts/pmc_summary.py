@@ -1,9 +1,19 @@
 """Summarise rocprofv3 --pmc counter_collection.csv: mean per ACTIVE dispatch of each counter, per kernel."""
-import csv, sys, collections
+import csv, sys, collections, re
+
+
+def kname(raw):
+    """kernel name without namespace, return type, template and argument lists: `void (anonymous namespace)::k_row_t<false>(...)` -> k_row"""
+    n = raw.replace("(anonymous namespace)::", "")
+    n = re.sub(r"^void\s+", "", n).split("(")[0]
+    n = re.sub(r"<.*$", "", n)
+    return "k_row" if n == "k_row_t" else n[:48]
+
+
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:40]
+    name = kname(r["Kernel_Name"])
     agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in agg.items():
     if not k.startswith("k_"): continue

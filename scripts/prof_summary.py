@@ -1,11 +1,20 @@
 """Summarise a rocprofv3 kernel_trace.csv: per-kernel totals, and for the SSFM kernels the average over
 ACTIVE launches (launches longer than 20 us; the chunked step loop also issues no-op launches)."""
-import csv, sys, collections
+import csv, sys, collections, re
+
+
+def kname(raw):
+    """kernel name without namespace, return type, template and argument lists: `void (anonymous namespace)::k_row_t<false>(...)` -> k_row"""
+    n = raw.replace("(anonymous namespace)::", "")
+    n = re.sub(r"^void\s+", "", n).split("(")[0]
+    n = re.sub(r"<.*$", "", n)
+    return "k_row" if n == "k_row_t" else n[:48]
+
+
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(list)
 for r in rows:
-    name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
-    name = name.split("(")[0][:48]
+    name = kname(r["Kernel_Name"])
     agg[name].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = sum(sum(v) for v in agg.values())
 print("| kernel | launches | total ms | active launches | avg active us | % of GPU time |")
