@@ -1,5 +1,5 @@
 """Summarise a rocprofv3 kernel_trace.csv: per-kernel totals, and for the SSFM kernels the average over
-ACTIVE launches (launches longer than 20 us; the chunked step loop also issues no-op launches)."""
+ACTIVE launches (at least half as long as the kernel's longest launch; the chunked step loop also issues no-op launches)."""
 import csv, sys, collections, re
 
 
@@ -20,5 +20,6 @@ tot = sum(sum(v) for v in agg.values())
 print("| kernel | launches | total ms | active launches | avg active us | % of GPU time |")
 print("|---|---|---|---|---|---|")
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-    act = [x for x in v if x > 20.0] or v
+    act = [x for x in v if x >= 0.5 * max(v)] or v     # active launches: at least half as long as the longest (the chunked
+                                                       # step loop also issues launches after every frame has finished)
     print("| `%s` | %d | %.2f | %d | %.1f | %.1f |" % (k, len(v), sum(v) / 1e3, len(act), sum(act) / len(act), 100 * sum(v) / tot))
