@@ -236,6 +236,11 @@ int plx_decide_count_dev(const double *d_sym, int64_t L, int32_t ncol, int nfram
 int plx_decide_count_frames_dev(const double *d_sym, int64_t L, int32_t ncol, int nframes, const uint8_t *d_pat,
                                 int64_t pat_frame_stride, uint8_t *d_pat_hat, int64_t *d_err, void *stream);
 
+/* per-frame error-vector magnitude of the recovered symbols, mean |s - s_hat|^2 with s_hat the unit-modulus QPSK point of
+ * the decided quadrant: one continuous sample per realisation for mc_estimate (mc_estimate.m:133-212), the way the error
+ * count above feeds ber_estimate.  d_sym [frame][ncol][L] complex; d_evm double [frame].                               */
+int plx_evm_dev(const double *d_sym, int64_t L, int32_t ncol, int nframes, double *d_evm, void *stream);
+
 /* ----------------------------------------------------------------- ampliflat --- */
 /* ampliflat(x,'gain',options), ampliflat.m:60-148 ("next" row): FIELD *= sqrt(gain) and
  * FIELD += sigma(c) * n with n complex Gaussian, E|Re n|^2 = E|Im n|^2 = 1.  sigma: host [nfc] (NULL/0 = no

@@ -90,6 +90,7 @@ SIGNATURES = {
     "plx_dsp_out_len": [_vp],
     "plx_decide_count_dev": [_vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _vp],
     "plx_decide_count_frames_dev": [_vp, _i64, _i32, C.c_int, _vp, _i64, _vp, _vp, _vp],
+    "plx_evm_dev": [_vp, _i64, _i32, C.c_int, _vp, _vp],
     "plx_ampliflat_dev": [_vp, _vp, _i64, _i32, C.c_int, _dbl, _vp, _vp, C.c_uint64, _vp, _i32, _i32, _vp],
     "plx_front_create": [C.POINTER(_vp), C.POINTER(FrontDesc)],
     "plx_front_destroy": [_vp],

@@ -716,6 +716,34 @@ __global__ __launch_bounds__(256) void k_decide(const cplx *sym, int64_t L, int 
     }
 }
 
+// Per-frame error-vector magnitude of the recovered symbols: mean over the frame's symbols (all columns) of
+// |s - s_hat|^2, s_hat the unit-modulus QPSK point of the quadrant samp2pat decides (samp2pat.m:61-66).  A continuous
+// per-realisation sample for mc_estimate (mc_estimate.m:133-212) beside the integer error count of ber_estimate.
+__global__ __launch_bounds__(256) void k_evm(const cplx *sym, int64_t L, int ncol, double *evm)
+{
+    PLX_DYN_LDS(lds);
+    double *red = (double *)lds;
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const size_t f = blockIdx.x;
+    const int64_t n = L * ncol;
+    double acc = 0;
+    for (int64_t i = tid; i < n; i += nthr) {
+        const cplx v = sym[f * (size_t)n + i];
+        const double hx = v.x >= 0 ? 0.70710678118654752440 : -0.70710678118654752440;
+        const double hy = v.y > 0 ? 0.70710678118654752440 : -0.70710678118654752440;
+        const double dx = v.x - hx, dy = v.y - hy;
+        acc += dx * dx + dy * dy;
+    }
+    for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = acc;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0;
+        for (int w = 0; w < (nthr + 63) / 64; w++) tot += red[w];
+        evm[f] = tot / (double)n;
+    }
+}
+
 int ilog2i(int64_t v)
 {
     int l = 0;
@@ -1142,6 +1170,14 @@ extern "C" int plx_decide_count_frames_dev(const double *d_sym, int64_t L, int32
     if (!d_sym || L < 1 || ncol < 1 || nframes < 1 || pat_frame_stride < 0) PLX_FAIL(PLX_ERR_ARG, "plx_decide_count_dev: bad argument");
     PLX_LAUNCH(k_decide, dim3((unsigned)(nframes * ncol)), dim3(256), 16 * sizeof(unsigned long long), stream,
                (const cplx *)d_sym, L, (int)ncol, d_pat, (size_t)pat_frame_stride, d_pat_hat, (unsigned long long *)d_err);
+    PLX_HIP(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_evm_dev(const double *d_sym, int64_t L, int32_t ncol, int nframes, double *d_evm, void *stream)
+{
+    if (!d_sym || !d_evm || L < 1 || ncol < 1 || nframes < 1) PLX_FAIL(PLX_ERR_ARG, "plx_evm_dev: bad argument");
+    PLX_LAUNCH(k_evm, dim3((unsigned)nframes), dim3(256), 16 * sizeof(double), stream, (const cplx *)d_sym, L, (int)ncol, d_evm);
     PLX_HIP(hipGetLastError());
     return PLX_OK;
 }

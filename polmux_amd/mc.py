@@ -207,7 +207,14 @@ class ShardedBer:
     simulate(indices) -> int64 array of error counts for those realisation indices (the
     device pipeline); bits_per_realisation = numel(pat).  One all_reduce(SUM) per round."""
 
-    def __init__(self, simulate, bits_per_realisation, x, per_rank_per_round=8, group=None, device=None):
+    def __init__(self, simulate, bits_per_realisation, x, per_rank_per_round=8, group=None, device=None, x_samples=None):
+        """x_samples: optional mc_estimate options (mc_estimate.m:104-131).  When given and the simulator's collect()
+        can return a continuous sample per realisation beside the error count (McCampaign: the EVM), every round's
+        sample vector is gathered the same way (one all-reduce of float64 slots) and fed to mc_estimate as one block
+        of M = round-size samples: `samples_result` = (cond, out) of the last call."""
+        self.x_samples = x_samples
+        self.samples_state = _State()
+        self.samples_result = None
         self.simulate = simulate
         self.M = float(bits_per_realisation)
         self.x = x
@@ -254,10 +261,16 @@ class ShardedBer:
                 if nxt < max_realisations:          # speculative: enqueue the next round before looking at this one
                     n2, m2 = plan(nxt)
                     pending = (nxt, n2, m2, launch(m2) if m2 else None)
-                local = np.asarray(collect(handle), dtype=np.int64) if mine else np.zeros(0, np.int64)
+                if self.x_samples is not None and mine:
+                    local, local_s = collect(handle, with_samples=True)
+                    local = np.asarray(local, dtype=np.int64)
+                else:
+                    local = np.asarray(collect(handle), dtype=np.int64) if mine else np.zeros(0, np.int64)
+                    local_s = None
             else:
                 n_round, mine = plan(start)
                 local = np.asarray(sim(mine), dtype=np.int64) if mine else np.zeros(0, np.int64)
+                local_s = None
             # one exchange step: every rank contributes its slots of the round's count vector
             vec = torch.zeros(n_round, dtype=torch.int64, device=self.device or "cpu")
             if mine:
@@ -267,6 +280,13 @@ class ShardedBer:
                 dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
             counts = vec.cpu().numpy()
             self.rounds += 1
+            if self.x_samples is not None and launch is not None:
+                sv = torch.zeros(n_round, dtype=torch.float64, device=self.device or "cpu")
+                if mine and local_s is not None:
+                    sv[torch.as_tensor([r - start for r in mine], device=sv.device)] = torch.as_tensor(local_s, device=sv.device)
+                if dist is not None and world > 1:
+                    dist.all_reduce(sv, op=dist.ReduceOp.SUM, group=self.group)   # disjoint slots: the sum is exact
+                self.samples_result = mc_estimate(sv.cpu().numpy(), self.x_samples, _state=self.samples_state)
             # replay the reference's sequential recursion in realisation order (ber_estimate.m:116-141)
             for c in counts:
                 result = ber_estimate_counts(int(c), self.M, self.x, _state=self.state)

@@ -328,6 +328,12 @@ class HotPath:
         self.sym[:F] = base
         return torch.minimum(best[0], best[1])
 
+    def evm(self, F):
+        """per-frame error-vector magnitude (mean |s - s_hat|^2) of the symbols now in self.sym: float64 tensor [F]"""
+        out = self.torch.empty(F, dtype=self.torch.float64, device=self.dev)
+        self.lib.call("plx_evm_dev", self.sym.data_ptr(), self.cfg.nsymb, 2, F, out.data_ptr(), self.stream())
+        return out
+
     def errors_min_over_rotations(self, F):
         """Resolve the pi/2 ambiguity of the blind phase estimate per polarisation (host-side
         convenience for BER sanity; the reference's scripts use differential decoding instead)."""
@@ -422,19 +428,25 @@ class McCampaign:
                 keep(i0, idx, ux, uy)
             hp.receive(ux, uy, self.sigma, 20260101, self._rx_stream, idx)   # receiver noise keyed by realisation index
             with torch.cuda.stream(self._rx_stream):
+                v = hp.evm(n)              # a continuous per-realisation sample (mc_estimate) beside the error count
                 e = hp.errors_resolved(n)
                 ux.record_stream(self._rx_stream); uy.record_stream(self._rx_stream)
                 done = torch.cuda.Event()
                 done.record(self._rx_stream)
-            out.append((e, done))
+            out.append((e, v, done))
         return out
 
-    def collect(self, handle):
-        res = []
-        for e, done in handle or []:
+    def collect(self, handle, with_samples=False):
+        """int64 error counts of a launch() handle (and, with_samples, the float64 EVM samples beside them)"""
+        res, smp = [], []
+        for e, v, done in handle or []:
             done.synchronize()             # the counts were formed on the receiver's stream
             res.append(e.cpu().numpy())
-        return np.concatenate(res) if res else np.zeros(0, np.int64)
+            smp.append(v.cpu().numpy())
+        counts = np.concatenate(res) if res else np.zeros(0, np.int64)
+        if with_samples:
+            return counts, (np.concatenate(smp) if smp else np.zeros(0))
+        return counts
 
     def simulate(self, indices, keep=None):
         """Error counts (pol swap and pi/2 ambiguities resolved, ex20_coherent_polmux.m:160-173) of the realisations

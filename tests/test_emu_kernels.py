@@ -291,6 +291,17 @@ def test_emu_dsp_chain(emu, oracle, kw):
     assert err[1].sum() == int(np.sum(oracle.samp2pat_coherent(np.angle(out[1].T)).T != dp))
 
 
+def test_emu_evm(emu):
+    r = np.random.default_rng(4)
+    F, L = 3, 130
+    sym = np.exp(1j * (np.pi / 4 + np.pi / 2 * r.integers(0, 4, (F, 2, L)))) + 0.1 * (r.standard_normal((F, 2, L)) + 1j * r.standard_normal((F, 2, L)))
+    d = _il(sym.reshape(F, -1))
+    out = np.zeros(F)
+    emu.call("plx_evm_dev", _vp(d), L, 2, F, _vp(out), None)
+    hat = (np.where(sym.real >= 0, 1, -1) + 1j * np.where(sym.imag > 0, 1, -1)) / np.sqrt(2)
+    np.testing.assert_allclose(out, (np.abs(sym - hat) ** 2).mean(axis=(1, 2)), rtol=1e-13)
+
+
 def test_emu_sweep_variants(emu, oracle, monkeypatch):
     """The fused column sweep (default at this geometry: k_colx16 with its per-frame barrier), the barrier-free
     three-sweep step (PLX_SSFM_NO_FUSE) and a 16 x 256 split (PLX_SSFM_P1=4: 256-point rows through the general

@@ -539,6 +539,22 @@ def test_decide_count_device(lib, oracle):
         assert err.cpu().numpy()[f].tolist() == [int((want[:2] != pat[:2]).sum()), int((want[2:] != pat[2:]).sum())]
 
 
+def test_evm_device(lib):
+    """plx_evm_dev: per-frame mean |s - s_hat|^2 against the unit-modulus QPSK point of the decided quadrant -- the
+    continuous sample the Monte-Carlo campaign hands to mc_estimate (mc_estimate.m:133-212)."""
+    import torch
+    r = np.random.default_rng(4)
+    F, L = 5, 300
+    sym = np.exp(1j * (np.pi / 4 + np.pi / 2 * r.integers(0, 4, (F, 2, L)))) + 0.1 * (r.standard_normal((F, 2, L)) + 1j * r.standard_normal((F, 2, L)))
+    d = _dev(sym)
+    out = torch.empty(F, dtype=torch.float64, device="cuda")
+    lib.call("plx_evm_dev", d.data_ptr(), L, 2, F, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    hat = (np.where(sym.real >= 0, 1, -1) + 1j * np.where(sym.imag > 0, 1, -1)) / np.sqrt(2)
+    want = (np.abs(sym - hat) ** 2).mean(axis=(1, 2))
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-13)
+    assert abs(want.mean() - 0.02) < 0.005
+
+
 # ======================================================= whole path, BASELINE size ===
 def test_hot_path_end_to_end_vs_oracle_c1(lib, oracle):
     """BASELINE config[1] frame (2^16 dual-pol, 80 km 'g-s-', CDE 256/128, CMA 7 taps, CPE) through the

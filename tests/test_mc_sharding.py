@@ -94,8 +94,11 @@ class _FakeCampaign:
         self.launched.append(list(idx))
         return list(idx)
 
-    def collect(self, handle):
-        return _errors_of(handle)
+    def collect(self, handle, with_samples=False):
+        e = _errors_of(handle)
+        if with_samples:       # a continuous sample per realisation beside the count (the device campaign's EVM)
+            return e, np.array([0.05 + 1e-3 * np.random.default_rng([9, int(r)]).standard_normal() for r in handle])
+        return e
 
     def simulate(self, idx):
         return self.collect(self.launch(idx))
@@ -115,6 +118,18 @@ def test_pipelined_rounds_give_the_sequential_statistics():
     for got, want in zip(res, ref):
         np.testing.assert_array_equal(np.asarray(got, dtype=float), np.asarray(want, dtype=float))
     assert len(camp.launched) == runner.rounds + 1                 # exactly one speculative round beyond the stop
+    # the continuous samples of the same rounds go through mc_estimate, block by block (mc_estimate.m:133-212)
+    camp3 = _FakeCampaign()
+    r3 = mc.ShardedBer(camp3.simulate, 4096, x, per_rank_per_round=4, x_samples=dict(stop=(1e-4, 95), nmin=10))
+    r3.run(max_realisations=5000)
+    st = mc._State()
+    want = None
+    for k in range(r3.rounds):
+        blk = camp3.collect(list(range(4 * k, 4 * k + 4)), with_samples=True)[1]
+        want = mc.mc_estimate(blk, dict(stop=(1e-4, 95), nmin=10), _state=st)
+    np.testing.assert_array_equal(r3.samples_result[1]["mean"], want[1]["mean"])
+    np.testing.assert_array_equal(r3.samples_result[1]["varlim"], want[1]["varlim"])
+    assert abs(r3.samples_result[1]["mean"][0] - 0.05) < 1e-3
     # a campaign that ends on max_realisations has no speculative round left over
     camp2 = _FakeCampaign()
     r2 = mc.ShardedBer(camp2.simulate, 4096, dict(stop=(1e-9, 95), nmin=10), per_rank_per_round=4)
@@ -133,9 +148,12 @@ def _gpu_worker(rank, world, port, q):
     cfg = pipeline.HotPathConfig(nsymb=256, nt=16, flag="gps-", nplates=10, dgd=0.2, length=4e4, pavg_mw=1.0, cma_mu=1 / 600,
                                  freqavg=50, dphimax=2e-2)
     camp = pipeline.McCampaign(cfg, frames_per_call=4, noise_sigma=0.28)
-    runner = mc.ShardedBer(camp.simulate, camp.bits_per_realisation, dict(stop=(0.01, 99), nmin=50), per_rank_per_round=4)
+    runner = mc.ShardedBer(camp.simulate, camp.bits_per_realisation, dict(stop=(0.01, 99), nmin=50), per_rank_per_round=4,
+                           x_samples=dict(stop=(1e-3, 95), nmin=10))
     res = runner.run(max_realisations=48)
-    q.put((rank, [np.asarray(v, dtype=float).tolist() for v in res], list(runner.counts)))
+    so = runner.samples_result[1]
+    q.put((rank, [np.asarray(v, dtype=float).tolist() for v in res], list(runner.counts),
+           [float(so["mean"][0]), float(so["var"][0]), float(so["stdmean"][0]), float(so["nruns"][0])] + [float(v) for v in so["varlim"][:, 0]]))
     camp.close()
     dist.destroy_process_group()
 
@@ -159,10 +177,12 @@ def test_real_campaign_on_two_ranks_equals_one_rank():
             assert p.exitcode == 0
         outs[world] = got
     ref = outs[1][0]
-    for rank, res, counts in outs[2]:
+    for rank, res, counts, evm in outs[2]:
         assert counts == ref[2]
         for a, b in zip(res, ref[1]):
             np.testing.assert_array_equal(np.asarray(a), np.asarray(b))
+        assert evm == ref[3]                                            # mc_estimate of the device EVM samples: sharding-invariant
+    assert 0 < ref[3][0] < 1 and ref[3][3] == len(ref[2]) and ref[3][4] <= ref[3][1] <= ref[3][5]   # mean, nruns, variance limits
     assert len(ref[2]) >= 8 and sum(ref[2]) > 0
 
 
