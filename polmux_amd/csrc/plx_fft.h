@@ -220,35 +220,76 @@ __device__ __forceinline__ void lvl2_dif256(cplx *y, int j, const cplx *tw)
     }
 }
 
-// Twiddle tables of the row transforms.  Plain: the half table W_M^k, k < M/2 (8 bytes of LDS per point of the row).
-// COMPACT (long rows, M >= 4096, where that table would cost a second workgroup per CU): W_M^{4k}, k < M/8, followed
-// by the four fine factors W_M^0..3; only the outermost radix-4 stage has odd exponents and pays one more complex
-// product per twiddle, every other stage reads W_M^{4k} directly.
-template <bool COMPACT> __device__ __forceinline__ cplx row_tw(const cplx *tw, int k, int halfM)
-{   // W_M^k, k < M/2
-    if (!COMPACT) return tw[k];
-    return cmul(tw[k >> 2], tw[(halfM >> 2) + (k & 3)]);
-}
-template <bool COMPACT> __device__ __forceinline__ cplx row_tw3(const cplx *tw, int k3, int halfM)
-{   // W_M^{k3}, k3 < 3M/4: W^{k+M/2} = -W^k
-    const cplx w = row_tw<COMPACT>(tw, k3 & (halfM - 1), halfM);
-    const bool neg = k3 >= halfM;
-    return make_double2(neg ? -w.x : w.x, neg ? -w.y : w.y);
-}
-template <bool COMPACT> __device__ __forceinline__ cplx row_tw4(const cplx *tw, int k, int halfM)
-{   // W_M^k for k a multiple of 4 (every stage but the outermost)
-    return COMPACT ? tw[k >> 2] : tw[k];
-}
-template <bool COMPACT> __device__ __forceinline__ cplx row_tw4_3(const cplx *tw, int k3, int halfM)
+// The register levels lvl2_dif256 / lvl2_dit256 for any length M = 16 S: y[k] is point j + S k (j < S) of a length-M
+// transform, W a functor e -> W_M^e (e < 3M/4).  Stages m = M (q = M/4) and m = M/4 (q = S) only combine points that
+// share j, so a transform of 16^L points is L such levels with one exchange between consecutive ones (4096-point
+// rows: k_row4k).
+template <int S, class W> __device__ __forceinline__ void lvl2_dif(cplx *y, int j, W w)
 {
-    const cplx w = row_tw4<COMPACT>(tw, k3 & (halfM - 1), halfM);
-    const bool neg = k3 >= halfM;
-    return make_double2(neg ? -w.x : w.x, neg ? -w.y : w.y);
+#pragma unroll
+    for (int r1 = 0; r1 < 4; r1++) { // m = M
+        const int e = j + S * r1;
+        const cplx a0 = y[r1], a1 = y[r1 + 4], a2 = y[r1 + 8], a3 = y[r1 + 12];
+        const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
+        cplx y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+        y1 = cmul(y1, w(e)); y2 = cmul(y2, w(2 * e)); y3 = cmul(y3, w(3 * e));
+        y[r1] = cadd(t0, t2); y[r1 + 4] = y2; y[r1 + 8] = y1; y[r1 + 12] = y3;
+    }
+    const int e = 4 * j;
+    const cplx u1 = w(e), u2 = w(2 * e), u3 = w(3 * e);
+#pragma unroll
+    for (int r2 = 0; r2 < 4; r2++) { // m = M/4
+        const cplx a0 = y[4 * r2], a1 = y[4 * r2 + 1], a2 = y[4 * r2 + 2], a3 = y[4 * r2 + 3];
+        const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
+        cplx y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+        y1 = cmul(y1, u1); y2 = cmul(y2, u2); y3 = cmul(y3, u3);
+        y[4 * r2] = cadd(t0, t2); y[4 * r2 + 1] = y2; y[4 * r2 + 2] = y1; y[4 * r2 + 3] = y3;
+    }
 }
+template <int S, class W> __device__ __forceinline__ void lvl2_dit(cplx *y, int j, W w)
+{
+    const int e = 4 * j;
+    const cplx u1 = w(e), u2 = w(2 * e), u3 = w(3 * e);
+#pragma unroll
+    for (int r2 = 0; r2 < 4; r2++) { // m = M/4
+        cplx c0 = y[4 * r2], c2 = y[4 * r2 + 1], c1 = y[4 * r2 + 2], c3 = y[4 * r2 + 3];
+        c1 = cmulc(c1, u1); c2 = cmulc(c2, u2); c3 = cmulc(c3, u3);
+        const cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
+        y[4 * r2] = cadd(s0, s2); y[4 * r2 + 1] = cadd(s1, s3); y[4 * r2 + 2] = csub(s0, s2); y[4 * r2 + 3] = csub(s1, s3);
+    }
+#pragma unroll
+    for (int r1 = 0; r1 < 4; r1++) { // m = M
+        const int e1 = j + S * r1;
+        cplx c0 = y[r1], c2 = y[r1 + 4], c1 = y[r1 + 8], c3 = y[r1 + 12];
+        c1 = cmulc(c1, w(e1)); c2 = cmulc(c2, w(2 * e1)); c3 = cmulc(c3, w(3 * e1));
+        const cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
+        y[r1] = cadd(s0, s2); y[r1 + 4] = cadd(s1, s3); y[r1 + 8] = csub(s0, s2); y[r1 + 12] = csub(s1, s3);
+    }
+}
+// twiddle functors over the COMPACT table of W_4096 (W^{4k}, k < 512, then W^0..3: 8 KiB instead of the 32 KiB half
+// table, so that two row workgroups share a CU): W_4096^e, and W_256^e = W_4096^{16 e}
+struct Tw4096 {
+    const cplx *t;
+    __device__ __forceinline__ cplx operator()(int e) const
+    {
+        const int i = e & 2047;
+        const cplx w = cmul(t[i >> 2], t[512 + (i & 3)]);
+        const bool neg = e >= 2048;
+        return make_double2(neg ? -w.x : w.x, neg ? -w.y : w.y);
+    }
+};
+struct Tw256of4096 {
+    const cplx *t;
+    __device__ __forceinline__ cplx operator()(int e) const
+    {
+        const int e16 = e << 4, i = e16 & 2047;
+        const cplx w = t[i >> 2];
+        const bool neg = e16 >= 2048;
+        return make_double2(neg ? -w.x : w.x, neg ? -w.y : w.y);
+    }
+};
 
 // T = 1<<logT padded rows of M = 1<<logM (M >= 16) points each, row t at s + t*row_pitch(M).
-// (COMPACT tables: logM even, >= 6, so that the head stage is the radix-4 stage with sh = 0.)
-template <bool COMPACT = false>
 __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
 {
     const int M = 1 << logM, halfM = M >> 1, T = 1 << logT, TSp = row_pitch(M);
@@ -277,16 +318,9 @@ __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const c
             cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
             const int k = j << sh;
             cplx y0 = cadd(t0, t2), y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
-            // (no guard for k = 0: it diverges inside every wave and splits the basic block)
-            if (COMPACT && sh == 0) {  // outermost stage: odd exponents (uniform branch)
-                y1 = cmul(y1, row_tw<COMPACT>(tw, k, halfM));
-                y2 = cmul(y2, row_tw<COMPACT>(tw, 2 * k, halfM));
-                y3 = cmul(y3, row_tw3<COMPACT>(tw, 3 * k, halfM));
-            } else {
-                y1 = cmul(y1, row_tw4<COMPACT>(tw, k, halfM));
-                y2 = cmul(y2, row_tw4<COMPACT>(tw, 2 * k, halfM));
-                y3 = cmul(y3, row_tw4_3<COMPACT>(tw, 3 * k, halfM));
-            }
+            y1 = cmul(y1, tw[k]);      // (no guard for k = 0: it diverges inside every wave and splits the basic block)
+            y2 = cmul(y2, tw[2 * k]);
+            y3 = cmul(y3, tw3(tw, 3 * k, halfM));
             p[0] = y0; p[qs] = y2; p[2 * qs] = y1; p[3 * qs] = y3;
         }
         __syncthreads();
@@ -307,7 +341,6 @@ __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const c
     }
 }
 
-template <bool COMPACT = false>
 __device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
 {
     const int M = 1 << logM, halfM = M >> 1, T = 1 << logT, TSp = row_pitch(M);
@@ -336,15 +369,9 @@ __device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const c
             cplx *p = s + t * TSp + row_phys(base);
             cplx c0 = p[0], c2 = p[qs], c1 = p[2 * qs], c3 = p[3 * qs];
             const int k = j << sh;
-            if (COMPACT && sh == 0) {
-                c1 = cmulc(c1, row_tw<COMPACT>(tw, k, halfM));
-                c2 = cmulc(c2, row_tw<COMPACT>(tw, 2 * k, halfM));
-                c3 = cmulc(c3, row_tw3<COMPACT>(tw, 3 * k, halfM));
-            } else {
-                c1 = cmulc(c1, row_tw4<COMPACT>(tw, k, halfM));
-                c2 = cmulc(c2, row_tw4<COMPACT>(tw, 2 * k, halfM));
-                c3 = cmulc(c3, row_tw4_3<COMPACT>(tw, 3 * k, halfM));
-            }
+            c1 = cmulc(c1, tw[k]);
+            c2 = cmulc(c2, tw[2 * k]);
+            c3 = cmulc(c3, tw3(tw, 3 * k, halfM));
             cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
             p[0] = cadd(s0, s2); p[qs] = cadd(s1, s3); p[2 * qs] = csub(s0, s2); p[3 * qs] = csub(s1, s3);
         }

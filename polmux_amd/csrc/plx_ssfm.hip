@@ -546,9 +546,7 @@ __device__ __forceinline__ void pmd_trunks(cplx &x, cplx &y, double btf, double 
 // transform, all on one LDS-resident row set (padded layout, see plx_fft.h).
 #define ROW_THREADS 128
 #define ROW_CH 4
-// TWC: compact twiddle table (plx_fft.h, row_tw): 4096-point rows, where the plain half table would cost the second
-// workgroup of a CU.
-template <bool TWC> __global__ __launch_bounds__(1024) void k_row_t(SsfmArgs a)
+__global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
@@ -562,7 +560,7 @@ template <bool TWC> __global__ __launch_bounds__(1024) void k_row_t(SsfmArgs a)
     const int N2 = 1 << a.p2, R = a.R, TSp = row_pitch(N2);
     cplx *s = (cplx *)lds;                       // [npol*R][TSp]
     cplx *tw = s + (size_t)(a.dual ? 2 : 1) * R * TSp;
-    lds_load_twiddles(tw, a.tw2, TWC ? (N2 >> 3) + 4 : N2 >> 1, tid, nthr);
+    lds_load_twiddles(tw, a.tw2, N2 >> 1, tid, nthr);
     const size_t N = (size_t)1 << (a.p1 + a.p2);
     const size_t base = (size_t)fc * N;
     const int j0 = blockIdx.x * R;
@@ -605,7 +603,7 @@ template <bool TWC> __global__ __launch_bounds__(1024) void k_row_t(SsfmArgs a)
         }
     }
     __syncthreads();
-    row_fft_dif<TWC>(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
+    row_fft_dif(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     const double cur = a.force ? a.f_cur : ctl->cur;
     if (!a.dual) {
         for (int e = tid; e < nel; e += nthr) { // Hf = fastexp(-betat*dz) :771
@@ -661,7 +659,7 @@ template <bool TWC> __global__ __launch_bounds__(1024) void k_row_t(SsfmArgs a)
         }
     }
     __syncthreads();
-    row_fft_dit<TWC>(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
+    row_fft_dit(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     if (keep_tw) {
 #pragma unroll
         for (int k = 0; k < ROW_CH; k++) {
@@ -680,7 +678,93 @@ template <bool TWC> __global__ __launch_bounds__(1024) void k_row_t(SsfmArgs a)
     }
 }
 
-#define k_row (k_row_t<false>)
+// ------------------------------------------------- pass 2 for 4096-point rows (2^20-sample frames) ---
+// One workgroup = one row of ONE polarisation (no PMD: the polarisations only share the multiplier), every radix level
+// in registers: 4096 = 16 x 16 x 16, thread j holds points j + 256 k, three register levels per direction (lvl2_dif<256>
+// on W_4096, lvl2_dif<16> on W_256, r16_dif; the inverse mirrors them) with ONE exchange through a padded LDS row between
+// consecutive levels -- four exchanges per row where the LDS-resident k_row makes eleven barrier-separated passes.  The
+// spectrum is left in the bit-reversed order of the in-place transform, where the multiplier tables already are.
+// Twiddles: the compact table of W_4096 (8 KiB); 78 KiB of LDS per workgroup: two per CU.
+__global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
+{
+    PLX_DYN_LDS(lds);
+    if (all_done_or_aborted(a)) return;
+    const int tid = threadIdx.x;
+    const int slot = blockIdx.y / a.nfc, c = blockIdx.y - slot * a.nfc;
+    int f;
+    if (!slot_frame(a, slot, f)) return;
+    const int fc = f * a.nfc + c;
+    const FrameCtl *ctl = a.ctl + f;
+    if (ctl->done) return;
+    cplx *s = (cplx *)lds;                       // [4352] padded row: physical(p) = p + (p >> 4)
+    cplx *tw = s + 4352;                         // W_4096^{4k}, k < 512, then W_4096^0..3
+    lds_load_twiddles(tw, a.tw2, 516, tid, 256);
+    const size_t N = (size_t)1 << (a.p1 + a.p2);
+    const size_t rowbase = (size_t)blockIdx.x << 12;
+    cplx *const u = a.ux + (size_t)fc * N + rowbase;
+    const cplx *const tp = a.tpass + rowbase;
+    const Tw4096 w1{tw};
+    const Tw256of4096 w2{tw};
+    const int b = tid >> 4, j2 = tid & 15;       // level 2: block b of 256 points, point j2 + 16 k of it
+    cplx x[16];
+    {
+        cplx tv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { x[k] = u[tid + 256 * k]; tv[k] = tp[tid + 256 * k]; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { pin(x[k]); pin(tv[k]); }
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = cmul(x[k], tv[k]);
+    }
+    __syncthreads();                             // twiddles staged
+    lvl2_dif<256>(x, tid, w1);
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[row_phys(tid + 256 * k)] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+    lvl2_dif<16>(x, j2, w2);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = s[17 * tid + k];             // row_phys(16 tid + k)
+    r16_dif(x);
+    {   // the step's multiplier at the 16 bins this thread holds (lin_step :771-773 / matrix_step with matR = I)
+        int o16 = 16 * tid;
+        pin(o16);
+        if (a.hmul) {
+            const cplx *h = a.hmul + rowbase + o16;
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = cmul(h[k], x[k]);
+        } else {
+            const double cur = a.force ? a.f_cur : ctl->cur;
+            const double *bt = a.betat_p + (size_t)c * N + rowbase + o16;
+#pragma unroll
+            for (int k = 0; k < 16; k++) x[k] = cmul(cexp_neg_turns(bt[k] * cur), x[k]);
+        }
+    }
+    r16_dit(x);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[17 * tid + k] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+    lvl2_dit<16>(x, j2, w2);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = s[row_phys(tid + 256 * k)];
+    lvl2_dit<256>(x, tid, w1);
+    int jo = tid;
+    pin(jo);
+#pragma unroll
+    for (int k = 0; k < 16; k++) u[jo + 256 * k] = cmulc(x[k], tp[jo + 256 * k]);
+}
 
 // ------------------------------------------------------ pass 3: inverse columns ---
 // Completes ifft (1/N), applies the attenuation of the step (:531-532) and feeds
@@ -1043,7 +1127,7 @@ struct plx_ssfm {
     int row_threads = ROW_THREADS; // workgroup size of k_row
     int row_split = 0, rs_threads = 0; // long rows without PMD: one polarisation per workgroup (scalar row pass twice)
     size_t rs_lds = 0;
-    int tw_compact = 0;            // 4096-point rows: compact twiddle table in d_tw2 (k_row_t<true>)
+    int tw_compact = 0;            // 4096-point rows: compact twiddle table in d_tw2, register-blocked row pass k_row4k
     double *h_brf[2] = {nullptr, nullptr}; // pinned staging of the waveplate tables
     hipEvent_t brf_ev[2] = {nullptr, nullptr};
     int brf_slot = 0;
@@ -1237,7 +1321,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     }
     std::vector<cplx> t1, t2;
     half_table(t1, N1);
-    if (P->tw_compact) {   // W_N2^{4k}, k < N2/8, then W_N2^0..3 (plx_fft.h, row_tw)
+    if (P->tw_compact) {   // W_N2^{4k}, k < N2/8, then W_N2^0..3 (plx_fft.h, Tw4096)
         t2.resize(N2 / 8 + 4);
         for (int k = 0; k < N2 / 8 + 4; k++) {
             const int e = k < N2 / 8 ? 4 * k : k - N2 / 8;
@@ -1285,7 +1369,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     if (allow_lds(k_colx16, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
         allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
         (!P->tw_compact && allow_lds(k_row, P->lds_row > P->rs_lds ? P->lds_row : P->rs_lds) != hipSuccess) ||
-        (P->tw_compact && allow_lds((k_row_t<true>), P->rs_lds) != hipSuccess)) {
+        (P->tw_compact && allow_lds(k_row4k, P->rs_lds) != hipSuccess)) {
         free_plan(P);
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
     }
@@ -1398,7 +1482,7 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         const dim3 gs((unsigned)N1, FC), bs((unsigned)P->rs_threads);
         for (int pol = 0; pol < 2; pol++) {
             if (pol) b.ux = a.uy;
-            if (P->tw_compact) PLX_LAUNCH((k_row_t<true>), gs, bs, P->rs_lds, st, b);
+            if (P->tw_compact) PLX_LAUNCH(k_row4k, gs, dim3(256), P->rs_lds, st, b);
             else PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
         }
         return;
