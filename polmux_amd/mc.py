@@ -210,8 +210,8 @@ class ShardedBer:
     def __init__(self, simulate, bits_per_realisation, x, per_rank_per_round=8, group=None, device=None, x_samples=None):
         """x_samples: optional mc_estimate options (mc_estimate.m:104-131).  When given and the simulator's collect()
         can return a continuous sample per realisation beside the error count (McCampaign: the EVM), every round's
-        sample vector is gathered the same way (one all-reduce of float64 slots) and fed to mc_estimate as one block
-        of M = round-size samples: `samples_result` = (cond, out) of the last call."""
+        sample vector is gathered the same way (one all-reduce of float64 slots) and fed to mc_estimate in blocks of
+        per_rank_per_round samples: `samples_result` = (cond, out) of the last call."""
         self.x_samples = x_samples
         self.samples_state = _State()
         self.samples_result = None
@@ -286,7 +286,11 @@ class ShardedBer:
                     sv[torch.as_tensor([r - start for r in mine], device=sv.device)] = torch.as_tensor(local_s, device=sv.device)
                 if dist is not None and world > 1:
                     dist.all_reduce(sv, op=dist.ReduceOp.SUM, group=self.group)   # disjoint slots: the sum is exact
-                self.samples_result = mc_estimate(sv.cpu().numpy(), self.x_samples, _state=self.samples_state)
+                # blocks of per_rank_per_round samples in realisation order, whatever the number of ranks: the recursion
+                # then sees the same sequence of blocks for any sharding (bit-equal statistics)
+                svn = sv.cpu().numpy()
+                for b0 in range(0, n_round, self.w):
+                    self.samples_result = mc_estimate(svn[b0:b0 + self.w], self.x_samples, _state=self.samples_state)
             # replay the reference's sequential recursion in realisation order (ber_estimate.m:116-141)
             for c in counts:
                 result = ber_estimate_counts(int(c), self.M, self.x, _state=self.state)
