@@ -305,7 +305,7 @@ def main():
         torch.cuda.synchronize()
 
     # receiver on its own HIP stream: Rx of batch i overlaps the fibre of batch i+1 (both inside the timed region)
-    rx_stream = None if a.no_overlap else torch.cuda.Stream()
+    rx_stream = None if (a.no_overlap or not hp.overlap_ok()) else torch.cuda.Stream()
     err_total = torch.zeros(2, dtype=torch.int64, device="cuda")
     errs, resolved = [], []
     fib_ms, rx_ms, row_launches, sample_steps = [], [], 0, 0

@@ -100,7 +100,10 @@ int plx_ssfm_set_birefringence_dev(plx_ssfm *plan, const double *db0, const doub
  * second plan propagating at the same time), a barrier that cannot complete within
  * 0.5 s raises a sticky abort: nothing is stored or advanced after it and the call
  * returns PLX_ERR_HIP ("frame barrier timed out"); PLX_SSFM_NO_FUSE=1 at plan creation
- * selects the barrier-free sweeps for such deployments.                             */
+ * selects the barrier-free sweeps for such deployments.  Short kernels of another stream
+ * of the same process are harmless as long as one frame takes at most half of the grid
+ * (plx_ssfm_info: 2 * info[4] <= info[3]); larger frames (2^19, 2^20 samples) should have
+ * the device to themselves while they propagate.                                     */
 int plx_ssfm_propagate_dev(plx_ssfm *plan, double *d_ux, double *d_uy, int nframes, void *stream);
 /* per-frame results of the last propagate: firstdz, ncycle (fiber.m:431)           */
 int plx_ssfm_results(plx_ssfm *plan, int nframes, double *firstdz, int32_t *ncycle);

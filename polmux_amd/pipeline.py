@@ -252,6 +252,8 @@ class HotPath:
         realisation indices the noise of a realisation does not depend on batching or sharding.
         With side_stream the whole receiver is enqueued on that stream behind the fibre of this batch, so
         the latency-bound CMA recurrence overlaps the HBM-bound fibre sweeps of the NEXT batch."""
+        if side_stream is not None and not self.overlap_ok():
+            side_stream = None
         if side_stream is not None:
             torch = self.torch
             ready = torch.cuda.Event()
@@ -377,6 +379,15 @@ class HotPath:
         info = (C.c_int32 * 8)()
         self.lib.call("plx_ssfm_info", self.ssfm, info)
         return bool(info[0])
+
+    def overlap_ok(self):
+        """May a second stream (the receiver of the previous batch) share the GPU with fibre()?  The fused column sweep needs
+        the tiles of a frame co-resident; when ONE frame takes more than half of the grid (2^19- and 2^20-sample frames)
+        a long-running receiver kernel that holds registers on every CU keeps the frame's second half from being placed
+        until it ends: the two serialise (or the barrier times out).  Such plans run the receiver on the fibre's stream."""
+        info = (C.c_int32 * 8)()
+        self.lib.call("plx_ssfm_info", self.ssfm, info)
+        return (not info[0]) or 2 * info[4] <= info[3]
 
     def ssfm_stats(self):
         """(row-pass launches, sample-steps) of the last fibre() call, summed over its frame groups"""
