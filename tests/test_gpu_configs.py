@@ -286,3 +286,24 @@ def test_power_ladder_batch_every_frame_keeps_the_reference_step_count(lib, orac
     assert max(want) >= 4 * min(want)                                # the ladder really spreads the trip counts
     assert hp.ssfm_stats()[1] == sum(want) * cfg.nfft
     hp.close()
+
+
+def test_front_end_at_2pow20_uses_the_long_row_filter_pass(lib, oracle):
+    """The coherent front end of a 2^20-sample frame: its two spectral filters run on the plan's FFT engine, i.e. through
+    the 256 x 4096 split and the 4096-point row pass k_row4k with a general multiplier table -- photocurrents against the
+    numpy restatement of receiver_cohmix.m:165-307 (oracle/front.py)."""
+    from oracle import front
+    from polmux_amd import pipeline
+    cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, frontend="cohmix", adcbits=0)
+    hp = pipeline.HotPath(cfg, max_frames=1)
+    ux, uy = hp.make_batch(1)
+    tx, ty = ux[0].cpu().numpy(), uy[0].cpu().numpy()
+    hp.front.run(ux, uy, hp.front_shifts, out=hp.rx[:1])
+    _sync()
+    t = hp.front_tables
+    cur = front.receiver_cohmix(tx, ty, t["hopt"], t["elo"], t["hel"], True)
+    got = np.stack([ux[0].real.cpu().numpy(), ux[0].imag.cpu().numpy(), uy[0].real.cpu().numpy(), uy[0].imag.cpu().numpy()], 1)
+    assert np.abs(got - cur).max() < 1e-10 * np.abs(cur).max()
+    rx = front.rx_front(cur, True, 0, hp.front_shifts, t["decim"], t["fir"])
+    assert np.abs(hp.rx[0].cpu().numpy().T - rx).max() < 1e-10 * np.abs(rx).max()
+    hp.close()
