@@ -210,9 +210,10 @@ def cpu_baseline(cfg, hp, nframes, noise):
     return one, allc
 
 
-def ladder_scales(nframes, pavg_mw):
-    """BASELINE config[4]: 64 launch powers -4...+8 dBm in equal dB steps; frame f sits at point f % 64."""
-    dbm = -4.0 + 12.0 * (np.arange(nframes) % 64) / 63.0
+def ladder_scales(nframes, pavg_mw, rank=0, world=1):
+    """BASELINE config[4]: 64 launch powers -4...+8 dBm in equal dB steps; frame f of rank r sits at point
+    (r + world * f) % 64, so that 8 GPUs x 8 frames cover the ladder once, each GPU with a similar mix of powers."""
+    dbm = -4.0 + 12.0 * ((rank + world * np.arange(nframes)) % 64) / 63.0
     return 10 ** (dbm / 10) / pavg_mw
 
 
@@ -269,7 +270,7 @@ def main():
     hp = pipeline.HotPath(cfg, max_frames=F)
     hp.profile(True)          # a HIP event between consecutive launches of the step loop: per-kernel durations, live
     n = cfg.nfft
-    scales = ladder_scales(F, a.pavg) if a.power_ladder else None
+    scales = ladder_scales(F, a.pavg, rank, world) if a.power_ladder else None
     # inputs for every step are staged in HBM before the timed region (fibre works in place)
     total = a.steps + a.warmup
     # (bounded by free HBM: with more steps than buffers a buffer is refilled from a pristine copy by one

@@ -16,7 +16,8 @@ timeout -k 10 600 python bench.py --frontend cohmix --no-cpu-baseline --mc-round
 timeout -k 10 600 python bench.py --power-ladder --no-cpu-baseline --mc-rounds 0 > $O/bench_ladder.json 2>/dev/null || exit 1
 timeout -k 10 600 python bench.py --mc --no-cpu-baseline --mc-rounds 4 --mc-frames 512 > $O/bench_mc.json 2>/dev/null || exit 1
 timeout -k 10 600 python bench.py --nsymb 16384 --frames 16 --steps 2 --warmup 1 --variants 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 > $O/bench_c4_frame.json 2>/dev/null || exit 1
-cat $O/bench_default.json $O/bench_no_overlap.json $O/bench_cohmix.json $O/bench_ladder.json $O/bench_mc.json $O/bench_c4_frame.json > $O/bench.jsonl
+timeout -k 10 900 python bench.py --nsymb 16384 --frames 8 --spans 40 --power-ladder --steps 1 --warmup 0 --variants 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 > $O/bench_c4_40spans.json 2>/dev/null || exit 1
+cat $O/bench_default.json $O/bench_no_overlap.json $O/bench_cohmix.json $O/bench_ladder.json $O/bench_mc.json $O/bench_c4_frame.json $O/bench_c4_40spans.json > $O/bench.jsonl
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 > /dev/null 2>&1 || exit 1
 f=$(find $O/prof -name "*kernel_trace.csv" | head -1)
 python scripts/prof_summary.py $f > $O/kernel_trace_summary.md
