@@ -101,8 +101,10 @@ template <int X> __device__ __forceinline__ double lane_xchg(double v)
 {
     constexpr int ctrl = X == 1 ? 0xB1 : X == 2 ? 0x4E : X == 7 ? 0x141 : X == 8 ? 0x128 : 0x140;
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xF, 0xF, false);
+    // every lane is a valid source under these patterns, so the "old" operand is never used: an untied old value (0,
+    // bound_ctrl) lets the DPP move write a fresh register straight from the source instead of copying it first
+    lo = __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, ctrl, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 #endif

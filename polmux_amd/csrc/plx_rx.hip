@@ -183,6 +183,17 @@ __device__ __forceinline__ double sum8(double v)
     v += lane_xchg<7>(v);
     return v;
 }
+// the same reduction for two values at once, level by level: the two dependent chains (move, move, add) interleave,
+// which is what hides their latency on the one wave per SIMD this kernel runs with
+__device__ __forceinline__ void sum8x2(double &a, double &b)
+{
+    double a1 = lane_xchg<1>(a), b1 = lane_xchg<1>(b);
+    a += a1; b += b1;
+    a1 = lane_xchg<2>(a); b1 = lane_xchg<2>(b);
+    a += a1; b += b1;
+    a1 = lane_xchg<7>(a); b1 = lane_xchg<7>(b);
+    a += a1; b += b1;
+}
 __device__ __forceinline__ double max16(double v)
 {
     double o = lane_xchg<1>(v); v = o > v ? o : v;
@@ -220,6 +231,7 @@ __global__ __launch_bounds__(64) void k_cma16(DemuxArgs a)
     const int64_t nchunks = L / CMA_U, tail0 = nchunks * CMA_U;
     while (__any(active)) {
         const cplx oa = ha, ob = hb;
+        const double mua = active ? mu : 0.0;
         cplx ca[CMA_U], cb[CMA_U], na[CMA_U], nb[CMA_U];
 #pragma unroll
         for (int u = 0; u < CMA_U; u++) {
@@ -239,19 +251,23 @@ __global__ __launch_bounds__(64) void k_cma16(DemuxArgs a)
                     nb[u] = tap_ok ? x2[idx] : make_double2(0, 0);
                 }
             }
+            cplx yk[CMA_U];                // the chunk's outputs: stored once, outside the dependent chain
 #pragma unroll
             for (int u = 0; u < CMA_U; u++) {
                 const cplx xa = ca[u], xb = cb[u];
-                const double pr = (xa.x * ha.x - xa.y * ha.y) + (xb.x * hb.x - xb.y * hb.y);
-                const double pi = (xa.x * ha.y + xa.y * ha.x) + (xb.x * hb.y + xb.y * hb.x);
-                const double yr = sum8(pr), yi = sum8(pi);
-                if (active && frame_ok && t == 0) yo[i0 + u] = make_double2(yr, yi);
-                if (active) {
-                    const double k = mu * (Rr - yr * yr - yi * yi);
-                    const double kr = k * yr, ki = k * yi;
-                    ha.x += kr * xa.x + ki * xa.y; ha.y += ki * xa.x - kr * xa.y;
-                    hb.x += kr * xb.x + ki * xb.y; hb.y += ki * xb.x - kr * xb.y;
-                }
+                double yr = (xa.x * ha.x - xa.y * ha.y) + (xb.x * hb.x - xb.y * hb.y);
+                double yi = (xa.x * ha.y + xa.y * ha.x) + (xb.x * hb.y + xb.y * hb.x);
+                sum8x2(yr, yi);
+                yk[u] = make_double2(yr, yi);
+                // (a finished frame keeps iterating with mu = 0: its taps stay as they are, no branch in the chain)
+                const double k = mua * (Rr - yr * yr - yi * yi);
+                const double kr = k * yr, ki = k * yi;
+                ha.x += kr * xa.x + ki * xa.y; ha.y += ki * xa.x - kr * xa.y;
+                hb.x += kr * xb.x + ki * xb.y; hb.y += ki * xb.x - kr * xb.y;
+            }
+            if (active && frame_ok && t == 0) {
+#pragma unroll
+                for (int u = 0; u < CMA_U; u++) yo[i0 + u] = yk[u];
             }
 #pragma unroll
             for (int u = 0; u < CMA_U; u++) { ca[u] = na[u]; cb[u] = nb[u]; }
@@ -260,16 +276,14 @@ __global__ __launch_bounds__(64) void k_cma16(DemuxArgs a)
             int64_t idx = i + off;
             if (idx < 0) idx += L; else if (idx >= L) idx -= L;
             const cplx xa = tap_ok ? x1[idx] : make_double2(0, 0), xb = tap_ok ? x2[idx] : make_double2(0, 0);
-            const double pr = (xa.x * ha.x - xa.y * ha.y) + (xb.x * hb.x - xb.y * hb.y);
-            const double pi = (xa.x * ha.y + xa.y * ha.x) + (xb.x * hb.y + xb.y * hb.x);
-            const double yr = sum8(pr), yi = sum8(pi);
+            double yr = (xa.x * ha.x - xa.y * ha.y) + (xb.x * hb.x - xb.y * hb.y);
+            double yi = (xa.x * ha.y + xa.y * ha.x) + (xb.x * hb.y + xb.y * hb.x);
+            sum8x2(yr, yi);
             if (active && frame_ok && t == 0) yo[i] = make_double2(yr, yi);
-            if (active) {
-                const double k = mu * (Rr - yr * yr - yi * yi);
-                const double kr = k * yr, ki = k * yi;
-                ha.x += kr * xa.x + ki * xa.y; ha.y += ki * xa.x - kr * xa.y;
-                hb.x += kr * xb.x + ki * xb.y; hb.y += ki * xb.x - kr * xb.y;
-            }
+            const double k = mua * (Rr - yr * yr - yi * yi);
+            const double kr = k * yr, ki = k * yi;
+            ha.x += kr * xa.x + ki * xa.y; ha.y += ki * xa.x - kr * xa.y;
+            hb.x += kr * xb.x + ki * xb.y; hb.y += ki * xb.x - kr * xb.y;
         }
         double d = hypot(oa.x - ha.x, oa.y - ha.y);
         const double e = hypot(ob.x - hb.x, ob.y - hb.y);
