@@ -262,8 +262,10 @@ __global__ __launch_bounds__(64) void k_cma16(DemuxArgs a)
                 // (a finished frame keeps iterating with mu = 0: its taps stay as they are, no branch in the chain)
                 const double k = mua * (Rr - yr * yr - yi * yi);
                 const double kr = k * yr, ki = k * yi;
-                ha.x += kr * xa.x + ki * xa.y; ha.y += ki * xa.x - kr * xa.y;
-                hb.x += kr * xb.x + ki * xb.y; hb.y += ki * xb.x - kr * xb.y;
+                // h += k y conj(x) as two dependent fused multiply-adds per component (the shortest chain back to the next
+                // symbol's products)
+                ha.x = fma(ki, xa.y, fma(kr, xa.x, ha.x)); ha.y = fma(-kr, xa.y, fma(ki, xa.x, ha.y));
+                hb.x = fma(ki, xb.y, fma(kr, xb.x, hb.x)); hb.y = fma(-kr, xb.y, fma(ki, xb.x, hb.y));
             }
             if (active && frame_ok && t == 0) {
 #pragma unroll
@@ -282,8 +284,8 @@ __global__ __launch_bounds__(64) void k_cma16(DemuxArgs a)
             if (active && frame_ok && t == 0) yo[i] = make_double2(yr, yi);
             const double k = mua * (Rr - yr * yr - yi * yi);
             const double kr = k * yr, ki = k * yi;
-            ha.x += kr * xa.x + ki * xa.y; ha.y += ki * xa.x - kr * xa.y;
-            hb.x += kr * xb.x + ki * xb.y; hb.y += ki * xb.x - kr * xb.y;
+            ha.x = fma(ki, xa.y, fma(kr, xa.x, ha.x)); ha.y = fma(-kr, xa.y, fma(ki, xa.x, ha.y));
+            hb.x = fma(ki, xb.y, fma(kr, xb.x, hb.x)); hb.y = fma(-kr, xb.y, fma(ki, xb.x, hb.y));
         }
         double d = hypot(oa.x - ha.x, oa.y - ha.y);
         const double e = hypot(ob.x - hb.x, ob.y - hb.y);
