@@ -82,7 +82,6 @@ struct DemuxArgs {
     cplx *y;         // [frame][2][L]
     const cplx *M;   // [frame][4] or [4] (m_stride 0)
     cplx *h;         // optional [frame][2][2*taps]: h1(:,1) h1(:,2) | h2(:,1) h2(:,2)
-    cplx *corr;      // workspace [frame][L] of the look-ahead form (k_cma_corr -> k_cma16la), or nullptr
     int *passes;     // optional
     int64_t L;
     int nframes, taps, halftaps, G, logG, m_stride, max_passes, single_pass, dontskip, skipk;
@@ -288,124 +287,6 @@ __global__ __launch_bounds__(64) void k_cma16(DemuxArgs a)
             ha.x = fma(ki, xa.y, fma(kr, xa.x, ha.x)); ha.y = fma(-kr, xa.y, fma(ki, xa.x, ha.y));
             hb.x = fma(ki, xb.y, fma(kr, xb.x, hb.x)); hb.y = fma(-kr, xb.y, fma(ki, xb.x, hb.y));
         }
-        double d = hypot(oa.x - ha.x, oa.y - ha.y);
-        const double e = hypot(ob.x - hb.x, ob.y - hb.y);
-        d = max16(e > d ? e : d);
-        if (active) {
-            npass++;
-            c++;
-            if (d < 5e-5 || !(c < a.max_passes)) active = false;
-        }
-    }
-    if (frame_ok && tap_ok && a.h) { // [h1(:,1) h1(:,2) | h2(:,1) h2(:,2)]
-        cplx *hh = a.h + (size_t)f * 4 * a.taps + (size_t)r * 2 * a.taps;
-        hh[t] = ha; hh[a.taps + t] = hb;
-    }
-    if (frame_ok && l16 == 0 && a.passes) a.passes[f] = npass;
-}
-
-// ---- the same driver with a ONE-SYMBOL LOOK-AHEAD of the recurrence -------------------------------------------------
-// The CMA recurrence is a dependent chain: taps -> products -> 8-lane sum -> y -> k -> taps, ~16 dependent FP64 steps per
-// symbol on the one wave per SIMD this kernel has.  With g_i = k_i y_i (the scalar of the tap update, cmaadaptivefilter.c:
-// 45-53) the next output splits exactly into
-//     y_{i+1} = sum_t xx(i+1+t) h_i(t)  +  g_i * c_i,      c_i = sum_{p,t} xx_p(i+1+t) conj(xx_p(i+t))
-// where h_i are the taps BEFORE the update by g_i and c_i depends on the data only (k_cma_corr fills it once per call;
-// it is the same for every pass and for both output rows).  The sum over the old taps no longer waits for y_i, so the
-// chain per symbol shrinks to  y_i -> k_i -> g_i -> y_{i+1}  while the tap update, the products and their 8-lane
-// reduction for the symbol after run beside it.  Same arithmetic up to the order of two additions per output (the
-// recurrence is contractive: outputs agree with the sequential form to ~1e-13).
-__global__ __launch_bounds__(256) void k_cma_corr(DemuxArgs a)
-{
-    const int64_t L = a.L;
-    const int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gi >= (int64_t)a.nframes * L) return;
-    const int64_t f = gi / L, i = gi - f * L;
-    const cplx *x1 = a.x + (size_t)f * 2 * L, *x2 = x1 + L;
-    cplx acc = make_double2(0, 0);
-    for (int t = 0; t < a.taps; t++) {
-        int64_t i0 = i + t - a.halftaps, i1 = i0 + 1;
-        if (i0 < 0) i0 += L; else if (i0 >= L) i0 -= L;
-        if (i1 < 0) i1 += L; else if (i1 >= L) i1 -= L;
-        acc = cadd(acc, cadd(cmulc(x1[i1], x1[i0]), cmulc(x2[i1], x2[i0])));
-    }
-    a.corr[gi] = acc;
-}
-
-__global__ __launch_bounds__(64) void k_cma16la(DemuxArgs a)
-{
-    const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int l16 = threadIdx.x & 15, r = l16 >> 3, t = l16 & 7;
-    const int grp = gtid >> 4;
-    const bool frame_ok = grp < a.nframes;
-    const int f = frame_ok ? grp : a.nframes - 1;
-    const bool tap_ok = t < a.taps;
-    const int64_t L = a.L;                       // a multiple of CMA_U (launch_demux)
-    const cplx *x1 = a.x + (size_t)f * 2 * L, *x2 = x1 + L;
-    const cplx *cr = a.corr + (size_t)f * L;
-    cplx *yo = a.y + (size_t)f * 2 * L + (size_t)r * L;
-    cplx ha = make_double2(0, 0), hb = ha;       // h_r(t,1), h_r(t,2)
-    if (t == a.halftaps) {
-        const cplx *M = a.M + (size_t)f * a.m_stride;
-        ha = M[2 * r]; hb = M[2 * r + 1];
-    }
-    const double Rr = r ? a.R2 : a.R1, mu = a.mu;
-    const int64_t off = (int64_t)t - a.halftaps;
-    int c = 1, npass = 0;
-    bool active = c < a.max_passes;
-    const int64_t nchunks = L / CMA_U;
-    const cplx zero = make_double2(0, 0);
-    auto xload = [&](const cplx *x, int64_t i) {  // xx(i + t): the driver's cyclic extension (DspPdmCohQpsk.m:161-165)
-        int64_t idx = i + off;
-        if (idx < 0) idx += L; else if (idx >= L) idx -= L;
-        return tap_ok ? x[idx] : zero;
-    };
-    // the first chunk of a pass is also what the last chunk of the previous pass prefetches (cyclic data)
-    cplx ca[CMA_U], cb[CMA_U], cc[CMA_U], na[CMA_U], nb[CMA_U], nc[CMA_U];
-#pragma unroll
-    for (int u = 0; u < CMA_U; u++) { ca[u] = xload(x1, u); cb[u] = xload(x2, u); cc[u] = cr[u]; }
-    while (__any(active)) {
-        const cplx oa = ha, ob = hb;
-        const double mua = active ? mu : 0.0;
-        // B_0 straight from the taps of the pass start; nothing pending (g = 0)
-        double Br = (ca[0].x * ha.x - ca[0].y * ha.y) + (cb[0].x * hb.x - cb[0].y * hb.y);
-        double Bi = (ca[0].x * ha.y + ca[0].y * ha.x) + (cb[0].x * hb.y + cb[0].y * hb.x);
-        sum8x2(Br, Bi);
-        double gr = 0.0, gi = 0.0;               // g_{i-1} = k y of the previous symbol
-        cplx cp = zero, xpa = zero, xpb = zero;  // c_{i-1}, xx_p(i-1+t)
-        for (int64_t ch = 0; ch < nchunks; ch++) {
-            const int64_t i0 = ch * CMA_U, inext = (ch + 1 < nchunks) ? i0 + CMA_U : 0;
-#pragma unroll
-            for (int u = 0; u < CMA_U; u++) { na[u] = xload(x1, inext + u); nb[u] = xload(x2, inext + u); nc[u] = cr[inext + u]; }
-            cplx yk[CMA_U];
-#pragma unroll
-            for (int u = 0; u < CMA_U; u++) {
-                // y_i = B_i + g_{i-1} c_{i-1}
-                const double yr = fma(gr, cp.x, fma(-gi, cp.y, Br));
-                const double yi = fma(gr, cp.y, fma(gi, cp.x, Bi));
-                yk[u] = make_double2(yr, yi);
-                // pending tap update h_i = h_{i-1} + g_{i-1} conj(xx(i-1+t))
-                ha.x = fma(gi, xpa.y, fma(gr, xpa.x, ha.x)); ha.y = fma(-gr, xpa.y, fma(gi, xpa.x, ha.y));
-                hb.x = fma(gi, xpb.y, fma(gr, xpb.x, hb.x)); hb.y = fma(-gr, xpb.y, fma(gi, xpb.x, hb.y));
-                // B_{i+1} = sum_t xx(i+1+t) h_i(t)
-                const cplx xna = (u + 1 < CMA_U) ? ca[(u + 1) % CMA_U] : na[0], xnb = (u + 1 < CMA_U) ? cb[(u + 1) % CMA_U] : nb[0];
-                Br = (xna.x * ha.x - xna.y * ha.y) + (xnb.x * hb.x - xnb.y * hb.y);
-                Bi = (xna.x * ha.y + xna.y * ha.x) + (xnb.x * hb.y + xnb.y * hb.x);
-                sum8x2(Br, Bi);
-                // g_i = k_i y_i  (a finished frame keeps iterating with mu = 0)
-                const double k = mua * (Rr - yr * yr - yi * yi);
-                gr = k * yr; gi = k * yi;
-                cp = cc[u]; xpa = ca[u]; xpb = cb[u];
-            }
-            if (active && frame_ok && t == 0) {
-#pragma unroll
-                for (int u = 0; u < CMA_U; u++) yo[i0 + u] = yk[u];
-            }
-#pragma unroll
-            for (int u = 0; u < CMA_U; u++) { ca[u] = na[u]; cb[u] = nb[u]; cc[u] = nc[u]; }
-        }
-        // flush the pending update of the pass's last symbol
-        ha.x = fma(gi, xpa.y, fma(gr, xpa.x, ha.x)); ha.y = fma(-gr, xpa.y, fma(gi, xpa.x, ha.y));
-        hb.x = fma(gi, xpb.y, fma(gr, xpb.x, hb.x)); hb.y = fma(-gr, xpb.y, fma(gi, xpb.x, hb.y));
         double d = hypot(oa.x - ha.x, oa.y - ha.y);
         const double e = hypot(ob.x - hb.x, ob.y - hb.y);
         d = max16(e > d ? e : d);
@@ -1023,13 +904,7 @@ static int launch_demux(int method, DemuxArgs &a, void *stream)
 {
     if (method == PLX_DEMUX_CMA && !a.single_pass && a.taps <= 8 && a.dontskip && a.L >= 16) {
         const unsigned gx = (unsigned)((a.nframes + 3) / 4); // 4 frames per wave, one wave per workgroup
-        if (a.corr && a.L % CMA_U == 0) {                    // look-ahead form of the recurrence
-            const int64_t n = (int64_t)a.nframes * a.L;
-            PLX_LAUNCH(k_cma_corr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
-            PLX_LAUNCH(k_cma16la, dim3(gx), dim3(64), 0, stream, a);
-        } else {
-            PLX_LAUNCH(k_cma16, dim3(gx), dim3(64), 0, stream, a);
-        }
+        PLX_LAUNCH(k_cma16, dim3(gx), dim3(64), 0, stream, a);
     } else if (method == PLX_DEMUX_CMA) {
         int G = 8;
         while (G < a.taps) G *= 2;
@@ -1049,27 +924,9 @@ static int launch_demux(int method, DemuxArgs &a, void *stream)
     return PLX_OK;
 }
 
-// corr_ws: optional workspace [nframes][L] complex for the look-ahead CMA (the DSP plan owns one); without it the
-// public entry point takes a stream-ordered temporary.
-static int poldemux_run(int method, const double *d_x, double *d_y, int64_t L, int nframes, int32_t taps,
-                        double mu, const double *R, const double *d_M, double *d_h, int32_t *d_passes,
-                        void *stream, cplx *corr_ws);
-
 extern "C" int plx_poldemux_dev(int method, const double *d_x, double *d_y, int64_t L, int nframes, int32_t taps,
                                 double mu, const double *R, const double *d_M, double *d_h, int32_t *d_passes,
                                 void *stream)
-{
-    cplx *ws = nullptr;
-    const bool want = method == PLX_DEMUX_CMA && taps <= 8 && L >= 16 && L % CMA_U == 0 && nframes >= 1;
-    if (want && hipMallocAsync((void **)&ws, sizeof(cplx) * (size_t)nframes * (size_t)L, (hipStream_t)stream) != hipSuccess) ws = nullptr;
-    const int rc = poldemux_run(method, d_x, d_y, L, nframes, taps, mu, R, d_M, d_h, d_passes, stream, ws);
-    if (ws) (void)hipFreeAsync(ws, (hipStream_t)stream);
-    return rc;
-}
-
-static int poldemux_run(int method, const double *d_x, double *d_y, int64_t L, int nframes, int32_t taps,
-                        double mu, const double *R, const double *d_M, double *d_h, int32_t *d_passes,
-                        void *stream, cplx *corr_ws)
 {
     if (!d_x || !d_y || !d_M) PLX_FAIL(PLX_ERR_ARG, "plx_poldemux_dev: null argument");
     if (method != PLX_DEMUX_CMA && method != PLX_DEMUX_EASI && method != PLX_DEMUX_EASI_M)
@@ -1079,7 +936,6 @@ static int poldemux_run(int method, const double *d_x, double *d_y, int64_t L, i
     std::memset(&a, 0, sizeof(a));
     a.x = (const cplx *)d_x; a.y = (cplx *)d_y; a.M = (const cplx *)d_M; a.h = (cplx *)d_h; a.passes = d_passes;
     a.L = L; a.nframes = nframes; a.m_stride = 4; a.mu = mu; a.dontskip = 1; // drivers pass sps = 1 (:179,:231)
-    a.corr = corr_ws;
     double *tmp_h = nullptr;
     if (method == PLX_DEMUX_CMA) {
         if (!R) PLX_FAIL(PLX_ERR_ARG, "plx_poldemux_dev: CMA needs R");
@@ -1197,7 +1053,6 @@ struct plx_dsp {
     int ncol, max_frames;
     cplx *d_a = nullptr, *d_b = nullptr, *d_M = nullptr, *d_h = nullptr, *d_wsc = nullptr;
     cplx *d_Mrot = nullptr; // [2][max_frames][4]: constant rotation matrices of the CMA / EASI drivers (:155-156)
-    cplx *d_corr = nullptr; // [max_frames][L]: data correlations of the look-ahead CMA (k_cma_corr)
     double *d_wsr = nullptr;
     int use_lds = 0;
     size_t lds_cpe = 0;
@@ -1207,7 +1062,7 @@ extern "C" int plx_dsp_destroy(plx_dsp *P)
 {
     if (P) {
         hipFree(P->d_a); hipFree(P->d_b); hipFree(P->d_M); hipFree(P->d_h); hipFree(P->d_wsc); hipFree(P->d_wsr);
-        hipFree(P->d_Mrot); hipFree(P->d_corr);
+        hipFree(P->d_Mrot);
         delete P;
     }
     return PLX_OK;
@@ -1232,8 +1087,7 @@ extern "C" int plx_dsp_create(plx_dsp **out, int64_t Lin, int32_t ncol, int32_t 
     bool ok = hipMalloc((void **)&P->d_a, n * sizeof(cplx)) == hipSuccess &&
               hipMalloc((void **)&P->d_b, n * sizeof(cplx)) == hipSuccess &&
               hipMalloc((void **)&P->d_M, (size_t)max_frames * 4 * sizeof(cplx)) == hipSuccess &&
-              hipMalloc((void **)&P->d_h, (size_t)max_frames * 4 * 64 * sizeof(cplx)) == hipSuccess &&
-              hipMalloc((void **)&P->d_corr, (size_t)max_frames * (size_t)P->L * sizeof(cplx)) == hipSuccess;
+              hipMalloc((void **)&P->d_h, (size_t)max_frames * 4 * 64 * sizeof(cplx)) == hipSuccess;
     if (ok && !P->use_lds)
         ok = hipMalloc((void **)&P->d_wsc, 2 * n * sizeof(cplx)) == hipSuccess &&
              hipMalloc((void **)&P->d_wsr, 2 * n * sizeof(double)) == hipSuccess;
@@ -1277,9 +1131,9 @@ static int demux_stage(plx_dsp *P, int method, cplx *src, cplx *dst, int nframes
                    (cplx *)nullptr, P->d_M, P->L, 0);
     }
     const int kmethod = (method == PLX_DEMUX_EASI && p.mfile_twins) ? PLX_DEMUX_EASI_M : method;   // no MEX compiled: the .m twin
-    return poldemux_run(kmethod, (const double *)src, (double *)dst, P->L, nframes,
-                        method == PLX_DEMUX_CMA ? p.cma_taps : 1, method == PLX_DEMUX_CMA ? p.cma_mu : p.easi_mu,
-                        p.cma_R, (const double *)Min, (double *)P->d_h, nullptr, stream, P->d_corr);
+    return plx_poldemux_dev(kmethod, (const double *)src, (double *)dst, P->L, nframes,
+                            method == PLX_DEMUX_CMA ? p.cma_taps : 1, method == PLX_DEMUX_CMA ? p.cma_mu : p.easi_mu,
+                            p.cma_R, (const double *)Min, (double *)P->d_h, nullptr, stream);
 }
 
 extern "C" int plx_dsp_run_dev(plx_dsp *P, const double *d_in, double *d_out, int nframes, void *stream)
