@@ -375,9 +375,9 @@ def main():
         x = dict(stop=(0.01, 95.0), nmin=100)                   # 1 % relative accuracy at 95 % confidence (ber_estimate.m:128-139)
         camp.simulate(list(range(10 ** 6 + rank * a.mc_frames, 10 ** 6 + (rank + 1) * a.mc_frames)))   # warm-up, not counted
         # mc_estimate (mc_estimate.m:133-212) on a continuous per-realisation sample, the EVM of the recovered symbols,
-        # gathered with the counts: 2 % accuracy of the mean at 95 % confidence
+        # gathered with the counts: 0.1 % accuracy of the mean at 95 % confidence
         sb = mc.ShardedBer(camp.simulate, camp.bits_per_realisation, x, per_rank_per_round=a.mc_frames, device=cdev,
-                           x_samples=dict(stop=(0.02, 95.0), nmin=50))
+                           x_samples=dict(stop=(1e-3, 95.0), nmin=50))
         sync_all()
         t1 = time.perf_counter()
         res = sb.run(max_realisations=a.mc_rounds * a.mc_frames * world)

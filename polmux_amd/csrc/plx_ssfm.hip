@@ -1607,7 +1607,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
         PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         PLX_HIP(hipEventRecord(P->ev, st));
         pending = true;
-        if (chunk < 8) chunk *= 2;
+        if (chunk < (compact_every_step ? 8 : 16)) chunk *= 2;   // (small batches are launch-bound: longer chunks keep the queue fed)
         if (steps > kMaxSteps) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate");
     }
     PLX_HIP(hipMemcpyAsync(P->h_ctl.data(), P->d_ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost, st));
