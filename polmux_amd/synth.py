@@ -66,6 +66,16 @@ def pattern_debruijn(nsymb, seed, alphabet=2):
     return pat, bmat
 
 
+def myseq(locpat, nsymb):
+    """pattern.m:236-258: periodic repetition of locpat up to nsymb symbols, truncated if necessary (user-supplied
+    patterns, pattern(array, ...))."""
+    locpat = np.asarray(locpat).reshape(-1)
+    lp = locpat.size
+    if lp > nsymb:
+        return locpat[:nsymb].copy()
+    return np.concatenate([np.tile(locpat, nsymb // lp), locpat[: nsymb % lp]])
+
+
 # ------------------------------------------------------------- electricsource.m ---
 def _pulse_cosroll(roll, duty, nt):
     el = np.zeros(2 * nt)                               # electricsource.m:246-262

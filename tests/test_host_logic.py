@@ -345,3 +345,11 @@ def test_mygeteyeinfo_best_instant_and_measured_delay():
     # X only
     e1 = px.mygeteyeinfo(irx[:, :2], pat, None, None)
     np.testing.assert_allclose(e1[0], eyeb[:4], atol=1e-12)
+
+
+def test_myseq_doc_examples():
+    """pattern.m:241-242: the two literal examples of the periodic-repetition helper."""
+    from polmux_amd import synth
+    assert synth.myseq([0, 1, 0], 8).tolist() == [0, 1, 0, 0, 1, 0, 0, 1]
+    assert synth.myseq([0, 1, 0, 0, 1, 0], 4).tolist() == [0, 1, 0, 0]
+    assert synth.myseq([1, 0], 6).tolist() == [1, 0, 1, 0, 1, 0]
