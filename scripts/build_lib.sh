@@ -7,7 +7,7 @@ OBJS=""
 for f in polmux_amd/csrc/*.hip; do
   o=build/$(basename ${f%.hip}).o
   if [ ! -f $o ] || [ $f -nt $o ] || [ polmux_amd/csrc/plx_common.h -nt $o ] || [ polmux_amd/csrc/plx_fft.h -nt $o ] || [ include/polmux_hip.h -nt $o ] || [ polmux_amd/csrc/plx_internal.h -nt $o ]; then
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result -c $f -o $o
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result $PLX_EXTRA_HIPCC_FLAGS -c $f -o $o
   fi
   OBJS="$OBJS $o"
 done
