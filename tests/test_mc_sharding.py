@@ -210,3 +210,35 @@ def test_bench_starts_its_own_ranks():
     if torch.cuda.device_count() < 2:
         bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
         assert bad.returncode != 0 and "device(s) visible" in bad.stderr
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_the_contract_fields():
+    """One small `bench.py` run at N = 1: ONE JSON line with the driver's fields, the roofline object of the dominant
+    kernel (real bytes per launch over a live HIP-event duration) and the CPU baseline timed beside it."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PLX_BENCH_REHEARSAL"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "32", "--nsymb", "256",
+                          "--nt", "64", "--variants", "2", "--mc-rounds", "1", "--mc-frames", "8", "--cpu-frames", "2"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["unit"] == "Gsample/s" and d["value"] > 0 and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert r["kernel"] in r["kernels"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    k = r["kernels"][r["kernel"]]
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (k["avg_launch_us"] * 1e-6) / 1e9) < 1e-6 * r["achieved"]
+    assert r["bytes_per_sample_per_launch"] == 64.0 and 0 < r["frac"] < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Gsample/s" and c["value"] > 0 and "frame" in c["sample"]
+    assert d["mc"]["realisations"] == 8 and d["mc"]["evm_mc_estimate"]["nruns"] == 8
