@@ -9,12 +9,14 @@
 #include "hip_emu.h"
 #define PLX_LAUNCH(kern, grid, block, shmem, stream, ...) PLX_EMU_LAUNCH(kern, grid, block, shmem, stream, __VA_ARGS__)
 #define PLX_DYN_LDS(name) char *name = emu::dyn_lds()
+#define PLX_LDS_QUAL
 #else
 #include <hip/hip_runtime.h>
 #define PLX_LAUNCH(kern, grid, block, shmem, stream, ...) \
     hipLaunchKernelGGL(kern, grid, block, shmem, (hipStream_t)(stream), __VA_ARGS__)
 // all LDS lives in the dynamic region, base 16-byte aligned (guide G17)
 #define PLX_DYN_LDS(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define PLX_LDS_QUAL __attribute__((address_space(3)))   // pointer-to-LDS by type (for out-of-line device functions)
 #endif
 
 #include <cstddef>

@@ -67,8 +67,7 @@ struct SsfmArgs {
     const int *active;             // [nframes] frames still propagating, in frame order (k_compact); nullptr: all of them
     int *nactive;                  // [0] length of the list, [1] running sum of it over the steps (utilisation accounting)
     long long spin_ticks;          // frame-barrier timeout in ticks of plx_clock() (10 ns)
-    unsigned long long *slots;     // [F][tiles per frame] per-tile max |u|^2 of the current round (k_colx16), ~0 = not arrived
-    unsigned long long *pubw;      // [F][2] published Leff (or -1: frame finished) of the round, by launch parity, ~0 = not yet
+    unsigned long long *slots;     // [2][nframes][tiles per frame] per-tile max |u|^2 by launch parity (k_colx16), ~0 = not arrived
     int round;                     // launch index of the fused sweep within this propagate call
     int p1, p2, nfc, dual, W, logW, T, logT, R, logR; // column tile: N1 rows x T complex (T = W*npol)
     int spm, xpm, manakov, pmd, nplates, brf_per_frame;
@@ -193,17 +192,19 @@ __global__ __launch_bounds__(256) void k_umax(SsfmArgs a)
 // (:512-551, :585-636) and checkstep (:718-758), one lane per frame.
 // have_pmax: Pmax = max_k gam(k)*Umax(k) (fiber.m:694-698) is handed in by the caller (the fused sweep collects it from
 // the per-tile slots of its frame barrier) instead of being formed from the umax words.
-// ctrl_core works on a copy of the frame's record (the fused sweep keeps the leader's copy in LDS and publishes the
-// result before the record goes back to memory); ctrl_step is load -> ctrl_core -> store.
-template <bool AGENT, class ARGS> __device__ __forceinline__ void ctrl_core(const ARGS &a, int f, FrameCtl &c, bool have_pmax, double pmax_in)
+// The controller comes in two parts.  ctrl_head is what the next nonlinear step waits for: the loop tail of the step just
+// finished, nextstep, the step length and Leff; ctrl_tail (the attenuation of the step and checkstep) is consumed by the row
+// pass and by the NEXT column pass only.  k_ctrl runs them back to back; the fused sweep runs the head in every workgroup of
+// the frame on an LDS copy of the record, and the tail off the critical path in the one workgroup that writes the record back.
+// ctrl_head returns false when the frame is finished (c.done set).
+template <bool AGENT, class ARGS, class REC> __device__ __forceinline__ bool ctrl_head(const ARGS &a, int f, REC &c, bool have_pmax, double pmax_in, bool count = true)
 {
-    if (c.done) return;
     if (c.started) {
         if (a.dual) c.ntot = c.ntot + c.ntrunk - c.nmem; // :529
         if (c.last) {
             c.done = 1;
-            atomicAdd(a.ndone, 1);
-            return;
+            if (count) atomicAdd(a.ndone, 1);      // (fused sweep: the controller runs in every workgroup of the frame, one of them counts)
+            return false;
         }
     }
     // nextstep
@@ -246,13 +247,17 @@ template <bool AGENT, class ARGS> __device__ __forceinline__ void ctrl_core(cons
         c.ncycle = c.ncycle + 1;
     }
     c.dz = dz;
-    double zc;
     if (c.zprop < a.Lf) {
-        c.cur = dz; c.last = 0; zc = c.zprop;
+        c.cur = dz; c.last = 0;
     } else {
-        c.cur = a.Lf - c.zprop + dz; c.last = 1; zc = a.Lf; // :538, :545
+        c.cur = a.Lf - c.zprop + dz; c.last = 1; // :538, :545
     }
     c.leff = (a.alphalin == 0) ? c.cur : (1 - exp(-a.alphalin * c.cur)) / a.alphalin;
+    return true;
+}
+template <class ARGS, class REC> __device__ __forceinline__ void ctrl_tail(const ARGS &a, REC &c)
+{
+    const double zc = c.last ? a.Lf : c.zprop;
     c.att = exp(-(0.5 * a.alphalin) * c.cur);
     if (a.dual) { // checkstep
         const double lcorr = a.lcorr;
@@ -278,8 +283,15 @@ template <bool AGENT, class ARGS> __device__ __forceinline__ void ctrl_core(cons
         }
     }
 }
-// The fused sweep calls the controller OUT OF LINE (one lane of one workgroup per frame and launch): inlined, the libm
-// log / exp constants are hoisted into registers for the whole kernel and push the 16-point register blocks into scratch.
+template <bool AGENT, class ARGS> __device__ __forceinline__ void ctrl_core(const ARGS &a, int f, FrameCtl &c, bool have_pmax, double pmax_in)
+{
+    if (c.done) return;
+    if (ctrl_head<AGENT>(a, f, c, have_pmax, pmax_in)) ctrl_tail(a, c);
+}
+// The fused sweep calls the controller OUT OF LINE: inlined, the libm log / exp constants are hoisted into registers for the
+// whole kernel and push the 16-point register blocks into scratch.  k: the plan's step-control constants, rec: the
+// workgroup's copy of the frame's record, both in LDS (LDS pointers by type: through a generic pointer every field would be
+// a flat access, and scalar arguments would be re-read from the kernel argument segment at every call).
 struct CtrlK {
     double dphimax, alphalin, dzmax, dz0, zdone0, Lf, lcorr;
     int dual, resume, ncycle0, nfc;
@@ -287,17 +299,16 @@ struct CtrlK {
     unsigned long long *umax;
     const double *gam;
 };
-__device__ __noinline__ double ctrl_core_call(double dphimax, double alphalin, double dzmax, double dz0, double zdone0, double Lf, double lcorr,
-                                              int dual_resume, int ncycle0, int *ndone, FrameCtl *rec, double pmax)
-{   // scalar arguments travel in registers (a by-value record goes through the stack).  rec: the leader's copy (LDS).
-    // Returns Leff of the next step, or -1 when the frame has reached the fibre end.
-    CtrlK k;
-    k.dphimax = dphimax; k.alphalin = alphalin; k.dzmax = dzmax; k.dz0 = dz0; k.zdone0 = zdone0; k.Lf = Lf; k.lcorr = lcorr;
-    k.dual = dual_resume & 1; k.resume = dual_resume >> 1; k.ncycle0 = ncycle0; k.nfc = 0; k.ndone = ndone; k.umax = nullptr; k.gam = nullptr;
-    FrameCtl c = *rec;
-    ctrl_core<true>(k, 0, c, true, pmax);
-    *rec = c;
-    return c.done ? -1.0 : c.leff;
+static_assert(sizeof(CtrlK) <= 128, "k_colx16 reserves 128 bytes of LDS for the constants");
+// Returns Leff of the next step, or -1 when the frame has reached the fibre end.
+__device__ __noinline__ double ctrl_head_call(const PLX_LDS_QUAL CtrlK *k, PLX_LDS_QUAL FrameCtl *rec, int count, double pmax)
+{
+    if (!ctrl_head<true>(*k, 0, *rec, true, pmax, count != 0)) return -1.0;
+    return rec->leff;
+}
+__device__ __noinline__ void ctrl_tail_call(const PLX_LDS_QUAL CtrlK *k, PLX_LDS_QUAL FrameCtl *rec)
+{
+    ctrl_tail(*k, *rec);
 }
 template <bool AGENT> __device__ __forceinline__ void ctrl_step(const SsfmArgs &a, int f, bool have_pmax = false, double pmax_in = 0.0)
 {
@@ -832,7 +843,7 @@ __global__ __launch_bounds__(COL_THREADS_MAX) void k_col_inv(SsfmArgs a)
 }
 
 // The rare full-range Kerr step of k_colx16 ('--s-' exact single step: |gamma Leff P| not small), on the tile parked in the
-// exchange buffer, one lane per polarisation pair.  Out of line for the same reason as ctrl_core_call: the argument
+// exchange buffer, one lane per polarisation pair.  Out of line for the same reason as ctrl_head_call: the argument
 // reduction constants of sincos must not live in the registers of the hot loop.
 __device__ __noinline__ void kerr_full_range(int j, int t, double gamleff, int manakov)
 {
@@ -881,6 +892,13 @@ __device__ __forceinline__ void glds16(const cplx *src, cplx *lds_wave_base, int
 __device__ __forceinline__ void glds_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 #endif
 
+#ifdef PLX_STAMPS   // dev build only (scripts/experiments/stamps.sh): where a workgroup's tile time goes, 10 ns wall-clock stamps of thread 0
+__device__ long long g_stamps[32];
+#define PLX_STAMP(i) do { if (tid == 0) { long long now_ = wall_clock64(); long long *st_ = (long long *)(red + 20); const long long d_ = now_ - st_[0]; st_[1 + (i)] += d_; ((long long *)((char *)(lctl + 8) + 128))[i] += d_ * d_; st_[0] = now_; } } while (0)
+#else
+#define PLX_STAMP(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf)
 {
     PLX_DYN_LDS(lds);
@@ -896,41 +914,67 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     const int colt = t & 7;
     const bool isx = t < 8;
     const int lane = tid & 63, row0 = (tid >> 6) * 64;     // this wave stages rows row0 .. row0+63
-    // stage(tl, live): start the asynchronous copy of tile tl into s (live: the tile exists and its frame is still
-    // running -- read by the caller ahead of time, so that no load sits between the decision and the copy)
-    // tile tl = (slot of the active list, tile of the frame).  The list may be a few steps old (small batches rebuild it
-    // once per chunk of steps), so a listed frame is still checked; its flag cannot change before THIS workgroup has met
-    // the frame's barrier, and the check for the next tile is read one tile ahead
+    // stage(tl, f): start the asynchronous copy of tile tl = (slot of the active list, tile of the frame) of frame f into s,
+    // and of the frame's step-control record into this wave's own copy (7 lanes x 16 B): everything the next iteration needs
+    // is then one vmcnt wait away, with no load between its loop top and its first transform.  The list may be a few steps
+    // old (small batches rebuild it once per chunk of steps), so the record's `done` is still checked at the loop top; it
+    // cannot change before THIS workgroup has met the frame's barrier.
+    // (record copies: [iteration parity][wave] -- the copy of the tile in hand is still needed while the next one lands)
     const int total = a.nactive[0] * tiles_pf;
-    auto frame_live = [&](int tl) -> int {
-        if (tl >= total) return 0;
-        return a.ctl[a.active[tl / tiles_pf]].done ? 0 : 1;
-    };
-    auto stage = [&](int tl, int live) -> bool {
-        if (!live) return false;
+    int it = 0;
+    auto stage = [&](int tl, int f, int par) {
+        if (tl >= total) return;
         const int slot = tl / tiles_pf, ti = tl - slot * tiles_pf;
-        const int fc = a.active[slot] * a.nfc + ti / tiles_x, bx = ti % tiles_x;
+        const int fc = f * a.nfc + ti / tiles_x, bx = ti % tiles_x;
         // (lane & 15 == t: the lane stages a piece of the same column of the same polarisation it later works on)
         const cplx *src = fld + ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt + (size_t)(row0 + (lane >> 4)) * N2;
 #pragma unroll
         for (int i = 0; i < 16; i++) glds16(src + (size_t)(4 * i) * N2, s + (size_t)(row0 + 4 * i) * 16, lane);
-        return true;
+        static_assert(sizeof(FrameCtl) % 16 == 0, "the record travels as 16-byte pieces");
+        int ln = lane;
+        pin(ln);                           // (the address is formed here: kept across the tile loop it would sit in scratch)
+        if (ln < (int)(sizeof(FrameCtl) / 16)) glds16((const cplx *)(a.ctl + f) + ln, (cplx *)(lctl + 4 * par + (tid >> 6)), ln);
     };
     int tl = blockIdx.x;
-    bool cur = stage(tl, frame_live(tl));
+#ifdef PLX_STAMPS
+    if (tid == 0) { long long *st_ = (long long *)(red + 20); for (int i = 1; i < 12; i++) st_[i] = 0;   /* red[20..31] */ for (int i = 0; i < 16; i++) ((long long *)((char *)(lctl + 8) + 128))[i] = 0; st_[0] = wall_clock64(); }
+#endif
+    int f = tl < total ? a.active[tl / tiles_pf] : 0;
+    stage(tl, f, 0);
+    // The workgroup of a frame's first tile owns the frame's record: it finishes the controller (ctrl_tail) and writes the
+    // record back LATER, while it waits at the barrier of its next tile (red[8]: the frame owed, or -1).
+    CtrlK *const kk = (CtrlK *)(lctl + 8);
+    if (tid == 0) {
+        red[8] = -1.0;
+        kk->dphimax = a.dphimax; kk->alphalin = a.alphalin; kk->dzmax = a.dzmax; kk->dz0 = a.dz0; kk->zdone0 = a.zdone0; kk->Lf = a.Lf; kk->lcorr = a.lcorr;
+        kk->dual = a.dual ? 1 : 0; kk->resume = a.resume ? 1 : 0; kk->ncycle0 = a.ncycle0; kk->nfc = 0; kk->ndone = a.ndone; kk->umax = nullptr; kk->gam = nullptr;
+    }
+    auto settle = [&](int par) {           // tid 0 only; par: the parity the owed record was staged in
+        const int pf = (int)red[8];
+        if (pf < 0) return;
+        FrameCtl *pr = lctl + 4 * par;
+        if (!pr->done) ctrl_tail_call((const PLX_LDS_QUAL CtrlK *)kk, (PLX_LDS_QUAL FrameCtl *)pr);
+        a.ctl[pf] = *pr;
+        red[8] = -1.0;
+    };
     __syncthreads();                       // twiddles staged
-    while (tl < total) {
+    for (; tl < total; it++) {
+        FrameCtl *const wrec = lctl + 4 * (it & 1) + (tid >> 6);
         const int nxt = tl + gridDim.x;
+        const int nf = nxt < total ? a.active[nxt / tiles_pf] : 0;    // (a scalar load, needed when the next tile is staged)
         const int slot = tl / tiles_pf, ti = tl - slot * tiles_pf;
-        const int f = a.active[slot], c = ti / tiles_x, bx = ti - c * tiles_x, fc = f * a.nfc + c;
-        int nxt_live = frame_live(nxt);
-        if (!cur) { cur = stage(nxt, nxt_live); tl = nxt; continue; }   // (s is free here: every path below ends past its last read of s)
+        const int c = ti / tiles_x, bx = ti - c * tiles_x, fc = f * a.nfc + c;
+        PLX_STAMP(0);                      // loop top
+        glds_landed();                     // this wave's own rows of the tile and its copy of the frame's record are in LDS
+        PLX_STAMP(1);                      // wait for the staged tile
+        if (wrec->done) {                  // a listed frame that has finished meanwhile (the same answer in every wave)
+            if (tid == 0) settle((it & 1) ^ 1);
+            stage(nxt, nf, (it & 1) ^ 1);  // (s is free here: every path below ends past its last read of s, and so far
+            tl = nxt; f = nf;              //  each wave has only touched its own rows)
+            continue;
+        }
         const size_t cbase = ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt;
-        const bool started = a.ctl[f].started != 0;
-        // the frame's leader takes the step-control record along now: at barrier time it is one LDS read away
-        if (tid == 0 && ti == 0) *lctl = a.ctl[f];
-        glds_landed();                     // this wave's own rows of the tile are in LDS
-        pin(nxt_live);
+        const bool started = wrec->started != 0;
         {
             cplx x[16];
 #pragma unroll
@@ -942,13 +986,14 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             }
         }
         __syncthreads();
+        PLX_STAMP(2);                      // r16_dit + exchange write + workgroup barrier
         cplx y[16];                        // point j + 16k
 #pragma unroll
         for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
         double sc = 1.0;
         if (started) {                     // finish step s: ifft (1/N), attenuation (:531-532)
             lvl2_dit256(y, j, tw);
-            sc = a.ctl[f].att * a.invN;
+            sc = wrec->att * a.invN;
         }
         double m = 0;
 #pragma unroll
@@ -963,79 +1008,71 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         m = wave_max(m);
         if ((tid & 63) == 0) red[tid >> 6] = m;
         __syncthreads();
-        // Frame barrier (dz of the next step needs the frame-wide maximum, fiber.m:694-698).  One launch = one round,
-        // so kernel boundaries order the rounds and the protocol needs no read-modify-write at all: every member
-        // stores its tile maximum into its own slot and polls ONE word; the leader (workgroup of the frame's first
-        // tile) polls the slots with a whole wave, runs the step controller and publishes Leff (or -1: finished) in
-        // the word of this launch's parity, having reset the slots and the other parity's word for the next round.
-        {
+        PLX_STAMP(3);                      // exchange read + lvl2_dit + scale + max
+        // Frame barrier (dz of the next step needs the frame-wide maximum, fiber.m:694-698): an all-gather.  Every workgroup
+        // stores its tile maximum into its own slot, then its first wave polls the slots of the whole frame and runs the
+        // step controller itself on its copy of the record (the same inputs, the same instructions: the same step in every
+        // workgroup, to the bit) -- one store-to-load trip across the chip instead of two (members -> leader -> members).
+        // One launch = one round, so kernel boundaries order the rounds and the protocol needs no read-modify-write: the slots
+        // of the two launch parities alternate, and a workgroup empties its slot of the OTHER parity (last read one launch
+        // ago) for the next round.  The workgroup of the frame's first tile writes the record back (k_row reads it) and
+        // counts the finished frame.
+        if (tid < 64) {
             const unsigned par = (unsigned)a.round & 1u;
-            unsigned long long *slots = a.slots + (size_t)f * tiles_pf;
-            unsigned long long *pubw = a.pubw + 2 * (size_t)f;
-            if (ti != 0) {
-                if (tid == 0) {
-                    double mm = red[0];
-                    for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
-                    st_agent(slots + ti, (unsigned long long)__double_as_longlong(mm));
-                    unsigned long long v = ~0ull;
-                    unsigned spins = 0;
-                    bool dead = false;
-                    const long long t0 = plx_clock();
-                    while ((v = ld_agent(pubw + par)) == ~0ull) {
-                        nap();
-                        if ((++spins & 255u) == 0 && (ld_agent((const unsigned *)a.ndone + 1) != 0 || plx_clock() - t0 > a.spin_ticks)) {
-                            st_agent((unsigned *)a.ndone + 1, 1u);   // the frame's partners are not co-resident: abort, store nothing
-                            dead = true;
-                            break;
-                        }
-                    }
-                    const double pv = __longlong_as_double((long long)v);
-                    red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm; red[19] = dead ? 1.0 : 0.0;
+            unsigned long long *slots = a.slots + ((size_t)par * a.nframes + f) * tiles_pf;
+            double mm = red[0];
+            for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
+            const unsigned long long mine = (unsigned long long)__double_as_longlong(mm);
+            if (tid == 0) {
+                st_agent(slots + ti, mine);
+                st_agent(a.slots + ((size_t)(par ^ 1u) * a.nframes + f) * tiles_pf + ti, ~0ull);
+                settle((it & 1) ^ 1);      // (the wait below hides it)
+            }
+            double pm;
+            unsigned spins = 0;
+            bool dead = false;
+            const long long t0 = plx_clock();
+            for (;;) {
+                bool all = true;
+                pm = -INFINITY;
+                for (int i = tid; i < tiles_pf; i += 64) {
+                    const unsigned long long b = (i == ti) ? mine : ld_agent(slots + i);
+                    if (b == ~0ull) all = false;
+                    else { const double gp = a.gam[i / tiles_x] * __longlong_as_double((long long)b); pm = gp > pm ? gp : pm; }
                 }
-            } else if (tid < 64) {
-                double mm = red[0];
-                for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
-                double pm;
-                unsigned spins = 0;
-                bool dead = false;
-                const long long t0 = plx_clock();
-                for (;;) {
-                    bool all = true;
-                    pm = (tid == 0) ? a.gam[c] * mm : -INFINITY;       // the leader's own tile (channel c of tile 0)
-                    for (int i = 1 + tid; i < tiles_pf; i += 64) {
-                        const unsigned long long b = ld_agent(slots + i);
-                        if (b == ~0ull) all = false;
-                        else { const double gp = a.gam[i / tiles_x] * __longlong_as_double((long long)b); pm = gp > pm ? gp : pm; }
-                    }
-                    if (__all(all)) break;
-                    nap();
-                    if ((++spins & 255u) == 0) {           // (wave-uniform: every lane evaluates the same test)
-                        const int late = ld_agent((const unsigned *)a.ndone + 1) != 0 || plx_clock() - t0 > a.spin_ticks;
-                        if (__any(late)) { dead = true; break; }
-                    }
+#ifdef PLX_STAMPS
+                if (tid == 0) ((long long *)(red + 20))[11] += 1;       // (dev) polls
+#endif
+                if (__all(all)) break;
+#ifdef PLX_NOWAIT   // dev build, TIMING ONLY (wrong results): nobody waits for the rest of the frame
+                break;
+#endif
+                nap();
+                if ((++spins & 255u) == 0) {           // (wave-uniform: every lane evaluates the same test)
+                    const int late = ld_agent((const unsigned *)a.ndone + 1) != 0 || plx_clock() - t0 > a.spin_ticks;
+                    if (__any(late)) { dead = true; break; }    // the frame's partners are not co-resident: abort, store nothing
                 }
-                pm = wave_max(pm);
+            }
+            pm = wave_max(pm);
+            PLX_STAMP(8);                  // (dev) slot store -> every slot of the frame seen
+            if (tid == 0) {
                 if (dead) {
-                    if (tid == 0) { st_agent((unsigned *)a.ndone + 1, 1u); red[19] = 1.0; }
+                    st_agent((unsigned *)a.ndone + 1, 1u);
+                    red[19] = 1.0;
                 } else {
-                    for (int i = 1 + tid; i < tiles_pf; i += 64) st_agent(slots + i, ~0ull);
-                    if (tid == 0) {
-                        const double pv = ctrl_core_call(a.dphimax, a.alphalin, a.dzmax, a.dz0, a.zdone0, a.Lf, a.lcorr,
-                                                         (a.dual ? 1 : 0) | (a.resume ? 2 : 0), a.ncycle0, a.ndone, lctl, pm);
-                        st_agent(pubw + (par ^ 1u), ~0ull);
-                        st_agent_f64((double *)(pubw + par), pv);    // the frame is released ...
-                        a.ctl[f] = *lctl;                            // ... before the record goes back (k_row reads it)
-                        red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm; red[19] = 0.0;
-                    }
+                    const double pv = ctrl_head_call((const PLX_LDS_QUAL CtrlK *)kk, (PLX_LDS_QUAL FrameCtl *)wrec, ti == 0, pm);
+                    if (ti == 0) red[8] = (double)f;
+                    red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm; red[19] = 0.0;
                 }
             }
         }
         __syncthreads();
+        PLX_STAMP(4);                      // frame barrier
         if (red[19] != 0.0) return;        // barrier timed out (uniform over the workgroup): no store, no control update
         const double leff = red[16];
         const bool finished = red[17] != 0.0;
         if (finished) {                    // the frame has reached the fibre end: write the field out
-            cur = stage(nxt, nxt_live);    // (every thread is past its reads of s: the barrier above)
+            stage(nxt, nf, (it & 1) ^ 1);  // (every thread is past its reads of s: the barrier above)
 #pragma unroll
             for (int k = 0; k < 16; k++) fld[cbase + (size_t)(j + 16 * k) * N2] = y[k];
         } else {
@@ -1044,33 +1081,40 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                 // |gamleff*P| <= gamleff * (tile maximum): a few mrad under the step controller, so the
                 // Taylor form applies to the whole tile; otherwise ('--s-' exact single step) the rare
                 // full-range path goes through LDS, one thread per polarisation pair.
-                const double sgn = isx ? 1.0 : -1.0;
+                int tq = t;
+                pin(tq);                   // (formed here, per tile: hoisted out of the tile loop the two constants would cost four registers for good)
+                const double sgn = tq < 8 ? 1.0 : -1.0, sgn2 = tq < 8 ? 2.0 : -2.0;
                 if (fabs(gamleff) * red[18] < 0.0625) {
-                    // (one loop per equation: a uniform branch inside the unrolled body would cut it into 32 basic blocks)
+                    // (one loop per equation: a uniform branch inside the unrolled body would cut it into 16 basic blocks)
+                    // A sample's two polarisations sit in the lane pair (t, t^8), and the Kerr rotation is the same arithmetic
+                    // on both: the pair shares the work by SAMPLES instead of doing all of it twice -- the X lane takes sample
+                    // k (its own ux, the partner's uy), the Y lane sample k+8 (its own uy, the partner's ux); each forms both
+                    // outputs of its sample and hands the partner's back.  own / oth = this lane's and the other polarisation.
                     auto kerr16 = [&](auto cn) {
                         constexpr bool CNLSE = decltype(cn)::value;
 #pragma unroll
-                        for (int k = 0; k < 16; k++) {
-                            // own / oth = this lane's and its partner's polarisation of the sample.  Everything the two
-                            // lanes both need (P, nl, s3, the rotation) is formed by the same instructions on the same
-                            // numbers in either lane, so the pair stays consistent to the bit without select chains.
-                            const cplx own = y[k], oth = make_double2(lane_xchg<8>(own.x), lane_xchg<8>(own.y));
+                        for (int k = 0; k < 8; k++) {
+                            const cplx own = isx ? y[k] : y[k + 8], snd = isx ? y[k + 8] : y[k];
+                            const cplx oth = make_double2(lane_xchg<8>(snd.x), lane_xchg<8>(snd.y));
                             const double P = fma(own.y, own.y, own.x * own.x) + fma(oth.y, oth.y, oth.x * oth.x);
                             double sn, cs;
                             sincos_taylor(-gamleff * P, &sn, &cs);
                             const cplx nl = make_double2(cs, sn);
-                            cplx A = cmul(own, nl);
+                            cplx A = cmul(own, nl), B = cmul(oth, nl);
                             if (CNLSE) {
-                                const cplx B = cmul(oth, nl);
                                 // s3 = 2 (Re ux Im uy - Im ux Re uy) (:841-851): on the Y lane own/oth are swapped, the two
                                 // products swap and the difference changes sign exactly
-                                const double s3 = 2 * sgn * __dsub_rn(__dmul_rn(A.x, B.y), __dmul_rn(A.y, B.x));
+                                const double s3 = sgn2 * __dsub_rn(__dmul_rn(A.x, B.y), __dmul_rn(A.y, B.x));
                                 double sp, cp;
                                 sincos_taylor(div3(gamleff * s3), &sp, &cp);
-                                const double sg = sgn * sp;      // ux' = cp ux + sp uy,  uy' = cp uy - sp ux
-                                A = make_double2(cp * A.x + sg * B.x, cp * A.y + sg * B.y);
+                                const double sg = sgn * sp, ng = -sg;   // ux' = cp ux + sp uy,  uy' = cp uy - sp ux
+                                const cplx A2 = make_double2(cp * A.x + sg * B.x, cp * A.y + sg * B.y);
+                                B = make_double2(cp * B.x + ng * A.x, cp * B.y + ng * A.y);
+                                A = A2;
                             }
-                            y[k] = A;
+                            const cplx back = make_double2(lane_xchg<8>(B.x), lane_xchg<8>(B.y));
+                            y[k] = isx ? A : back;
+                            y[k + 8] = isx ? back : A;
                         }
                     };
                     if (a.manakov) kerr16(std::false_type{}); else kerr16(std::true_type{});
@@ -1085,6 +1129,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                     __syncthreads();
                 }
             }
+            PLX_STAMP(5);                  // Kerr step
             lvl2_dif256(y, j, tw);
 #pragma unroll
             for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
@@ -1093,13 +1138,22 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = s[((16 * j + k) << 4) + t];
             __syncthreads();               // the exchange buffer is free: the next tile may land in it ...
-            cur = stage(nxt, nxt_live);
+            PLX_STAMP(6);                  // lvl2_dif + exchange
+            stage(nxt, nf, (it & 1) ^ 1);
             r16_dif(x);                    // ... during the last register transform and the stores of this one
 #pragma unroll
             for (int k = 0; k < 16; k++) fld[cbase + (size_t)(16 * j + k) * N2] = x[k];
+            PLX_STAMP(7);                  // staging issue + r16_dif + stores issued
         }
-        tl = nxt;
+        tl = nxt; f = nf;
+#ifdef PLX_STAMPS
+        if (tid == 0) ((long long *)(red + 20))[10] += 1;
+#endif
     }
+    if (tid == 0) settle((it & 1) ^ 1);
+#ifdef PLX_STAMPS
+    if (tid == 0) { const long long *st_ = (const long long *)(red + 20); for (int i = 0; i < 11; i++) atomicAdd((unsigned long long *)&g_stamps[i], (unsigned long long)st_[1 + i]); for (int i = 0; i < 9; i++) atomicAdd((unsigned long long *)&g_stamps[16 + i], (unsigned long long)((const long long *)(lctl + 8))[i]); }
+#endif
 }
 
 } // namespace
@@ -1121,7 +1175,7 @@ struct plx_ssfm {
     std::vector<FrameCtl> h_ctl;
     int brf_sets = 0;
     size_t lds_col = 0, lds_row = 0;
-    unsigned long long *d_slots = nullptr, *d_pubw = nullptr;   // slot barrier of the fused column sweep
+    unsigned long long *d_slots = nullptr;   // slot barrier of the fused column sweep: [launch parity][frame][tile]
     int fused = 0, fused_grid = 0, tiles_pf = 0;
     int col_threads = 512;         // workgroup size of k_col_fwd / k_col_inv
     int row_threads = ROW_THREADS; // workgroup size of k_row
@@ -1155,7 +1209,7 @@ static void free_plan(plx_ssfm *P)
     if (!P) return;
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
-    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_pubw); hipFree(P->d_active);
+    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_active);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     if (P->ev) hipEventDestroy(P->ev);
     for (hipEvent_t e : P->evpool) hipEventDestroy(e);
@@ -1361,7 +1415,10 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     a.gam = P->d_gam; a.ctl = P->d_ctl; a.umax = P->d_umax; a.ndone = P->d_ndone; a.psum = P->d_psum;
     P->h_ctl.resize(F);
 
-    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double) + sizeof(FrameCtl);
+    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double) + 8 * sizeof(FrameCtl) + 128;   // (128: CtrlK)
+#ifdef PLX_STAMPS
+    P->lds_col += 128;
+#endif
     P->lds_row = ((size_t)(a.dual ? 2 : 1) * a.R * (N2 + N2 / 16) + N2 / 2) * sizeof(cplx);
     P->col_threads = P->lds_col > 80 * 1024 ? 1024 : 512;   // measured: 512-thread column workgroups (2 per CU, 16 waves) beat
                                                             // 256 by 3-12 %; tall tiles of large frames: one workgroup per CU, 16 waves
@@ -1392,12 +1449,11 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             P->fused = 1;
             P->tiles_pf = tiles_pf;
             P->fused_grid = (cap / tiles_pf) * tiles_pf;
-            if (hipMalloc((void **)&P->d_slots, sizeof(unsigned long long) * (size_t)F * tiles_pf) != hipSuccess ||
-                hipMalloc((void **)&P->d_pubw, sizeof(unsigned long long) * 2 * (size_t)F) != hipSuccess) {
+            if (hipMalloc((void **)&P->d_slots, sizeof(unsigned long long) * 2 * (size_t)F * tiles_pf) != hipSuccess) {
                 free_plan(P);
                 PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed");
             }
-            a.slots = P->d_slots; a.pubw = P->d_pubw;
+            a.slots = P->d_slots;
         }
     }
     if (a.pmd && !a.dual) { free_plan(P); PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: PMD needs a dual-polarisation plan"); }
@@ -1512,8 +1568,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     P->slots_launched = 0;
     const bool fused = P->fused != 0;
     if (fused) { // the first fused launch also forms nextstep's initial maximum
-        PLX_HIP(hipMemsetAsync(P->d_slots, 0xFF, sizeof(unsigned long long) * (size_t)nframes * P->tiles_pf, st));   // ~0 = "not arrived"
-        PLX_HIP(hipMemsetAsync(P->d_pubw, 0xFF, sizeof(unsigned long long) * 2 * (size_t)nframes, st));
+        PLX_HIP(hipMemsetAsync(P->d_slots, 0xFF, sizeof(unsigned long long) * 2 * (size_t)nframes * P->tiles_pf, st));   // ~0 = "not arrived"; [parity][frame][tile]
     } else {
         unsigned gx = (unsigned)((P->N + 255) / 256);
         if (gx > 64) gx = 64;
@@ -1970,3 +2025,12 @@ extern "C" int plx_scalar_ssfm_adaptive(double *ur, double *ui, const plx_ssfm_d
     if (nrej_out) *nrej_out = nrej;
     return PLX_OK;
 }
+
+#ifdef PLX_STAMPS
+extern "C" void plx_ssfm_stamps(long long *out, int reset)
+{
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 32);
+    if (reset) { long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
+}
+#endif
