@@ -880,21 +880,60 @@ __device__ __noinline__ void kerr_full_range(int j, int t, double gamleff, int m
 // LDS image of a tile: s[row][16] (256 B per row: 8 columns of ux | 8 of uy); one LDS-DMA instruction of a wave
 // fills 4 consecutive rows (64 lanes x 16 B = 1 KiB, lane-linear), wave w owns rows 64w .. 64w+63 -- exactly the
 // rows its own threads read first, so the landing needs the wave's own vmcnt wait and no workgroup barrier.
+//
+// Landing WITHOUT a vmcnt wait.  A gfx9-family wave has one counter for its loads and its stores, and they retire out of
+// order with respect to each other: waiting for the staged tile through vmcnt means waiting for the acknowledgement of
+// every store of the previous tile as well (~1 us at the top of every tile, the most variable microsecond of the loop, and
+// what varies shows up again as waiting at the frame barrier).  So the copies are issued from inline assembly (the
+// compiler's wait-count pass does not see them and inserts no wait of its own in front of the LDS reads), the frame record
+// goes LAST into a copy whose `done` word holds a sentinel, and the wave spins on that word in LDS: loads return in
+// issue order, so the record's arrival implies the tile's.  The workgroup barriers of the tile loop are bare s_barrier +
+// lgkmcnt waits for the same reason (__syncthreads carries a release fence = a vmcnt wait while stores are in flight).
+#define PLX_REC_SENTINEL 0x7fffffff
+#define COLX_LIST 256          // tiles per workgroup whose frames are listed in LDS at a time
+#define COLX_NFC 64            // channels whose gam the fused sweep keeps in LDS
 #ifdef PLX_EMU
 __device__ __forceinline__ void glds16(const cplx *src, cplx *lds_wave_base, int lane) { lds_wave_base[lane] = *src; }
-__device__ __forceinline__ void glds_landed() {}
+// rows row .. row+63 of a tile: 16 copies of 4 rows each; src: this lane's first element, stride: elements between copies
+__device__ __forceinline__ void glds_rows(const cplx *src, size_t stride, cplx *lds_wave_base, int lane)
+{
+    for (int i = 0; i < 16; i++) glds16(src + i * stride, lds_wave_base + 64 * i, lane);
+}
+__device__ __forceinline__ void lds_barrier() { __syncthreads(); }
+__device__ __forceinline__ int lds_peek(const int *p) { return *(const volatile int *)p; }
+__device__ __forceinline__ void lds_settle() {}
+__device__ __forceinline__ void emu_lockstep() { __syncthreads(); }   // (the emulator's lanes are free-running threads: a wave's lanes meet here)
 #else
 __device__ __forceinline__ void glds16(const cplx *src, cplx *lds_wave_base, int)
 {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+    const unsigned lb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)lds_wave_base);   // (wave-uniform by construction)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lb) : "memory", "m0");
 }
-__device__ __forceinline__ void glds_landed() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void glds_rows(const cplx *src, size_t stride, cplx *lds_wave_base, int)
+{
+    unsigned lb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)lds_wave_base);
+    unsigned long long p = (unsigned long long)src;
+    const unsigned long long st = (unsigned long long)stride * sizeof(cplx);
+#define PLX_GLDS_STEP "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tv_lshl_add_u64 %0, %0, 0, %2\n\ts_add_u32 %1, %1, 0x400\n\t"
+    asm volatile(PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP
+                 PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP
+                 : "+v"(p), "+s"(lb) : "s"(st) : "memory", "m0", "scc");
+#undef PLX_GLDS_STEP
+}
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ int lds_peek(const int *p)
+{
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((unsigned)(size_t)(const __attribute__((address_space(3))) void *)p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void emu_lockstep() {}
 #endif
 
 #ifdef PLX_STAMPS   // dev build only (scripts/experiments/stamps.sh): where a workgroup's tile time goes, 10 ns wall-clock stamps of thread 0
 __device__ long long g_stamps[32];
-#define PLX_STAMP(i) do { if (tid == 0) { long long now_ = wall_clock64(); long long *st_ = (long long *)(red + 20); const long long d_ = now_ - st_[0]; st_[1 + (i)] += d_; ((long long *)((char *)(lctl + 8) + 128))[i] += d_ * d_; st_[0] = now_; } } while (0)
+#define PLX_STAMP(i) do { if (tid == 0) { long long now_ = wall_clock64(); long long *st_ = (long long *)(red + 20); const long long d_ = now_ - st_[0]; st_[1 + (i)] += d_; ((long long *)((char *)(lctl + 8) + 128 + COLX_LIST * sizeof(int) + COLX_NFC * sizeof(double)))[i] += d_ * d_; st_[0] = now_; } } while (0)
 #else
 #define PLX_STAMP(i) do { } while (0)
 #endif
@@ -928,18 +967,34 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         const int fc = f * a.nfc + ti / tiles_x, bx = ti % tiles_x;
         // (lane & 15 == t: the lane stages a piece of the same column of the same polarisation it later works on)
         const cplx *src = fld + ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt + (size_t)(row0 + (lane >> 4)) * N2;
-#pragma unroll
-        for (int i = 0; i < 16; i++) glds16(src + (size_t)(4 * i) * N2, s + (size_t)(row0 + 4 * i) * 16, lane);
+        FrameCtl *const rec = lctl + 4 * par + (tid >> 6);
+        if (lane == (int)(offsetof(FrameCtl, done) / 16)) rec->done = PLX_REC_SENTINEL;   // (the lane whose piece of the record holds the word)
+        lds_settle();                      // (the sentinel is in place before the copy that replaces it can land)
+        glds_rows(src, (size_t)4 * N2, s + (size_t)row0 * 16, lane);
         static_assert(sizeof(FrameCtl) % 16 == 0, "the record travels as 16-byte pieces");
         int ln = lane;
         pin(ln);                           // (the address is formed here: kept across the tile loop it would sit in scratch)
-        if (ln < (int)(sizeof(FrameCtl) / 16)) glds16((const cplx *)(a.ctl + f) + ln, (cplx *)(lctl + 4 * par + (tid >> 6)), ln);
+        if (ln < (int)(sizeof(FrameCtl) / 16)) glds16((const cplx *)(a.ctl + f) + ln, (cplx *)rec, ln);
     };
     int tl = blockIdx.x;
 #ifdef PLX_STAMPS
-    if (tid == 0) { long long *st_ = (long long *)(red + 20); for (int i = 1; i < 12; i++) st_[i] = 0;   /* red[20..31] */ for (int i = 0; i < 16; i++) ((long long *)((char *)(lctl + 8) + 128))[i] = 0; st_[0] = wall_clock64(); }
+    if (tid == 0) { long long *st_ = (long long *)(red + 20); for (int i = 1; i < 12; i++) st_[i] = 0;   /* red[20..31] */ for (int i = 0; i < 16; i++) ((long long *)((char *)(lctl + 8) + 128 + COLX_LIST * sizeof(int) + COLX_NFC * sizeof(double)))[i] = 0; st_[0] = wall_clock64(); }
 #endif
-    int f = tl < total ? a.active[tl / tiles_pf] : 0;
+    // The frames of this workgroup's tiles (tile tl + k * grid: slot tl / tiles_pf + k * (grid / tiles_pf)), read from the
+    // active list once: no global load in the tile loop but the barrier's polls (a load's wait would be a vmcnt wait).
+    int *const alist = (int *)((char *)(lctl + 8) + 128);
+    double *const gaml = (double *)(alist + COLX_LIST);    // gam[channel] (at most COLX_NFC channels: checked by the plan)
+    for (int k = tid; k < a.nfc; k += 256) gaml[k] = a.gam[k];
+    int wb = 0;                            // the list holds the frames of iterations wb .. wb + COLX_LIST - 1
+    auto list_fill = [&]() {
+        for (int k = tid; k < COLX_LIST; k += 256) {
+            const long long tk = (long long)blockIdx.x + (long long)(wb + k) * gridDim.x;
+            alist[k] = tk < total ? a.active[tk / tiles_pf] : 0;
+        }
+        __syncthreads();
+    };
+    list_fill();
+    int f = alist[0];
     stage(tl, f, 0);
     // The workgroup of a frame's first tile owns the frame's record: it finishes the controller (ctrl_tail) and writes the
     // record back LATER, while it waits at the barrier of its next tile (red[8]: the frame owed, or -1).
@@ -961,11 +1016,17 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     for (; tl < total; it++) {
         FrameCtl *const wrec = lctl + 4 * (it & 1) + (tid >> 6);
         const int nxt = tl + gridDim.x;
-        const int nf = nxt < total ? a.active[nxt / tiles_pf] : 0;    // (a scalar load, needed when the next tile is staged)
+        if (it + 1 - wb == COLX_LIST) {    // (rare: the window of the list moves on -- loads and fence-carrying barriers, once per COLX_LIST tiles)
+            __syncthreads();
+            wb = it + 1;
+            list_fill();
+        }
+        const int nf = alist[it + 1 - wb];
         const int slot = tl / tiles_pf, ti = tl - slot * tiles_pf;
         const int c = ti / tiles_x, bx = ti - c * tiles_x, fc = f * a.nfc + c;
         PLX_STAMP(0);                      // loop top
-        glds_landed();                     // this wave's own rows of the tile and its copy of the frame's record are in LDS
+        while (lds_peek(&wrec->done) == PLX_REC_SENTINEL) nap();   // this wave's rows of the tile and its copy of the record are in LDS
+        emu_lockstep();
         PLX_STAMP(1);                      // wait for the staged tile
         if (wrec->done) {                  // a listed frame that has finished meanwhile (the same answer in every wave)
             if (tid == 0) settle((it & 1) ^ 1);
@@ -985,7 +1046,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                 for (int k = 0; k < 16; k++) s[((16 * j + k) << 4) + t] = x[k];
             }
         }
-        __syncthreads();
+        lds_barrier();
         PLX_STAMP(2);                      // r16_dit + exchange write + workgroup barrier
         cplx y[16];                        // point j + 16k
 #pragma unroll
@@ -1007,7 +1068,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         }
         m = wave_max(m);
         if ((tid & 63) == 0) red[tid >> 6] = m;
-        __syncthreads();
+        lds_barrier();
         PLX_STAMP(3);                      // exchange read + lvl2_dit + scale + max
         // Frame barrier (dz of the next step needs the frame-wide maximum, fiber.m:694-698): an all-gather.  Every workgroup
         // stores its tile maximum into its own slot, then its first wave polls the slots of the whole frame and runs the
@@ -1038,7 +1099,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                 for (int i = tid; i < tiles_pf; i += 64) {
                     const unsigned long long b = (i == ti) ? mine : ld_agent(slots + i);
                     if (b == ~0ull) all = false;
-                    else { const double gp = a.gam[i / tiles_x] * __longlong_as_double((long long)b); pm = gp > pm ? gp : pm; }
+                    else { const double gp = gaml[i / tiles_x] * __longlong_as_double((long long)b); pm = gp > pm ? gp : pm; }
                 }
 #ifdef PLX_STAMPS
                 if (tid == 0) ((long long *)(red + 20))[11] += 1;       // (dev) polls
@@ -1066,7 +1127,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         PLX_STAMP(4);                      // frame barrier
         if (red[19] != 0.0) return;        // barrier timed out (uniform over the workgroup): no store, no control update
         const double leff = red[16];
@@ -1077,7 +1138,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             for (int k = 0; k < 16; k++) fld[cbase + (size_t)(j + 16 * k) * N2] = y[k];
         } else {
             if (a.spm) {                   // Kerr step of step s+1 (:832-852) on registers
-                const double gamleff = a.gam[c] * leff;
+                const double gamleff = gaml[c] * leff;
                 // |gamleff*P| <= gamleff * (tile maximum): a few mrad under the step controller, so the
                 // Taylor form applies to the whole tile; otherwise ('--s-' exact single step) the rare
                 // full-range path goes through LDS, one thread per polarisation pair.
@@ -1121,23 +1182,23 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                 } else {
 #pragma unroll
                     for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
-                    __syncthreads();
+                    lds_barrier();
                     if (isx) kerr_full_range(j, t, gamleff, a.manakov);
-                    __syncthreads();
+                    lds_barrier();
 #pragma unroll
                     for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
-                    __syncthreads();
+                    lds_barrier();
                 }
             }
             PLX_STAMP(5);                  // Kerr step
             lvl2_dif256(y, j, tw);
 #pragma unroll
             for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
-            __syncthreads();
+            lds_barrier();
             cplx x[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = s[((16 * j + k) << 4) + t];
-            __syncthreads();               // the exchange buffer is free: the next tile may land in it ...
+            lds_barrier();               // the exchange buffer is free: the next tile may land in it ...
             PLX_STAMP(6);                  // lvl2_dif + exchange
             stage(nxt, nf, (it & 1) ^ 1);
             r16_dif(x);                    // ... during the last register transform and the stores of this one
@@ -1415,7 +1476,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     a.gam = P->d_gam; a.ctl = P->d_ctl; a.umax = P->d_umax; a.ndone = P->d_ndone; a.psum = P->d_psum;
     P->h_ctl.resize(F);
 
-    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double) + 8 * sizeof(FrameCtl) + 128;   // (128: CtrlK)
+    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double) + 8 * sizeof(FrameCtl) + 128 + COLX_LIST * sizeof(int) + COLX_NFC * sizeof(double);   // (128: CtrlK)
 #ifdef PLX_STAMPS
     P->lds_col += 128;
 #endif
@@ -1436,7 +1497,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     // launch, so all of them must be resident together: the grid is sized from the runtime's own occupancy answer
     // for this kernel (block size and dynamic LDS as launched), a multiple of the tiles per frame; a plan whose
     // frame does not fit the chip that way takes the barrier-free three-sweep step.
-    if (a.dual && !tune.no_fuse && a.p1 == 8 && a.W == 8) {
+    if (a.dual && !tune.no_fuse && a.p1 == 8 && a.W == 8 && nfc <= COLX_NFC) {
         int ncu = 256;
         {
             int dev = 0, v = 0;
