@@ -208,7 +208,12 @@ __device__ __forceinline__ double max16(double v)
 // products are DPP-reduced over the 8 tap lanes, the input samples of the next chunk are
 // prefetched while the current chunk runs (the recurrence itself is latency-bound).
 #define CMA_U 8
-__global__ __launch_bounds__(64) void k_cma16(DemuxArgs a)
+// Workgroup = 4 waves = 16 frames.  The waves are independent (no workgroup barrier); they travel together so that a long
+// Monte-Carlo demultiplexing pass running BESIDE the fibre of the next batch sits on a quarter of the CUs, one wave on every
+// SIMD of each, instead of taking one SIMD's registers on every CU of the chip: a 210-VGPR wave leaves room for one
+// 254-VGPR wave of the fused column sweep on its SIMD, so a CU with a CMA wave anywhere holds ONE column workgroup, not two.
+#define CMA16_THREADS 256
+__global__ __launch_bounds__(CMA16_THREADS) void k_cma16(DemuxArgs a)
 {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const int l16 = threadIdx.x & 15, r = l16 >> 3, t = l16 & 7;
@@ -903,8 +908,9 @@ extern "C" int plx_cde_ofde(const double *xr, const double *xi, const double *yr
 static int launch_demux(int method, DemuxArgs &a, void *stream)
 {
     if (method == PLX_DEMUX_CMA && !a.single_pass && a.taps <= 8 && a.dontskip && a.L >= 16) {
-        const unsigned gx = (unsigned)((a.nframes + 3) / 4); // 4 frames per wave, one wave per workgroup
-        PLX_LAUNCH(k_cma16, dim3(gx), dim3(64), 0, stream, a);
+        const int fpw = CMA16_THREADS / 16;                   // 4 frames per wave
+        const unsigned gx = (unsigned)((a.nframes + fpw - 1) / fpw);
+        PLX_LAUNCH(k_cma16, dim3(gx), dim3(CMA16_THREADS), 0, stream, a);
     } else if (method == PLX_DEMUX_CMA) {
         int G = 8;
         while (G < a.taps) G *= 2;

@@ -933,6 +933,8 @@ __device__ __forceinline__ void emu_lockstep() {}
 
 #ifdef PLX_STAMPS   // dev build only (scripts/experiments/stamps.sh): where a workgroup's tile time goes, 10 ns wall-clock stamps of thread 0
 __device__ long long g_stamps[32];
+__device__ long long g_wgwait[1024];
+__device__ long long g_wgend[1024], g_t0;    // per workgroup: wall clock at its exit of the last launch; earliest start   // per workgroup: time between its slot store and the frame's last arrival
 #define PLX_STAMP(i) do { if (tid == 0) { long long now_ = wall_clock64(); long long *st_ = (long long *)(red + 20); const long long d_ = now_ - st_[0]; st_[1 + (i)] += d_; ((long long *)((char *)(lctl + 8) + 128 + COLX_LIST * sizeof(int) + COLX_NFC * sizeof(double)))[i] += d_ * d_; st_[0] = now_; } } while (0)
 #else
 #define PLX_STAMP(i) do { } while (0)
@@ -977,6 +979,9 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         if (ln < (int)(sizeof(FrameCtl) / 16)) glds16((const cplx *)(a.ctl + f) + ln, (cplx *)rec, ln);
     };
     int tl = blockIdx.x;
+#ifdef PLX_XCD_MAJOR   // dev experiment: a frame's tiles on one XCD (static)
+    if ((gridDim.x & 7) == 0) tl = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
+#endif
 #ifdef PLX_STAMPS
     if (tid == 0) { long long *st_ = (long long *)(red + 20); for (int i = 1; i < 12; i++) st_[i] = 0;   /* red[20..31] */ for (int i = 0; i < 16; i++) ((long long *)((char *)(lctl + 8) + 128 + COLX_LIST * sizeof(int) + COLX_NFC * sizeof(double)))[i] = 0; st_[0] = wall_clock64(); }
 #endif
@@ -985,10 +990,11 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     int *const alist = (int *)((char *)(lctl + 8) + 128);
     double *const gaml = (double *)(alist + COLX_LIST);    // gam[channel] (at most COLX_NFC channels: checked by the plan)
     for (int k = tid; k < a.nfc; k += 256) gaml[k] = a.gam[k];
+    const int tl0 = tl;
     int wb = 0;                            // the list holds the frames of iterations wb .. wb + COLX_LIST - 1
     auto list_fill = [&]() {
         for (int k = tid; k < COLX_LIST; k += 256) {
-            const long long tk = (long long)blockIdx.x + (long long)(wb + k) * gridDim.x;
+            const long long tk = (long long)tl0 + (long long)(wb + k) * gridDim.x;
             alist[k] = tk < total ? a.active[tk / tiles_pf] : 0;
         }
         __syncthreads();
@@ -1213,6 +1219,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     }
     if (tid == 0) settle((it & 1) ^ 1);
 #ifdef PLX_STAMPS
+    if (tid == 0 && blockIdx.x < 1024) { g_wgwait[blockIdx.x] += ((const long long *)(red + 20))[1 + 8]; g_wgend[blockIdx.x] = wall_clock64(); }
     if (tid == 0) { const long long *st_ = (const long long *)(red + 20); for (int i = 0; i < 11; i++) atomicAdd((unsigned long long *)&g_stamps[i], (unsigned long long)st_[1 + i]); for (int i = 0; i < 9; i++) atomicAdd((unsigned long long *)&g_stamps[16 + i], (unsigned long long)((const long long *)(lctl + 8))[i]); }
 #endif
 }
@@ -2092,6 +2099,9 @@ extern "C" void plx_ssfm_stamps(long long *out, int reset)
 {
     hipDeviceSynchronize();
     hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 32);
+    hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_wgwait), sizeof(long long) * 1024);
+    hipMemcpyFromSymbol(out + 32 + 1024, HIP_SYMBOL(g_wgend), sizeof(long long) * 1024);
+    if (reset) { static long long zz[1024]; hipMemcpyToSymbol(HIP_SYMBOL(g_wgwait), zz, sizeof(zz)); }
     if (reset) { long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
 }
 #endif

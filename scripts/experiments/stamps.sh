@@ -26,7 +26,7 @@ from polmux_amd import pipeline
 F = int(os.environ["F"])
 hp = pipeline.HotPath(pipeline.HotPathConfig(flag="g-s-", manakov=os.environ["MK"]), max_frames=F)
 lib = _abi.get().lib
-out = (C.c_longlong * 32)()
+out = (C.c_longlong * (32 + 2048))()
 hp.profile(True)
 for r in range(4):
     ux, uy = hp.make_batch(F)
@@ -51,5 +51,16 @@ print("  %-50s %6.2f us per tile" % ("sum", tot + out[8] * 0.01 / tiles))
 u8 = out[8] * 0.01 / tiles
 print("  %-50s %6.2f us per tile  (std %.2f) (inside the frame barrier: the remainder is the step controller + workgroup barrier)" % ("  slot store -> all slots seen", u8, max(out[24] * 1e-4 / tiles - u8 * u8, 0.0) ** 0.5))
 print("  polls per tile %.2f" % (out[10] / tiles))
+import numpy as np
+w = np.array(out[32:32 + 512], dtype=np.float64) * 0.01 / (tiles / 512.0)
+print("  barrier wait per tile by workgroup: min %.2f  median %.2f  max %.2f us" % (w.min(), np.median(w), w.max()))
+print("  by XCD (workgroup id mod 8):", " ".join("%.2f" % w[x::8].mean() for x in range(8)))
+print("  by tile of the frame (id mod 32):", " ".join("%.1f" % w[x::32].mean() for x in range(32)))
+print("  first / second workgroup of a CU (id < 256 / >= 256): %.2f / %.2f" % (w[:256].mean(), w[256:].mean()))
+e = np.array(out[32 + 1024:32 + 1024 + 512], dtype=np.float64) * 0.01
+e -= e.max()
+print("  exit of the last launch, us before the last workgroup, by XCD:", " ".join("%.0f" % e[x::8].mean() for x in range(8)))
+srt = np.argsort(w)
+print("  least waiting workgroups:", " ".join("%d(%.1f)" % (i, w[i]) for i in srt[:16]))
 hp.close()
 PY
