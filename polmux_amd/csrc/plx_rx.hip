@@ -212,7 +212,11 @@ __device__ __forceinline__ double max16(double v)
 // Monte-Carlo demultiplexing pass running BESIDE the fibre of the next batch sits on a quarter of the CUs, one wave on every
 // SIMD of each, instead of taking one SIMD's registers on every CU of the chip: a 210-VGPR wave leaves room for one
 // 254-VGPR wave of the fused column sweep on its SIMD, so a CU with a CMA wave anywhere holds ONE column workgroup, not two.
+#ifdef PLX_EMU
+#define CMA16_THREADS 64      // (the host emulator runs one OS thread per lane: one wave per workgroup keeps its tests short)
+#else
 #define CMA16_THREADS 256
+#endif
 __global__ __launch_bounds__(CMA16_THREADS) void k_cma16(DemuxArgs a)
 {
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
