@@ -571,7 +571,13 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     const int N2 = 1 << a.p2, R = a.R, TSp = row_pitch(N2);
     cplx *s = (cplx *)lds;                       // [npol*R][TSp]
     cplx *tw = s + (size_t)(a.dual ? 2 : 1) * R * TSp;
-    lds_load_twiddles(tw, a.tw2, N2 >> 1, tid, nthr);
+    // the half table of W_N2: with at most one entry per thread (the usual shape) the load is issued HERE and lands in LDS
+    // after the tile's loads have been issued -- one memory round trip for both instead of two in a row
+    const int twn = N2 >> 1;
+    const bool tw_one = twn <= nthr;
+    cplx twv = make_double2(0, 0);
+    if (tw_one) { if (tid < twn) twv = a.tw2[tid]; }
+    else lds_load_twiddles(tw, a.tw2, twn, tid, nthr);
     const size_t N = (size_t)1 << (a.p1 + a.p2);
     const size_t base = (size_t)fc * N;
     const int j0 = blockIdx.x * R;
@@ -613,6 +619,7 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
             }
         }
     }
+    if (tw_one && tid < twn) tw[tid] = twv;
     __syncthreads();
     row_fft_dif(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     const double cur = a.force ? a.f_cur : ctl->cur;
@@ -693,9 +700,14 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 // One workgroup = one row of ONE polarisation (no PMD: the polarisations only share the multiplier), every radix level
 // in registers: 4096 = 16 x 16 x 16, thread j holds points j + 256 k, three register levels per direction (lvl2_dif<256>
 // on W_4096, lvl2_dif<16> on W_256, r16_dif; the inverse mirrors them) with ONE exchange through a padded LDS row between
-// consecutive levels -- four exchanges per row where the LDS-resident k_row makes eleven barrier-separated passes.  The
+// consecutive levels (a thread writes a level's result back where it read its input, so one barrier per exchange) -- four
+// exchanges per row where the LDS-resident k_row makes eleven barrier-separated passes.  The
 // spectrum is left in the bit-reversed order of the in-place transform, where the multiplier tables already are.
 // Twiddles: the compact table of W_4096 (8 KiB); 78 KiB of LDS per workgroup: two per CU.
+// Inter-pass twiddles: the row's table is a geometric sequence, tpass[i] = w^i (w = W_N^k1 of the row), so
+// tpass[tid + 256 k] = tpass[tid] * tpass[256 k]: a thread reads ONE entry and the workgroup shares sixteen (bk, in LDS)
+// instead of 16 entries per thread at either end of the kernel -- 128 KiB less through the L2 per 64-KiB row, for two more
+// complex products per point.
 __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
@@ -709,72 +721,86 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     if (ctl->done) return;
     cplx *s = (cplx *)lds;                       // [4352] padded row: physical(p) = p + (p >> 4)
     cplx *tw = s + 4352;                         // W_4096^{4k}, k < 512, then W_4096^0..3
-    lds_load_twiddles(tw, a.tw2, 516, tid, 256);
+    cplx *bk = tw + 516;                         // tpass[256 k], k < 16
     const size_t N = (size_t)1 << (a.p1 + a.p2);
     const size_t rowbase = (size_t)blockIdx.x << 12;
-    cplx *const u = a.ux + (size_t)fc * N + rowbase;
+    cplx *const u = (blockIdx.z ? a.uy : a.ux) + (size_t)fc * N + rowbase;   // (grid.z: the polarisation)
     const cplx *const tp = a.tpass + rowbase;
+
     const Tw4096 w1{tw};
     const Tw256of4096 w2{tw};
     const int b = tid >> 4, j2 = tid & 15;       // level 2: block b of 256 points, point j2 + 16 k of it
     cplx x[16];
     {
-        cplx tv[16];
+        cplx ta = tp[tid];
 #pragma unroll
-        for (int k = 0; k < 16; k++) { x[k] = u[tid + 256 * k]; tv[k] = tp[tid + 256 * k]; }
+        for (int k = 0; k < 16; k++) x[k] = u[tid + 256 * k];
+        // (the row is asked for first: the tables, a few KiB out of the L2, arrive behind it under the same wait)
+        {
+            const cplx t0 = a.tw2[tid], t1 = a.tw2[tid + 256], t2 = a.tw2[512 + (tid & 3)], t3 = tp[256 * (tid & 15)];
+            tw[tid] = t0; tw[tid + 256] = t1;
+            if (tid < 4) tw[512 + tid] = t2;
+            if (tid < 16) bk[tid] = t3;
+        }
 #pragma unroll
-        for (int k = 0; k < 16; k++) { pin(x[k]); pin(tv[k]); }
+        for (int k = 0; k < 16; k++) pin(x[k]);
+        pin(ta);
+        __syncthreads();                         // twiddles and bk staged
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = cmul(x[k], tv[k]);
+        for (int k = 0; k < 16; k++) x[k] = cmul(x[k], cmul(ta, bk[k]));
     }
-    __syncthreads();                             // twiddles staged
     lvl2_dif<256>(x, tid, w1);
 #pragma unroll
     for (int k = 0; k < 16; k++) s[row_phys(tid + 256 * k)] = x[k];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
-    lvl2_dif<16>(x, j2, w2);
-    __syncthreads();
+    lvl2_dif<16>(x, j2, w2);                     // (written back where this thread read it: no barrier in between)
 #pragma unroll
     for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
     __syncthreads();
+    // the step's multiplier at the 16 bins this thread holds (lin_step :771-773 / matrix_step with matR = I): the phases are
+    // asked for HERE, one exchange and one register level ahead of their use (16 more registers fit beside r16_dif)
+    double btv[16];
+    if (!a.hmul) {
+        const double *bt = a.betat_p + (size_t)c * N + rowbase + 16 * tid;
+#pragma unroll
+        for (int k = 0; k < 16; k++) btv[k] = bt[k];
+    }
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[17 * tid + k];             // row_phys(16 tid + k)
     r16_dif(x);
-    {   // the step's multiplier at the 16 bins this thread holds (lin_step :771-773 / matrix_step with matR = I)
-        int o16 = 16 * tid;
-        pin(o16);
+    {
         if (a.hmul) {
+            int o16 = 16 * tid;
+            pin(o16);
             const cplx *h = a.hmul + rowbase + o16;
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = cmul(h[k], x[k]);
         } else {
             const double cur = a.force ? a.f_cur : ctl->cur;
-            const double *bt = a.betat_p + (size_t)c * N + rowbase + o16;
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = cmul(cexp_neg_turns(bt[k] * cur), x[k]);
+            for (int k = 0; k < 16; k++) x[k] = cmul(cexp_neg_turns(btv[k] * cur), x[k]);
         }
     }
     r16_dit(x);
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) s[17 * tid + k] = x[k];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
     lvl2_dit<16>(x, j2, w2);
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
     __syncthreads();
+    int jo = tid;
+    pin(jo);
+    const cplx tb = tp[jo];                      // (asked for ahead of the last register level)
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[row_phys(tid + 256 * k)];
     lvl2_dit<256>(x, tid, w1);
-    int jo = tid;
-    pin(jo);
 #pragma unroll
-    for (int k = 0; k < 16; k++) u[jo + 256 * k] = cmulc(x[k], tp[jo + 256 * k]);
+    for (int k = 0; k < 16; k++) u[jo + 256 * k] = cmulc(x[k], cmul(tb, bk[k]));
 }
 
 // ------------------------------------------------------ pass 3: inverse columns ---
@@ -1408,7 +1434,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     if (a.dual && (N2 >= 2048 && !tune.no_row_split)) {   // measured: 2^20 frames 74 -> 66 ms; at N2 = 1024 it loses (47 -> 52)
         P->row_split = 1;
         P->rs_threads = N2 / 8 < ROW_THREADS ? ROW_THREADS : (N2 / 8 > 1024 ? 1024 : N2 / 8);
-        P->rs_lds = ((size_t)(N2 + N2 / 16) + (P->tw_compact ? N2 / 8 + 4 : N2 / 2)) * sizeof(cplx);
+        P->rs_lds = ((size_t)(N2 + N2 / 16) + (P->tw_compact ? N2 / 8 + 4 + 16 : N2 / 2)) * sizeof(cplx);   // (+16: k_row4k's bk)
     }
     if (P->tw_compact && (!P->row_split || a.pmd)) {
         free_plan(P);
@@ -1604,10 +1630,13 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         SsfmArgs b = a;
         b.dual = 0; b.R = 1; b.logR = 0;
         const dim3 gs((unsigned)N1, FC), bs((unsigned)P->rs_threads);
+        if (P->tw_compact) {                     // (both polarisations in one launch: one tail instead of two)
+            PLX_LAUNCH(k_row4k, dim3(gs.x, gs.y, 2), dim3(256), P->rs_lds, st, b);
+            return;
+        }
         for (int pol = 0; pol < 2; pol++) {
             if (pol) b.ux = a.uy;
-            if (P->tw_compact) PLX_LAUNCH(k_row4k, gs, dim3(256), P->rs_lds, st, b);
-            else PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
+            PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
         }
         return;
     }

@@ -1,7 +1,7 @@
 #!/bin/bash
 # dev tool: A/B timing of library builds on ONE box (boxes differ by a few per cent).
 # usage: scripts/experiments/ab.sh build <name> [extra hipcc flags]   (here; builds the current sources as polmux_amd/lib/libpolmux_hip_<name>.so)
-#        gpurun -- bash scripts/experiments/ab.sh run <nameA> <nameB> ... [-- frames flag]   ("base" = the library of record)
+#        gpurun -- bash scripts/experiments/ab.sh run <nameA> <nameB> ... [-- frames flag nsymb]   ("base" = the library of record)
 set -e
 cd "$(dirname "$0")/../.."
 if [ "$1" = build ]; then
@@ -21,9 +21,9 @@ fi
 shift
 names=""; while [ $# -gt 0 ] && [ "$1" != "--" ]; do names="$names $1"; shift; done
 [ "$1" = "--" ] && shift
-F=${1:-1024}; FLAG=${2:-g-s-}
+F=${1:-1024}; FLAG=${2:-g-s-}; NSYMB=${3:-1024}
 for rep in 1 2; do for n in $names; do
-ABN=$n F=$F FLAG=$FLAG timeout -k 10 200 python - <<'PY'
+ABN=$n F=$F FLAG=$FLAG NSYMB=$NSYMB timeout -k 10 200 python - <<'PY'
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch
@@ -32,7 +32,7 @@ n = os.environ["ABN"]
 if n != "base": _abi.LIB_PATH = os.path.join(os.path.dirname(_abi.LIB_PATH), "libpolmux_hip_%s.so" % n)
 from polmux_amd import pipeline
 F = int(os.environ["F"])
-hp = pipeline.HotPath(pipeline.HotPathConfig(flag=os.environ["FLAG"]), max_frames=F)
+hp = pipeline.HotPath(pipeline.HotPathConfig(flag=os.environ["FLAG"], nsymb=int(os.environ["NSYMB"])), max_frames=F)
 hp.profile(True)
 ts = []
 for r in range(5):
