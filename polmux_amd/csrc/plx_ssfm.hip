@@ -916,7 +916,11 @@ __device__ __noinline__ void kerr_full_range(int j, int t, double gamleff, int m
 // issue order, so the record's arrival implies the tile's.  The workgroup barriers of the tile loop are bare s_barrier +
 // lgkmcnt waits for the same reason (__syncthreads carries a release fence = a vmcnt wait while stores are in flight).
 #define PLX_REC_SENTINEL 0x7fffffff
+#ifdef PLX_EMU
+#define COLX_LIST 2            // (the emulator's tests walk the window of the list)
+#else
 #define COLX_LIST 256          // tiles per workgroup whose frames are listed in LDS at a time
+#endif
 #define COLX_NFC 64            // channels whose gam the fused sweep keeps in LDS
 #ifdef PLX_EMU
 __device__ __forceinline__ void glds16(const cplx *src, cplx *lds_wave_base, int lane) { lds_wave_base[lane] = *src; }

@@ -151,7 +151,13 @@ static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) {
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
-static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 256; return hipSuccess; }
+// (PLX_EMU_CUS: the emulated device's CU count -- a test sets 1 so that the persistent kernels loop over several tiles)
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int)
+{
+    const char *e = std::getenv("PLX_EMU_CUS");
+    *v = e ? std::atoi(e) : 256;
+    return hipSuccess;
+}
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new emu_event{0}; return hipSuccess; }

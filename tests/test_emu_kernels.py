@@ -311,7 +311,9 @@ def test_emu_sweep_variants(emu, oracle, monkeypatch):
     betat, db1 = _tables(n, nt, fls, 1)
     fields = [_qpsk_field(n, nt, p)[:2] for p in (6.0, 9.0, 12.0)]
     ref = [oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0]) for f in fields]
-    for env in ({}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_P1": "4"}):
+    # (PLX_EMU_CUS=1: a one-CU device -- the fused grid is two workgroups, so each walks the tiles of all three frames, with the
+    # emulator's two-entry window of the frame list moving on under it)
+    for env in ({}, {"PLX_EMU_CUS": "1"}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_P1": "4"}):
         nf = 1 if "PLX_SSFM_P1" in env else 3
         for k, v in env.items():
             monkeypatch.setenv(k, v)
