@@ -84,12 +84,18 @@ __device__ __forceinline__ cplx cexp_neg_turns(double x)
 __device__ __forceinline__ void pin(cplx &) {}
 __device__ __forceinline__ void pin(double &) {}
 __device__ __forceinline__ void pin(int &) {}
+__device__ __forceinline__ void pin_uniform(int &) {}
+__device__ __forceinline__ void sched_fence() {}
 #else
 __device__ __forceinline__ void pin(cplx &v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
 __device__ __forceinline__ void pin(double &v) { asm volatile("" : "+v"(v)); }
 // an index made opaque at this point: loads addressed through it cannot be hoisted above (keeps the live ranges of
 // a later phase's operands out of an earlier, register-hungry phase)
 __device__ __forceinline__ void pin(int &v) { asm volatile("" : "+v"(v)); }
+// the same for a wave-uniform value (stays in a scalar register)
+__device__ __forceinline__ void pin_uniform(int &v) { asm volatile("" : "+s"(v)); }
+// the instruction scheduler moves nothing across this point (keeps the live ranges of unrolled iterations apart)
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
 
 // ---- DPP lane exchange inside a 16-lane row (no LDS crossbar on the critical path) ----

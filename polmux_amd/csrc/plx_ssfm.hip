@@ -69,6 +69,8 @@ struct SsfmArgs {
     long long spin_ticks;          // frame-barrier timeout in ticks of plx_clock() (10 ns)
     unsigned long long *slots;     // [2][nframes][tiles per frame] per-tile max |u|^2 by launch parity (k_colx16), ~0 = not arrived
     int round;                     // launch index of the fused sweep within this propagate call
+    int *grab;                     // [2] frames claimed beyond the first of every team, by launch parity (k_colx16)
+    unsigned long long *mbox;      // [teams][4] the team's frame of iteration k, posted by its first workgroup: (launch, k, frame)
     int p1, p2, nfc, dual, W, logW, T, logT, R, logR; // column tile: N1 rows x T complex (T = W*npol)
     int spm, xpm, manakov, pmd, nplates, brf_per_frame;
     int nframes; // frames of the current propagate call (kernels return at once when all are done)
@@ -916,11 +918,6 @@ __device__ __noinline__ void kerr_full_range(int j, int t, double gamleff, int m
 // issue order, so the record's arrival implies the tile's.  The workgroup barriers of the tile loop are bare s_barrier +
 // lgkmcnt waits for the same reason (__syncthreads carries a release fence = a vmcnt wait while stores are in flight).
 #define PLX_REC_SENTINEL 0x7fffffff
-#ifdef PLX_EMU
-#define COLX_LIST 2            // (the emulator's tests walk the window of the list)
-#else
-#define COLX_LIST 256          // tiles per workgroup whose frames are listed in LDS at a time
-#endif
 #define COLX_NFC 64            // channels whose gam the fused sweep keeps in LDS
 #ifdef PLX_EMU
 __device__ __forceinline__ void glds16(const cplx *src, cplx *lds_wave_base, int lane) { lds_wave_base[lane] = *src; }
@@ -965,7 +962,7 @@ __device__ __forceinline__ void emu_lockstep() {}
 __device__ long long g_stamps[32];
 __device__ long long g_wgwait[1024];
 __device__ long long g_wgend[1024], g_t0;    // per workgroup: wall clock at its exit of the last launch; earliest start   // per workgroup: time between its slot store and the frame's last arrival
-#define PLX_STAMP(i) do { if (tid == 0) { long long now_ = wall_clock64(); long long *st_ = (long long *)(red + 20); const long long d_ = now_ - st_[0]; st_[1 + (i)] += d_; ((long long *)((char *)(lctl + 8) + 128 + COLX_LIST * sizeof(int) + COLX_NFC * sizeof(double)))[i] += d_ * d_; st_[0] = now_; } } while (0)
+#define PLX_STAMP(i) do { if (tid == 0) { long long now_ = wall_clock64(); long long *st_ = (long long *)(red + 20); const long long d_ = now_ - st_[0]; st_[1 + (i)] += d_; ((long long *)((char *)(lctl + 8) + 128 + COLX_NFC * sizeof(double)))[i] += d_ * d_; st_[0] = now_; } } while (0)
 #else
 #define PLX_STAMP(i) do { } while (0)
 #endif
@@ -985,20 +982,38 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     const int colt = t & 7;
     const bool isx = t < 8;
     const int lane = tid & 63, row0 = (tid >> 6) * 64;     // this wave stages rows row0 .. row0+63
-    // stage(tl, f): start the asynchronous copy of tile tl = (slot of the active list, tile of the frame) of frame f into s,
-    // and of the frame's step-control record into this wave's own copy (7 lanes x 16 B): everything the next iteration needs
-    // is then one vmcnt wait away, with no load between its loop top and its first transform.  The list may be a few steps
-    // old (small batches rebuild it once per chunk of steps), so the record's `done` is still checked at the loop top; it
-    // cannot change before THIS workgroup has met the frame's barrier.
+    // Teams.  The grid is a whole number of TEAMS of tiles_pf workgroups; a team takes a frame at a time, workgroup ti of the
+    // team its tile ti (channel c, column block bx: the same every time round).  A team's first frame is slot `team` of the
+    // active list; the further ones are claimed from a counter, one at a time, so a team that runs late -- its workgroups
+    // found no room beside another kernel's waves, or its CUs are slow -- leaves its share to the others instead of holding
+    // the launch up.  The team's first workgroup claims the frame of iteration k+2 while the team sits at the barrier of
+    // iteration k (its second wave does: it has nothing else to do there) and posts it in the team's mailbox; everybody
+    // picks the frame of iteration k+1 up with the polls of barrier k, where it has been lying for a whole iteration.
+    const int nact = a.nactive[0];
+    const int NT = gridDim.x / tiles_pf, team = blockIdx.x / tiles_pf, ti = blockIdx.x - team * tiles_pf;
+    const int c = ti / tiles_x, bx = ti - c * tiles_x;
+    const unsigned long long rtag = (unsigned long long)(((unsigned)a.round + 1u) & 0xfffffu) << 22;
+    unsigned long long *const mbox = a.mbox + 4 * (size_t)team;
+    if (blockIdx.x == 0 && tid == 0) a.grab[(a.round & 1) ^ 1] = 0;        // (the other parity's counter: for the next launch)
+    auto post = [&](int k) {               // the team's first workgroup, thread 64: claim the frame of iteration k and post it
+        const int sl = NT + atomicAdd(a.grab + (a.round & 1), 1);
+        const int fr = sl < nact ? a.active[sl] : -1;
+        st_agent(mbox + (k & 3), ((rtag | (unsigned long long)(k + 1)) << 22) | (unsigned long long)(fr + 1));
+    };
+    auto posted = [&](int k, unsigned long long v) -> bool { return (v >> 22) == (rtag | (unsigned long long)(k + 1)); };
+    // stage(f, par): start the asynchronous copy of this workgroup's tile of frame f into s, and of the frame's step-control
+    // record into this wave's own copy (7 lanes x 16 B): everything the next iteration needs arrives without a load between
+    // its loop top and its first transform.  The list may be a few steps old (small batches rebuild it once per chunk of
+    // steps), so the record's `done` is still checked at the loop top; it cannot change before THIS workgroup has met the
+    // frame's barrier.
     // (record copies: [iteration parity][wave] -- the copy of the tile in hand is still needed while the next one lands)
-    const int total = a.nactive[0] * tiles_pf;
     int it = 0;
-    auto stage = [&](int tl, int f, int par) {
-        if (tl >= total) return;
-        const int slot = tl / tiles_pf, ti = tl - slot * tiles_pf;
-        const int fc = f * a.nfc + ti / tiles_x, bx = ti % tiles_x;
+    auto stage = [&](int f, int par) {
+        const int fc = f * a.nfc + c;
         // (lane & 15 == t: the lane stages a piece of the same column of the same polarisation it later works on)
-        const cplx *src = fld + ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt + (size_t)(row0 + (lane >> 4)) * N2;
+        int lq = lane >> 4;
+        pin(lq);                           // (addresses are formed where they are used: hoisted out of the tile loop they end up in scratch)
+        const cplx *src = fld + ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt + (size_t)(row0 + lq) * N2;
         FrameCtl *const rec = lctl + 4 * par + (tid >> 6);
         if (lane == (int)(offsetof(FrameCtl, done) / 16)) rec->done = PLX_REC_SENTINEL;   // (the lane whose piece of the record holds the word)
         lds_settle();                      // (the sentinel is in place before the copy that replaces it can land)
@@ -1008,30 +1023,15 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         pin(ln);                           // (the address is formed here: kept across the tile loop it would sit in scratch)
         if (ln < (int)(sizeof(FrameCtl) / 16)) glds16((const cplx *)(a.ctl + f) + ln, (cplx *)rec, ln);
     };
-    int tl = blockIdx.x;
-#ifdef PLX_XCD_MAJOR   // dev experiment: a frame's tiles on one XCD (static)
-    if ((gridDim.x & 7) == 0) tl = (int)((blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3));
-#endif
 #ifdef PLX_STAMPS
-    if (tid == 0) { long long *st_ = (long long *)(red + 20); for (int i = 1; i < 12; i++) st_[i] = 0;   /* red[20..31] */ for (int i = 0; i < 16; i++) ((long long *)((char *)(lctl + 8) + 128 + COLX_LIST * sizeof(int) + COLX_NFC * sizeof(double)))[i] = 0; st_[0] = wall_clock64(); }
+    if (tid == 0) { long long *st_ = (long long *)(red + 20); for (int i = 1; i < 12; i++) st_[i] = 0;   /* red[20..31] */ for (int i = 0; i < 16; i++) ((long long *)((char *)(lctl + 8) + 128 + COLX_NFC * sizeof(double)))[i] = 0; st_[0] = wall_clock64(); }
 #endif
-    // The frames of this workgroup's tiles (tile tl + k * grid: slot tl / tiles_pf + k * (grid / tiles_pf)), read from the
-    // active list once: no global load in the tile loop but the barrier's polls (a load's wait would be a vmcnt wait).
-    int *const alist = (int *)((char *)(lctl + 8) + 128);
-    double *const gaml = (double *)(alist + COLX_LIST);    // gam[channel] (at most COLX_NFC channels: checked by the plan)
+    double *const gaml = (double *)((char *)(lctl + 8) + 128);    // gam[channel] (at most COLX_NFC channels: checked by the plan)
     for (int k = tid; k < a.nfc; k += 256) gaml[k] = a.gam[k];
-    const int tl0 = tl;
-    int wb = 0;                            // the list holds the frames of iterations wb .. wb + COLX_LIST - 1
-    auto list_fill = [&]() {
-        for (int k = tid; k < COLX_LIST; k += 256) {
-            const long long tk = (long long)tl0 + (long long)(wb + k) * gridDim.x;
-            alist[k] = tk < total ? a.active[tk / tiles_pf] : 0;
-        }
-        __syncthreads();
-    };
-    list_fill();
-    int f = alist[0];
-    stage(tl, f, 0);
+    int f = team < nact ? a.active[team] : -1;
+    if (f < 0) return;                     // (more teams than frames)
+    stage(f, 0);
+    if (ti == 0 && tid == 64) post(1);     // (the one claim nobody's wait hides: once per launch)
     // The workgroup of a frame's first tile owns the frame's record: it finishes the controller (ctrl_tail) and writes the
     // record back LATER, while it waits at the barrier of its next tile (red[8]: the frame owed, or -1).
     CtrlK *const kk = (CtrlK *)(lctl + 8);
@@ -1049,26 +1049,27 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         red[8] = -1.0;
     };
     __syncthreads();                       // twiddles staged
-    for (; tl < total; it++) {
+    for (;; it++) {
         FrameCtl *const wrec = lctl + 4 * (it & 1) + (tid >> 6);
-        const int nxt = tl + gridDim.x;
-        if (it + 1 - wb == COLX_LIST) {    // (rare: the window of the list moves on -- loads and fence-carrying barriers, once per COLX_LIST tiles)
-            __syncthreads();
-            wb = it + 1;
-            list_fill();
-        }
-        const int nf = alist[it + 1 - wb];
-        const int slot = tl / tiles_pf, ti = tl - slot * tiles_pf;
-        const int c = ti / tiles_x, bx = ti - c * tiles_x, fc = f * a.nfc + c;
+        const int fc = f * a.nfc + c;
         PLX_STAMP(0);                      // loop top
         while (lds_peek(&wrec->done) == PLX_REC_SENTINEL) nap();   // this wave's rows of the tile and its copy of the record are in LDS
         emu_lockstep();
         PLX_STAMP(1);                      // wait for the staged tile
         if (wrec->done) {                  // a listed frame that has finished meanwhile (the same answer in every wave)
-            if (tid == 0) settle((it & 1) ^ 1);
-            stage(nxt, nf, (it & 1) ^ 1);  // (s is free here: every path below ends past its last read of s, and so far
-            tl = nxt; f = nf;              //  each wave has only touched its own rows)
-            continue;
+            if (tid == 0) {
+                settle((it & 1) ^ 1);
+                unsigned long long v;
+                while (!posted(it + 1, v = ld_agent(mbox + ((it + 1) & 3)))) nap();
+                red[9] = (double)((int)(v & 0x3fffffull) - 1);
+            } else if (ti == 0 && tid == 64) {
+                post(it + 2);
+            }
+            lds_barrier();
+            f = (int)red[9];
+            if (f < 0) { it++; break; }
+            stage(f, (it & 1) ^ 1);        // (s is free here: every path below ends past its last read of s, and so far
+            continue;                      //  each wave has only touched its own rows)
         }
         const size_t cbase = ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt;
         const bool started = wrec->started != 0;
@@ -1126,13 +1127,17 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                 settle((it & 1) ^ 1);      // (the wait below hides it)
             }
             double pm;
+            unsigned long long mv = 0;      // (lane 0: the team's mailbox entry of the next iteration, read with the polls)
             unsigned spins = 0;
             bool dead = false;
             const long long t0 = plx_clock();
             for (;;) {
                 bool all = true;
                 pm = -INFINITY;
-                for (int i = tid; i < tiles_pf; i += 64) {
+                if (tid == 0) { mv = ld_agent(mbox + ((it + 1) & 3)); all = posted(it + 1, mv); }
+                int i0 = tid;
+                pin(i0);
+                for (int i = i0; i < tiles_pf; i += 64) {
                     const unsigned long long b = (i == ti) ? mine : ld_agent(slots + i);
                     if (b == ~0ull) all = false;
                     else { const double gp = gaml[i / tiles_x] * __longlong_as_double((long long)b); pm = gp > pm ? gp : pm; }
@@ -1153,6 +1158,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             pm = wave_max(pm);
             PLX_STAMP(8);                  // (dev) slot store -> every slot of the frame seen
             if (tid == 0) {
+                red[9] = (double)((int)(mv & 0x3fffffull) - 1);
                 if (dead) {
                     st_agent((unsigned *)a.ndone + 1, 1u);
                     red[19] = 1.0;
@@ -1162,6 +1168,8 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                     red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm; red[19] = 0.0;
                 }
             }
+        } else if (ti == 0 && tid == 64) {
+            post(it + 2);                  // (this wave only waits for the first one here)
         }
         lds_barrier();
         PLX_STAMP(4);                      // frame barrier
@@ -1169,7 +1177,8 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         const double leff = red[16];
         const bool finished = red[17] != 0.0;
         if (finished) {                    // the frame has reached the fibre end: write the field out
-            stage(nxt, nf, (it & 1) ^ 1);  // (every thread is past its reads of s: the barrier above)
+            const int nf = (int)red[9];    // (the team's next frame, or -1: none left)
+            if (nf >= 0) stage(nf, (it & 1) ^ 1);  // (every thread is past its reads of s: the barrier above)
 #pragma unroll
             for (int k = 0; k < 16; k++) fld[cbase + (size_t)(j + 16 * k) * N2] = y[k];
         } else {
@@ -1191,6 +1200,9 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                         constexpr bool CNLSE = decltype(cn)::value;
 #pragma unroll
                         for (int k = 0; k < 8; k++) {
+                            int tk = tq;
+                            pin(tk);               // (the pair's operands are selected HERE: not for all pairs ahead of the loop,
+                            const bool isx = tk < 8;   //  nor -- common to the two equations -- ahead of the branch between them)
                             const cplx own = isx ? y[k] : y[k + 8], snd = isx ? y[k + 8] : y[k];
                             const cplx oth = make_double2(lane_xchg<8>(snd.x), lane_xchg<8>(snd.y));
                             const double P = fma(own.y, own.y, own.x * own.x) + fma(oth.y, oth.y, oth.x * oth.x);
@@ -1212,7 +1224,8 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                             const cplx back = make_double2(lane_xchg<8>(B.x), lane_xchg<8>(B.y));
                             y[k] = isx ? A : back;
                             y[k + 8] = isx ? back : A;
-                        }
+                            sched_fence();         // (one sample pair at a time: a lone wave's FP64 rate does not depend on
+                        }                          //  interleaving, and the pairs' operands need not all be selected up front)
                     };
                     if (a.manakov) kerr16(std::false_type{}); else kerr16(std::true_type{});
                 } else {
@@ -1236,16 +1249,20 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             for (int k = 0; k < 16; k++) x[k] = s[((16 * j + k) << 4) + t];
             lds_barrier();               // the exchange buffer is free: the next tile may land in it ...
             PLX_STAMP(6);                  // lvl2_dif + exchange
-            stage(nxt, nf, (it & 1) ^ 1);
+            {
+                const int nf = (int)red[9];
+                if (nf >= 0) stage(nf, (it & 1) ^ 1);
+            }
             r16_dif(x);                    // ... during the last register transform and the stores of this one
 #pragma unroll
             for (int k = 0; k < 16; k++) fld[cbase + (size_t)(16 * j + k) * N2] = x[k];
             PLX_STAMP(7);                  // staging issue + r16_dif + stores issued
         }
-        tl = nxt; f = nf;
+        f = (int)red[9];
 #ifdef PLX_STAMPS
         if (tid == 0) ((long long *)(red + 20))[10] += 1;
 #endif
+        if (f < 0) { it++; break; }
     }
     if (tid == 0) settle((it & 1) ^ 1);
 #ifdef PLX_STAMPS
@@ -1274,6 +1291,8 @@ struct plx_ssfm {
     int brf_sets = 0;
     size_t lds_col = 0, lds_row = 0;
     unsigned long long *d_slots = nullptr;   // slot barrier of the fused column sweep: [launch parity][frame][tile]
+    unsigned long long *d_mbox = nullptr;    // [teams][4] mailboxes of the fused column sweep's teams, then the two claim counters
+    size_t mbox_bytes = 0;
     int fused = 0, fused_grid = 0, tiles_pf = 0;
     int col_threads = 512;         // workgroup size of k_col_fwd / k_col_inv
     int row_threads = ROW_THREADS; // workgroup size of k_row
@@ -1307,7 +1326,7 @@ static void free_plan(plx_ssfm *P)
     if (!P) return;
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
-    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_active);
+    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     if (P->ev) hipEventDestroy(P->ev);
     for (hipEvent_t e : P->evpool) hipEventDestroy(e);
@@ -1513,7 +1532,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     a.gam = P->d_gam; a.ctl = P->d_ctl; a.umax = P->d_umax; a.ndone = P->d_ndone; a.psum = P->d_psum;
     P->h_ctl.resize(F);
 
-    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double) + 8 * sizeof(FrameCtl) + 128 + COLX_LIST * sizeof(int) + COLX_NFC * sizeof(double);   // (128: CtrlK)
+    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double) + 8 * sizeof(FrameCtl) + 128 + COLX_NFC * sizeof(double);   // (128: CtrlK)
 #ifdef PLX_STAMPS
     P->lds_col += 128;
 #endif
@@ -1547,11 +1566,15 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             P->fused = 1;
             P->tiles_pf = tiles_pf;
             P->fused_grid = (cap / tiles_pf) * tiles_pf;
-            if (hipMalloc((void **)&P->d_slots, sizeof(unsigned long long) * 2 * (size_t)F * tiles_pf) != hipSuccess) {
+            P->mbox_bytes = sizeof(unsigned long long) * (4 * (size_t)(P->fused_grid / tiles_pf) + 1);
+            if (hipMalloc((void **)&P->d_slots, sizeof(unsigned long long) * 2 * (size_t)F * tiles_pf) != hipSuccess ||
+                hipMalloc((void **)&P->d_mbox, P->mbox_bytes) != hipSuccess) {
                 free_plan(P);
                 PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed");
             }
             a.slots = P->d_slots;
+            a.mbox = P->d_mbox;
+            a.grab = (int *)(P->d_mbox + 4 * (size_t)(P->fused_grid / tiles_pf));
         }
     }
     if (a.pmd && !a.dual) { free_plan(P); PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: PMD needs a dual-polarisation plan"); }
@@ -1670,6 +1693,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     const bool fused = P->fused != 0;
     if (fused) { // the first fused launch also forms nextstep's initial maximum
         PLX_HIP(hipMemsetAsync(P->d_slots, 0xFF, sizeof(unsigned long long) * 2 * (size_t)nframes * P->tiles_pf, st));   // ~0 = "not arrived"; [parity][frame][tile]
+        PLX_HIP(hipMemsetAsync(P->d_mbox, 0, P->mbox_bytes, st));                                                      // no entry posted, nothing claimed
     } else {
         unsigned gx = (unsigned)((P->N + 255) / 256);
         if (gx > 64) gx = 64;
