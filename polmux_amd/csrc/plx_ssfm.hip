@@ -70,7 +70,9 @@ struct SsfmArgs {
     unsigned long long *slots;     // [2][nframes][tiles per frame] per-tile max |u|^2 by launch parity (k_colx16), ~0 = not arrived
     int round;                     // launch index of the fused sweep within this propagate call
     int *grab;                     // [2] frames claimed beyond the first of every team, by launch parity (k_colx16)
-    unsigned long long *mbox;      // [teams][4] the team's frame of iteration k, posted by its first workgroup: (launch, k, frame)
+    unsigned long long *mbox;      // [teams][mbox_stride] the team's frame of iteration k, posted by its first workgroup: (launch, k, frame)
+    int mbox_stride;               // entries per team: one per iteration a team can reach in a launch (no reuse: a team's workgroups
+                                   // run through finished frames of a stale list without meeting, and its first may be far ahead)
     int p1, p2, nfc, dual, W, logW, T, logT, R, logR; // column tile: N1 rows x T complex (T = W*npol)
     int spm, xpm, manakov, pmd, nplates, brf_per_frame;
     int nframes; // frames of the current propagate call (kernels return at once when all are done)
@@ -989,16 +991,18 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     // the launch up.  The team's first workgroup claims the frame of iteration k+2 while the team sits at the barrier of
     // iteration k (its second wave does: it has nothing else to do there) and posts it in the team's mailbox; everybody
     // picks the frame of iteration k+1 up with the polls of barrier k, where it has been lying for a whole iteration.
+    // The mailbox is a log, one entry per iteration and no reuse within a launch: through finished frames of a stale list the
+    // team's workgroups run without meeting, and its first may be any number of iterations ahead of its slowest.
     const int nact = a.nactive[0];
     const int NT = gridDim.x / tiles_pf, team = blockIdx.x / tiles_pf, ti = blockIdx.x - team * tiles_pf;
     const int c = ti / tiles_x, bx = ti - c * tiles_x;
     const unsigned long long rtag = (unsigned long long)(((unsigned)a.round + 1u) & 0xfffffu) << 22;
-    unsigned long long *const mbox = a.mbox + 4 * (size_t)team;
+    unsigned long long *const mbox = a.mbox + (size_t)a.mbox_stride * team;
     if (blockIdx.x == 0 && tid == 0) a.grab[(a.round & 1) ^ 1] = 0;        // (the other parity's counter: for the next launch)
     auto post = [&](int k) {               // the team's first workgroup, thread 64: claim the frame of iteration k and post it
         const int sl = NT + atomicAdd(a.grab + (a.round & 1), 1);
         const int fr = sl < nact ? a.active[sl] : -1;
-        st_agent(mbox + (k & 3), ((rtag | (unsigned long long)(k + 1)) << 22) | (unsigned long long)(fr + 1));
+        if (k < a.mbox_stride) st_agent(mbox + k, ((rtag | (unsigned long long)(k + 1)) << 22) | (unsigned long long)(fr + 1));
     };
     auto posted = [&](int k, unsigned long long v) -> bool { return (v >> 22) == (rtag | (unsigned long long)(k + 1)); };
     // stage(f, par): start the asynchronous copy of this workgroup's tile of frame f into s, and of the frame's step-control
@@ -1049,6 +1053,8 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         red[8] = -1.0;
     };
     __syncthreads();                       // twiddles staged
+    // (red[10 + (it & 1)]: the team's next frame, by iteration parity -- the waves of a workgroup read it at their own pace at the
+    //  end of an iteration, and the next iteration may write its successor with no workgroup barrier in between)
     for (;; it++) {
         FrameCtl *const wrec = lctl + 4 * (it & 1) + (tid >> 6);
         const int fc = f * a.nfc + c;
@@ -1060,13 +1066,24 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             if (tid == 0) {
                 settle((it & 1) ^ 1);
                 unsigned long long v;
-                while (!posted(it + 1, v = ld_agent(mbox + ((it + 1) & 3)))) nap();
-                red[9] = (double)((int)(v & 0x3fffffull) - 1);
+                unsigned spins = 0;
+                bool dead = false;
+                const long long t0 = plx_clock();
+                while (!posted(it + 1, v = ld_agent(mbox + (it + 1)))) {
+                    nap();
+                    if ((++spins & 255u) == 0 && (ld_agent((const unsigned *)a.ndone + 1) != 0 || plx_clock() - t0 > a.spin_ticks)) {
+                        st_agent((unsigned *)a.ndone + 1, 1u);      // (the same sticky abort as the frame barrier's)
+                        dead = true;
+                        break;
+                    }
+                }
+                red[10 + (it & 1)] = dead ? -2.0 : (double)((int)(v & 0x3fffffull) - 1);
             } else if (ti == 0 && tid == 64) {
                 post(it + 2);
             }
             lds_barrier();
-            f = (int)red[9];
+            f = (int)red[10 + (it & 1)];
+            if (f == -2) return;           // (timed out: uniform over the workgroup)
             if (f < 0) { it++; break; }
             stage(f, (it & 1) ^ 1);        // (s is free here: every path below ends past its last read of s, and so far
             continue;                      //  each wave has only touched its own rows)
@@ -1134,7 +1151,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             for (;;) {
                 bool all = true;
                 pm = -INFINITY;
-                if (tid == 0) { mv = ld_agent(mbox + ((it + 1) & 3)); all = posted(it + 1, mv); }
+                if (tid == 0) { mv = ld_agent(mbox + (it + 1)); all = posted(it + 1, mv); }
                 int i0 = tid;
                 pin(i0);
                 for (int i = i0; i < tiles_pf; i += 64) {
@@ -1158,7 +1175,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             pm = wave_max(pm);
             PLX_STAMP(8);                  // (dev) slot store -> every slot of the frame seen
             if (tid == 0) {
-                red[9] = (double)((int)(mv & 0x3fffffull) - 1);
+                red[10 + (it & 1)] = (double)((int)(mv & 0x3fffffull) - 1);
                 if (dead) {
                     st_agent((unsigned *)a.ndone + 1, 1u);
                     red[19] = 1.0;
@@ -1177,7 +1194,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         const double leff = red[16];
         const bool finished = red[17] != 0.0;
         if (finished) {                    // the frame has reached the fibre end: write the field out
-            const int nf = (int)red[9];    // (the team's next frame, or -1: none left)
+            const int nf = (int)red[10 + (it & 1)];    // (the team's next frame, or -1: none left)
             if (nf >= 0) stage(nf, (it & 1) ^ 1);  // (every thread is past its reads of s: the barrier above)
 #pragma unroll
             for (int k = 0; k < 16; k++) fld[cbase + (size_t)(j + 16 * k) * N2] = y[k];
@@ -1250,7 +1267,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             lds_barrier();               // the exchange buffer is free: the next tile may land in it ...
             PLX_STAMP(6);                  // lvl2_dif + exchange
             {
-                const int nf = (int)red[9];
+                const int nf = (int)red[10 + (it & 1)];
                 if (nf >= 0) stage(nf, (it & 1) ^ 1);
             }
             r16_dif(x);                    // ... during the last register transform and the stores of this one
@@ -1258,7 +1275,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             for (int k = 0; k < 16; k++) fld[cbase + (size_t)(16 * j + k) * N2] = x[k];
             PLX_STAMP(7);                  // staging issue + r16_dif + stores issued
         }
-        f = (int)red[9];
+        f = (int)red[10 + (it & 1)];
 #ifdef PLX_STAMPS
         if (tid == 0) ((long long *)(red + 20))[10] += 1;
 #endif
@@ -1291,7 +1308,7 @@ struct plx_ssfm {
     int brf_sets = 0;
     size_t lds_col = 0, lds_row = 0;
     unsigned long long *d_slots = nullptr;   // slot barrier of the fused column sweep: [launch parity][frame][tile]
-    unsigned long long *d_mbox = nullptr;    // [teams][4] mailboxes of the fused column sweep's teams, then the two claim counters
+    unsigned long long *d_mbox = nullptr;    // [teams][frames + 4] mailboxes of the fused column sweep's teams, then the two claim counters
     size_t mbox_bytes = 0;
     int fused = 0, fused_grid = 0, tiles_pf = 0;
     int col_threads = 512;         // workgroup size of k_col_fwd / k_col_inv
@@ -1566,7 +1583,8 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             P->fused = 1;
             P->tiles_pf = tiles_pf;
             P->fused_grid = (cap / tiles_pf) * tiles_pf;
-            P->mbox_bytes = sizeof(unsigned long long) * (4 * (size_t)(P->fused_grid / tiles_pf) + 1);
+            const int mstride = F + 4;       // (iterations of a team in a launch <= frames listed; its first workgroup posts two ahead)
+            P->mbox_bytes = sizeof(unsigned long long) * ((size_t)mstride * (P->fused_grid / tiles_pf) + 1);
             if (hipMalloc((void **)&P->d_slots, sizeof(unsigned long long) * 2 * (size_t)F * tiles_pf) != hipSuccess ||
                 hipMalloc((void **)&P->d_mbox, P->mbox_bytes) != hipSuccess) {
                 free_plan(P);
@@ -1574,7 +1592,8 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             }
             a.slots = P->d_slots;
             a.mbox = P->d_mbox;
-            a.grab = (int *)(P->d_mbox + 4 * (size_t)(P->fused_grid / tiles_pf));
+            a.mbox_stride = mstride;
+            a.grab = (int *)(P->d_mbox + (size_t)mstride * (P->fused_grid / tiles_pf));
         }
     }
     if (a.pmd && !a.dual) { free_plan(P); PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: PMD needs a dual-polarisation plan"); }
@@ -1712,7 +1731,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     // steps are launch-bound: the sweeps skip a listed frame that has finished meanwhile)
     const bool compact_every_step = nframes >= 64;
     int chunk = 4, steps = 0;
-    const int kMaxSteps = 1 << 22;
+    const int kMaxSteps = getenv("PLX_DBG_MAX_STEPS") ? atoi(getenv("PLX_DBG_MAX_STEPS")) : (1 << 22);
     bool pending = false, aborted = false;
     // profiling: an event in front of every launch of the loop (and one after the last); intervals are attributed to
     // the kernel class that follows the event.  Classes: 0 k_colx16 / k_col_fwd, 1 k_row, 2 k_col_inv, 3 control.
@@ -1788,7 +1807,19 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
         PLX_HIP(hipEventRecord(P->ev, st));
         pending = true;
         if (chunk < (compact_every_step ? 8 : 16)) chunk *= 2;   // (small batches are launch-bound: longer chunks keep the queue fed)
-        if (steps > kMaxSteps) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate");
+        if (steps > kMaxSteps) {
+            if (getenv("PLX_DBG_MAX_STEPS")) {
+                hipStreamSynchronize(st);
+                std::vector<FrameCtl> hc(nframes);
+                hipMemcpy(hc.data(), P->d_ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost);
+                int hd[4]; hipMemcpy(hd, P->d_ndone, sizeof(hd), hipMemcpyDeviceToHost);
+                fprintf(stderr, "DBG steps %d ndone %d abort %d nactive %d FC %u\n", steps, hd[0], hd[1], hd[2], FC);
+                for (int i = 0; i < nframes; i++)
+                    fprintf(stderr, "DBG frame %d: started %d last %d done %d ncycle %d zprop %.6g dz %.6g cur %.6g leff %.6g att %.6g\n", i, hc[i].started, hc[i].last,
+                            hc[i].done, hc[i].ncycle, hc[i].zprop, hc[i].dz, hc[i].cur, hc[i].leff, hc[i].att);
+            }
+            PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate");
+        }
     }
     PLX_HIP(hipMemcpyAsync(P->h_ctl.data(), P->d_ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost, st));
     PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 4 * sizeof(int), hipMemcpyDeviceToHost, st));

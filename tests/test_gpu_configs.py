@@ -288,6 +288,42 @@ def test_power_ladder_batch_every_frame_keeps_the_reference_step_count(lib, orac
     hp.close()
 
 
+def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monkeypatch):
+    """Config[4]'s shape in small: 8 frames of 2^20 samples on a steep launch-power ladder, three spans.  A 2^20 frame is ONE
+    team of the fused column sweep (512 tiles = the whole grid), and batches under 64 frames rebuild the active list only once
+    per chunk of steps -- so most of the time the team walks a STALE list, running through finished frames without meeting at
+    a barrier while its first workgroup posts the next frames ahead.  (A ring of four mailbox entries used to be overwritten
+    there before the slowest workgroup had read it: the launch never ended.  The mailbox is a log now.)  Property instead of
+    the oracle at this size: the fused sweep and the barrier-free three-sweep step give the same step counts and fields."""
+    import torch
+    from polmux_amd import pipeline
+    F = 8
+    dbm = -4.0 + 12.0 * np.arange(F) / (F - 1)
+    out = []
+    for env in ({}, {"PLX_SSFM_NO_FUSE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, nspans=3)
+        hp = pipeline.HotPath(cfg, max_frames=F)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert hp.fused() == (not env)
+        scale = 10 ** (dbm / 10) / cfg.pavg_mw
+        ux, uy = hp.make_batch(F, scale)
+        hp.fibre(ux, uy)
+        _sync()
+        out.append((hp.last_ncycle(F).copy(), hp.ssfm_stats()[1], ux.cpu().numpy(), uy.cpu().numpy()))
+        hp.close()
+        del ux, uy
+        torch.cuda.empty_cache()
+    (nc0, st0, x0, y0), (nc1, st1, x1, y1) = out
+    assert nc0.tolist() == nc1.tolist() and st0 == st1
+    assert max(nc0) >= 4 * min(nc0)
+    for f in range(F):
+        assert np.abs(x0[f] - x1[f]).max() <= FIELD_RTOL * np.abs(x1[f]).max()
+        assert np.abs(y0[f] - y1[f]).max() <= FIELD_RTOL * np.abs(y1[f]).max()
+
+
 def test_front_end_at_2pow20_uses_the_long_row_filter_pass(lib, oracle):
     """The coherent front end of a 2^20-sample frame: its two spectral filters run on the plan's FFT engine, i.e. through
     the 256 x 4096 split and the 4096-point row pass k_row4k with a general multiplier table -- photocurrents against the
