@@ -92,7 +92,9 @@ int plx_ssfm_set_birefringence_dev(plx_ssfm *plan, const double *db0, const doub
  * (or filter) call may be in flight per plan; different plans may run from different
  * host threads / streams.
  * Dual-polarisation plans with 256-row column tiles use a fused sweep (k_colx16) whose
- * workgroups of one frame meet at a barrier inside the launch.  Its grid is sized at
+ * workgroups of one frame meet at a barrier inside the launch (the grid is a whole number
+ * of such teams; a team claims frames one at a time, so one that is displaced by another
+ * kernel's waves leaves its share to the others).  Its grid is sized at
  * plan creation from hipOccupancyMaxActiveBlocksPerMultiprocessor for that kernel, so
  * the frame's workgroups are co-resident on a GPU the process has to itself; when the
  * frame does not fit the chip that way the plan takes the barrier-free three-sweep
