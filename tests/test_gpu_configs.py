@@ -324,6 +324,39 @@ def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monk
         assert np.abs(y0[f] - y1[f]).max() <= FIELD_RTOL * np.abs(y1[f]).max()
 
 
+def test_fibre_beside_a_busy_stream_is_bit_identical_to_the_fibre_alone(lib):
+    """The fused column sweep's teams claim their frames as they go: when another stream's kernels hold part of the chip, some
+    teams start late (or never get a frame) and the others take their share.  Which team propagates a frame must not show in
+    the result: a batch beside a stream of large FP64 matrix products leaves with the bits and step counts of the same batch on
+    a quiet GPU."""
+    import torch
+    from polmux_amd import pipeline
+    cfg = pipeline.HotPathConfig(nsymb=1024, nt=64, variants=4)
+    F = 256
+    hp = pipeline.HotPath(cfg, max_frames=F)
+    assert hp.fused()
+    dbm = -2.0 + 6.0 * np.arange(F) / (F - 1)                  # different trip counts: frames leave the list on the way
+    scale = 10 ** (dbm / 10) / cfg.pavg_mw
+    ux0, uy0 = hp.make_batch(F, scale)
+    ux1, uy1 = ux0.clone(), uy0.clone()
+    hp.fibre(ux0, uy0)
+    _sync()
+    nc0 = hp.last_ncycle(F).copy()
+    side = torch.cuda.Stream()
+    a = torch.randn(6144, 6144, dtype=torch.float64, device="cuda")
+    b = torch.randn(6144, 6144, dtype=torch.float64, device="cuda")
+    _sync()
+    with torch.cuda.stream(side):
+        for _ in range(12):
+            c = a @ b                                           # ~0.5 TFLOP each: the chip is busy for the whole pass
+    hp.fibre(ux1, uy1)
+    _sync()
+    assert float(c.abs().max()) > 0
+    assert hp.last_ncycle(F).tolist() == nc0.tolist() and max(nc0) > min(nc0)
+    assert torch.equal(ux0, ux1) and torch.equal(uy0, uy1)
+    hp.close()
+
+
 def test_front_end_at_2pow20_uses_the_long_row_filter_pass(lib, oracle):
     """The coherent front end of a 2^20-sample frame: its two spectral filters run on the plan's FFT engine, i.e. through
     the 256 x 4096 split and the 4096-point row pass k_row4k with a general multiplier table -- photocurrents against the
