@@ -67,7 +67,8 @@ def parse():
     ap.add_argument("--mc", action="store_true",
                     help="timed region in BASELINE config[3] style: fiber('gps-') with a fresh random-birefringence draw per "
                          "frame and per step; the Monte-Carlo leg proper (ShardedBer) runs after the timed region in every mode")
-    ap.add_argument("--mc-rounds", type=int, default=4, help="rounds of the Monte-Carlo leg (0: skip it)")
+    ap.add_argument("--mc-rounds", type=int, default=8, help="rounds of the Monte-Carlo leg (0: skip it; 8 x 128 = config[3]'s 1024 realisations per GPU)")
+    ap.add_argument("--mc-depth", type=int, default=3, help="Monte-Carlo rounds enqueued ahead of the one being reduced (their receivers run beside each other)")
     ap.add_argument("--mc-frames", type=int, default=128, help="realisations per GPU per round (config[3]: 1024 over 8 GPUs)")
     ap.add_argument("--mc-nf", type=float, default=31.0, help="noise figure [dB] of the amplifier in the Monte-Carlo leg")
     ap.add_argument("--spans", type=int, default=1, help="spans per step, with in-line amplifiers between them (config[4]: 40)")
@@ -371,16 +372,17 @@ def main():
     if a.mc_rounds > 0:
         mcfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag="gps-", frontend="cohmix", rx_amp=True,
                                       span_nf_db=a.mc_nf)
-        camp = pipeline.McCampaign(mcfg, frames_per_call=a.mc_frames)
+        camp = pipeline.McCampaignPool(mcfg, frames_per_call=a.mc_frames, n=a.mc_depth + 1)
         x = dict(stop=(0.01, 95.0), nmin=100)                   # 1 % relative accuracy at 95 % confidence (ber_estimate.m:128-139)
-        camp.simulate(list(range(10 ** 6 + rank * a.mc_frames, 10 ** 6 + (rank + 1) * a.mc_frames)))   # warm-up, not counted
+        for w_ in range(a.mc_depth + 1):                        # warm-up of every instance of the pool, not counted
+            camp.simulate(list(range(10 ** 6 + rank * a.mc_frames, 10 ** 6 + (rank + 1) * a.mc_frames)))
         # mc_estimate (mc_estimate.m:133-212) on a continuous per-realisation sample, the EVM of the recovered symbols,
         # gathered with the counts: 0.1 % accuracy of the mean at 95 % confidence
         sb = mc.ShardedBer(camp.simulate, camp.bits_per_realisation, x, per_rank_per_round=a.mc_frames, device=cdev,
                            x_samples=dict(stop=(1e-3, 95.0), nmin=50))
         sync_all()
         t1 = time.perf_counter()
-        res = sb.run(max_realisations=a.mc_rounds * a.mc_frames * world)
+        res = sb.run(max_realisations=a.mc_rounds * a.mc_frames * world, depth=a.mc_depth)
         sync_all()
         mdt = time.perf_counter() - t1
         if world > 1:
@@ -389,7 +391,7 @@ def main():
             mdt = float(tm.item())
         done = len(sb.counts)
         mc_out = {"realisations_per_s": done / mdt, "realisations": done, "rounds": sb.rounds, "seconds": mdt,
-                  "per_gpu_per_round": a.mc_frames, "bits_per_realisation": camp.bits_per_realisation,
+                  "per_gpu_per_round": a.mc_frames, "rounds_in_flight": a.mc_depth + 1, "bits_per_realisation": camp.bits_per_realisation,
                   "avgber": float(res[1][0]), "stdber": float(res[3][0]), "nruns_bits": float(res[2][0]),
                   "evm_mc_estimate": None if sb.samples_result is None else {
                       "mean": float(sb.samples_result[1]["mean"][0]), "stdmean": float(sb.samples_result[1]["stdmean"][0]),

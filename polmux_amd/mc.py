@@ -231,16 +231,19 @@ class ShardedBer:
             return dist, dist.get_rank(self.group), dist.get_world_size(self.group)
         return None, 0, 1
 
-    def run(self, max_realisations=1 << 30):
+    def run(self, max_realisations=1 << 30, depth=1):
         """Rounds of per_rank_per_round realisations per rank until the reference's stop rule fires.  When the simulator
-        offers launch()/collect() (pipeline.McCampaign) the NEXT round is already enqueued while this round's counts are
-        reduced and replayed: a round computed past the stop is simply discarded, the statistics are unchanged."""
+        offers launch()/collect() (pipeline.McCampaign, McCampaignPool) up to `depth` FURTHER rounds are already enqueued
+        while a round's counts are reduced and replayed: rounds computed past the stop are simply discarded, the
+        statistics are unchanged (the rounds are fixed in size and replayed in order whatever the depth)."""
+        import collections
         import torch
         dist, rank, world = self._dist()
         sim = self.simulate
         owner = getattr(sim, "__self__", None)
         launch = getattr(owner, "launch", None) if owner is not None and getattr(sim, "__name__", "") == "simulate" else None
         collect = getattr(owner, "collect", None) if launch is not None else None
+        depth = max(1, int(depth))
 
         def plan(start):
             n_round = min(self.w * world, max_realisations - start)
@@ -249,18 +252,22 @@ class ShardedBer:
         start = 0
         result = None
         cond = True
-        pending = None          # (start, n_round, mine, handle) of the round in flight
-        if launch is not None and start < max_realisations:
-            n_round, mine = plan(start)
-            pending = (start, n_round, mine, launch(mine) if mine else None)
+        inflight = collections.deque()   # (start, n_round, mine, handle) of the rounds enqueued and not yet collected
+        nxt = 0
+
+        def top_up(limit):
+            nonlocal nxt
+            while len(inflight) < limit and nxt < max_realisations:
+                n_round, mine = plan(nxt)
+                inflight.append((nxt, n_round, mine, launch(mine) if mine else None))
+                nxt += n_round
+
+        if launch is not None:
+            top_up(1)
         while cond and start < max_realisations:
             if launch is not None:
-                start, n_round, mine, handle = pending
-                nxt = start + n_round
-                pending = None
-                if nxt < max_realisations:          # speculative: enqueue the next round before looking at this one
-                    n2, m2 = plan(nxt)
-                    pending = (nxt, n2, m2, launch(m2) if m2 else None)
+                start, n_round, mine, handle = inflight.popleft()
+                top_up(depth)               # speculative: enqueue the next round(s) before looking at this one
                 if self.x_samples is not None and mine:
                     local, local_s = collect(handle, with_samples=True)
                     local = np.asarray(local, dtype=np.int64)
@@ -299,6 +306,8 @@ class ShardedBer:
                     cond = False
                     break
             start += n_round
-        if pending is not None and pending[3] is not None:   # a speculative round past the stop: wait for it, drop it
-            collect(pending[3])
+        while inflight:                      # speculative rounds past the stop: wait for them, drop them
+            h = inflight.popleft()[3]
+            if h is not None:
+                collect(h)
         return result

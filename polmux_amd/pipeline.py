@@ -467,3 +467,38 @@ class McCampaign:
 
     def close(self):
         self.hp.close()
+
+
+class McCampaignPool:
+    """`n` McCampaign instances taking the rounds of a campaign in turn, each with its own plans, receiver buffers and
+    receiver stream: the receivers of up to n rounds are in flight at once (ShardedBer.run(depth=n - 1)).  A noise-loaded
+    realisation's CMA runs all of its 299 passes -- ~58 ms of a serial recurrence whatever the batch size -- while its
+    fibre takes a few ms: with one receiver in flight a round of 128 realisations is latency-bound on that."""
+
+    def __init__(self, cfg, frames_per_call, n=2, noise_sigma=0.0, noise_provider=None):
+        self.camps = [McCampaign(cfg, frames_per_call, noise_sigma, noise_provider) for _ in range(max(1, int(n)))]
+        self._turn = 0
+
+    @property
+    def bits_per_realisation(self):
+        return self.camps[0].bits_per_realisation
+
+    @property
+    def hp(self):
+        return self.camps[0].hp
+
+    def launch(self, indices, keep=None):
+        i = self._turn % len(self.camps)
+        self._turn += 1
+        return i, self.camps[i].launch(indices, keep)
+
+    def collect(self, handle, with_samples=False):
+        i, h = handle
+        return self.camps[i].collect(h, with_samples)
+
+    def simulate(self, indices, keep=None):
+        return self.collect(self.launch(indices, keep))
+
+    def close(self):
+        for c in self.camps:
+            c.close()

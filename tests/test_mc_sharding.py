@@ -118,6 +118,15 @@ def test_pipelined_rounds_give_the_sequential_statistics():
     for got, want in zip(res, ref):
         np.testing.assert_array_equal(np.asarray(got, dtype=float), np.asarray(want, dtype=float))
     assert len(camp.launched) == runner.rounds + 1                 # exactly one speculative round beyond the stop
+    # several rounds in flight (the campaign pool's receivers run beside each other): the same statistics, `depth` rounds dropped
+    camp4 = _FakeCampaign()
+    r4 = mc.ShardedBer(camp4.simulate, 4096, x, per_rank_per_round=4)
+    res4 = r4.run(max_realisations=5000, depth=3)
+    assert r4.counts == runner.counts and r4.rounds == runner.rounds
+    for got, want in zip(res4, ref):
+        np.testing.assert_array_equal(np.asarray(got, dtype=float), np.asarray(want, dtype=float))
+    assert len(camp4.launched) == r4.rounds + 3
+    assert camp4.launched == [list(range(4 * k, 4 * k + 4)) for k in range(r4.rounds + 3)]   # in order, fixed size
     # the continuous samples of the same rounds go through mc_estimate, block by block (mc_estimate.m:133-212)
     camp3 = _FakeCampaign()
     r3 = mc.ShardedBer(camp3.simulate, 4096, x, per_rank_per_round=4, x_samples=dict(stop=(1e-4, 95), nmin=10))
