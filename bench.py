@@ -83,7 +83,8 @@ def parse():
 # ------------------------------------------------------------------------------------- launcher ---
 def launch_ranks(a):
     """`bench.py --gpus N` outside a launcher: start N ranks as fresh child processes of THIS interpreter, which has not
-    touched (and never touches) a GPU; rank 0's JSON line passes through on stdout."""
+    touched (and never touches) a GPU.  Only rank 0's JSON line reaches stdout: the ranks' own stdout (the gloo backend of
+    the rehearsal mode chats there) goes to a temporary file / stderr."""
     import torch       # device_count() does not initialise the GPU on this image
     rehearsal = os.environ.get("PLX_BENCH_REHEARSAL") == "1"
     ndev = torch.cuda.device_count()
@@ -94,11 +95,14 @@ def launch_ranks(a):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    import tempfile
     procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else sys.stderr))
     rc = 0
     try:
         while procs and rc == 0:
@@ -119,6 +123,14 @@ def launch_ranks(a):
                 p.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 p.kill()
+        out0.seek(0)
+        for line in out0:
+            if line.startswith("{"):
+                sys.stdout.write(line)
+            elif line.strip():
+                sys.stderr.write(line)
+        sys.stdout.flush()
+        out0.close()
     return rc
 
 
