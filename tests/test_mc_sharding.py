@@ -196,6 +196,28 @@ def test_real_campaign_on_two_ranks_equals_one_rank():
 
 
 @pytest.mark.gpu
+def test_campaign_pool_with_rounds_in_flight_equals_the_single_campaign():
+    """pipeline.McCampaignPool + ShardedBer.run(depth=3): four rounds in flight, each on its own campaign (plans, receiver
+    buffers, receiver stream) -- the counts, the BER statistics and the EVM samples' mc_estimate equal the single campaign's
+    with one round in flight, bit for bit (realisations are keyed by their index, rounds are replayed in order)."""
+    sys.path.insert(0, ROOT)
+    from polmux_amd import mc, pipeline
+    cfg = pipeline.HotPathConfig(nsymb=256, nt=16, flag="gps-", nplates=10, dgd=0.2, length=4e4, pavg_mw=1.0, cma_mu=1 / 600,
+                                 freqavg=50, dphimax=2e-2)
+    x = dict(stop=(0.01, 99), nmin=50)
+    outs = []
+    for pool_n, depth in ((0, 1), (4, 3)):
+        camp = pipeline.McCampaignPool(cfg, 4, n=pool_n, noise_sigma=0.28) if pool_n else pipeline.McCampaign(cfg, 4, noise_sigma=0.28)
+        runner = mc.ShardedBer(camp.simulate, camp.bits_per_realisation, x, per_rank_per_round=4, x_samples=dict(stop=(1e-3, 95), nmin=10))
+        res = runner.run(max_realisations=48, depth=depth)
+        so = runner.samples_result[1]
+        outs.append((list(runner.counts), [np.asarray(v, dtype=float).tolist() for v in res], float(so["mean"][0]), float(so["var"][0])))
+        camp.close()
+    assert outs[0] == outs[1]
+    assert len(outs[0][0]) >= 8 and sum(outs[0][0]) > 0
+
+
+@pytest.mark.gpu
 def test_bench_starts_its_own_ranks():
     """`bench.py --gpus 2` with no launcher around it starts two ranks itself (fresh child processes, before any GPU call);
     on this one-GPU box as a rehearsal (both on cuda:0, gloo).  One JSON line, n_gpus 2, frames of both ranks counted, the
