@@ -210,7 +210,7 @@ class ShardedBer:
     def __init__(self, simulate, bits_per_realisation, x, per_rank_per_round=8, group=None, device=None, x_samples=None):
         """x_samples: optional mc_estimate options (mc_estimate.m:104-131).  When given and the simulator's collect()
         can return a continuous sample per realisation beside the error count (McCampaign: the EVM), every round's
-        sample vector is gathered the same way (one all-reduce of float64 slots) and fed to mc_estimate in blocks of
+        sample vector travels in the SAME all-reduce as the counts (bit patterns in the int64 buffer) and is fed to mc_estimate in blocks of
         per_rank_per_round samples: `samples_result` = (cond, out) of the last call."""
         self.x_samples = x_samples
         self.samples_state = _State()
@@ -224,6 +224,7 @@ class ShardedBer:
         self.state = _State()
         self.counts = []          # accepted per-realisation error counts, in index order
         self.rounds = 0
+        self.exchanges = 0        # all-reduces issued (one per round)
 
     def _dist(self):
         import torch.distributed as dist
@@ -278,24 +279,28 @@ class ShardedBer:
                 n_round, mine = plan(start)
                 local = np.asarray(sim(mine), dtype=np.int64) if mine else np.zeros(0, np.int64)
                 local_s = None
-            # one exchange step: every rank contributes its slots of the round's count vector
-            vec = torch.zeros(n_round, dtype=torch.int64, device=self.device or "cpu")
+            # ONE exchange step per round: every rank contributes its slots of the round's vector -- the int64
+            # error counts and, when a continuous sample travels with them, the BIT PATTERNS of the float64 samples in the
+            # second half of the same int64 buffer.  Slots are disjoint (every other rank holds 0 there), so SUM is exact
+            # for both halves.
+            with_s = self.x_samples is not None and launch is not None
+            vec = torch.zeros(n_round * (2 if with_s else 1), dtype=torch.int64, device=self.device or "cpu")
             if mine:
-                vec[torch.as_tensor([r - start for r in mine], device=vec.device)] = \
-                    torch.as_tensor(local, device=vec.device)
-            if dist is not None and world > 1:
+                slots = torch.as_tensor([r - start for r in mine], device=vec.device)
+                vec[slots] = torch.as_tensor(local, device=vec.device)
+                if with_s and local_s is not None:
+                    bits = np.ascontiguousarray(np.asarray(local_s, dtype=np.float64)).view(np.int64)
+                    vec[slots + n_round] = torch.as_tensor(bits, device=vec.device)
+            if dist is not None:            # (also with one rank: the collective is the same code path on every world size)
                 dist.all_reduce(vec, op=dist.ReduceOp.SUM, group=self.group)
-            counts = vec.cpu().numpy()
+            self.exchanges += 1
+            host = vec.cpu().numpy()
+            counts = host[:n_round]
             self.rounds += 1
-            if self.x_samples is not None and launch is not None:
-                sv = torch.zeros(n_round, dtype=torch.float64, device=self.device or "cpu")
-                if mine and local_s is not None:
-                    sv[torch.as_tensor([r - start for r in mine], device=sv.device)] = torch.as_tensor(local_s, device=sv.device)
-                if dist is not None and world > 1:
-                    dist.all_reduce(sv, op=dist.ReduceOp.SUM, group=self.group)   # disjoint slots: the sum is exact
+            if with_s:
                 # blocks of per_rank_per_round samples in realisation order, whatever the number of ranks: the recursion
                 # then sees the same sequence of blocks for any sharding (bit-equal statistics)
-                svn = sv.cpu().numpy()
+                svn = np.ascontiguousarray(host[n_round:]).view(np.float64)
                 for b0 in range(0, n_round, self.w):
                     self.samples_result = mc_estimate(svn[b0:b0 + self.w], self.x_samples, _state=self.samples_state)
             # replay the reference's sequential recursion in realisation order (ber_estimate.m:116-141)

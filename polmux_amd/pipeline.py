@@ -437,13 +437,19 @@ class McCampaign:
             hp.fibre(ux, uy, span_keys=idx, inject_noise=inj)
             if keep is not None:
                 keep(i0, idx, ux, uy)
-            hp.receive(ux, uy, self.sigma, 20260101, self._rx_stream, idx)   # receiver noise keyed by realisation index
-            with torch.cuda.stream(self._rx_stream):
+            # ONE stream for the receiver and everything that reads its outputs (hp.sym, hp.err): the side stream when the
+            # plan may share the GPU with the next fibre, the fibre's own stream otherwise (receive() would fall back to
+            # it by itself, and the EVM / error kernels must follow the DSP in stream order)
+            rxs = self._rx_stream if hp.overlap_ok() else torch.cuda.current_stream()
+            side = rxs if rxs is self._rx_stream else None
+            hp.receive(ux, uy, self.sigma, 20260101, side, idx)   # receiver noise keyed by realisation index
+            with torch.cuda.stream(rxs):
                 v = hp.evm(n)              # a continuous per-realisation sample (mc_estimate) beside the error count
                 e = hp.errors_resolved(n)
-                ux.record_stream(self._rx_stream); uy.record_stream(self._rx_stream)
+                if side is not None:
+                    ux.record_stream(rxs); uy.record_stream(rxs)
                 done = torch.cuda.Event()
-                done.record(self._rx_stream)
+                done.record(rxs)
             out.append((e, v, done))
         return out
 

@@ -139,11 +139,60 @@ def test_pipelined_rounds_give_the_sequential_statistics():
     np.testing.assert_array_equal(r3.samples_result[1]["mean"], want[1]["mean"])
     np.testing.assert_array_equal(r3.samples_result[1]["varlim"], want[1]["varlim"])
     assert abs(r3.samples_result[1]["mean"][0] - 0.05) < 1e-3
+    assert r3.exchanges == r3.rounds                                # counts and samples travel in ONE exchange per round
     # a campaign that ends on max_realisations has no speculative round left over
     camp2 = _FakeCampaign()
     r2 = mc.ShardedBer(camp2.simulate, 4096, dict(stop=(1e-9, 95), nmin=10), per_rank_per_round=4)
     r2.run(max_realisations=12)
     assert len(r2.counts) == 12 and len(camp2.launched) == 3
+
+
+def _sample_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from polmux_amd import mc
+    camp = _FakeCampaign()
+    runner = mc.ShardedBer(camp.simulate, 4096, dict(stop=(0.05, 95), nmin=10), per_rank_per_round=4,
+                           x_samples=dict(stop=(1e-4, 95), nmin=10))
+    res = runner.run(max_realisations=5000, depth=2)
+    so = runner.samples_result[1]
+    q.put((rank, [np.asarray(v, dtype=float).tolist() for v in res], list(runner.counts), runner.rounds, runner.exchanges,
+           [float(so["mean"][0]), float(so["var"][0]), float(so["nruns"][0])]))
+    dist.destroy_process_group()
+
+
+def test_counts_and_samples_share_one_exchange_per_round_on_two_ranks():
+    """World 2 over gloo: the round's int64 counts and the bit patterns of its float64 samples travel in ONE all-reduce
+    (disjoint slots, SUM exact -- negative samples included); counts, BER statistics and the samples' mc_estimate equal
+    the one-rank campaign's bit for bit."""
+    sys.path.insert(0, ROOT)
+    from polmux_amd import mc
+    camp = _FakeCampaign()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 101) % 2000
+    procs = [ctx.Process(target=_sample_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref, nseq = _sequential(dict(stop=(0.05, 95), nmin=10), 4096.0, 5000)
+    rounds = outs[0][3]
+    st = mc._State()
+    want = None
+    for k in range(rounds):                       # rounds of 8 realisations, fed to mc_estimate in blocks of 4
+        for b in range(2):
+            idx = list(range(8 * k + 4 * b, 8 * k + 4 * b + 4))
+            want = mc.mc_estimate(camp.collect(idx, with_samples=True)[1], dict(stop=(1e-4, 95), nmin=10), _state=st)
+    for rank, res, counts, rnds, exch, smp in outs:
+        assert len(counts) == nseq and rnds == rounds and exch == rounds       # one exchange per round
+        for got, w in zip(res, ref):
+            np.testing.assert_array_equal(np.asarray(got), np.asarray(w, dtype=float))
+        assert smp == [float(want[1]["mean"][0]), float(want[1]["var"][0]), float(want[1]["nruns"][0])]
 
 
 def _gpu_worker(rank, world, port, q):
@@ -273,3 +322,48 @@ def test_bench_line_carries_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Gsample/s" and c["value"] > 0 and "frame" in c["sample"]
     assert d["mc"]["realisations"] == 8 and d["mc"]["evm_mc_estimate"]["nruns"] == 8
+
+
+def _nccl_worker(q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(29500 + (os.getpid() + 211) % 2000)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))     # RCCL, as bench.py does for N > 1
+    from polmux_amd import mc, pipeline
+    cfg = pipeline.HotPathConfig(nsymb=256, nt=16, flag="gps-", nplates=10, dgd=0.2, length=4e4, pavg_mw=1.0, cma_mu=1 / 600,
+                                 freqavg=50, dphimax=2e-2)
+    camp = pipeline.McCampaign(cfg, frames_per_call=4, noise_sigma=0.28)
+    out = {}
+    for dev in ("cuda", "cpu"):               # the collective's buffer on the device (RCCL) / the host reference, no process group use
+        runner = mc.ShardedBer(camp.simulate, camp.bits_per_realisation, dict(stop=(1e-9, 99), nmin=50), per_rank_per_round=4,
+                               device=dev if dev == "cuda" else None, x_samples=dict(stop=(1e-9, 95), nmin=10))
+        if dev == "cpu":
+            runner._dist = lambda: (None, 0, 1)
+        res = runner.run(max_realisations=8)  # two rounds
+        out[dev] = (list(runner.counts), runner.rounds, runner.exchanges, float(runner.samples_result[1]["mean"][0]),
+                    [np.asarray(v, dtype=float).tolist() for v in res])
+    t = torch.ones(4, dtype=torch.int64, device="cuda")
+    dist.all_reduce(t)
+    out["allreduce"] = t.cpu().tolist()
+    q.put(out)
+    camp.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_nccl_backend_world_one_runs_the_rccl_exchange():
+    """The N-GPU code path of bench.py -- init_process_group('nccl', device_id=...), ShardedBer with its exchange buffer in
+    device memory -- executes on a one-GPU box: world size 1, two rounds, the all-reduce issued through RCCL; results equal
+    the same campaign with no process group."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(q,))
+    p.start()
+    out = q.get(timeout=300)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert out["cuda"] == out["cpu"]
+    assert out["cuda"][1] == 2 and out["cuda"][2] == 2 and len(out["cuda"][0]) == 8
+    assert out["allreduce"] == [1, 1, 1, 1]
