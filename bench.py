@@ -230,6 +230,23 @@ def ladder_scales(nframes, pavg_mw, rank=0, world=1):
     return 10 ** (dbm / 10) / pavg_mw
 
 
+def workload_label(a, n):
+    """config.workload from the ACTUAL arguments: which BASELINE configuration (if any) this line is."""
+    what = ("28 Gbaud PDM-QPSK, 2^%d-sample dual-pol frame, %dx80 km SSMF span fiber('%s'), CDE_OFDE 256/128, CMA 7 taps + "
+            "V&V carrier recovery; front end: %s" % (int(np.log2(n)), a.spans, a.flag, a.frontend))
+    if a.mc:
+        tag = "ex24_pmd-style random-PMD batch (BASELINE config[3] realisations in the timed region: fresh waveplates per frame and step)"
+    elif n == 1 << 20 or a.spans > 1 or a.power_ladder:
+        tag = "long-haul launch-power-sweep style (BASELINE config[4]: 2^20-sample frame x 40 spans x 64-point ladder%s)" % (
+            "" if (n == 1 << 20 and a.spans == 40 and a.power_ladder) else
+            "; this line: 2^%d samples, %d span(s), %s" % (int(np.log2(n)), a.spans, "power ladder" if a.power_ladder else "one launch power"))
+    elif n == 65536 and a.flag == "g-s-" and a.nt == 64:
+        tag = "Run_my_PDM_QPSK-style (BASELINE config[1])"
+    else:
+        tag = "custom configuration (no BASELINE config)"
+    return tag + ": " + what
+
+
 def offline_traffic(fused, F, n):
     """HBM bytes per launch of the dominant kernel from the PMC counters.  Counters need their own rocprofv3 passes
     (FETCH_SIZE, WRITE_SIZE: MI355X_MICROARCH.md, HBM section), so this is NOT measured in this run: it is read from the
@@ -458,9 +475,7 @@ def main():
             "metric": "dual-pol Gsample/s through SSFM+Rx-DSP", "value": value, "unit": "Gsample/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Run_my_PDM_QPSK-style (BASELINE config[1]): 28 Gbaud PDM-QPSK, 2^%d-sample "
-                                   "dual-pol frame, %dx80 km SSMF span fiber('%s'), CDE_OFDE 256/128, CMA 7 taps + "
-                                   "V&V carrier recovery; front end: %s" % (int(np.log2(n)), a.spans, a.flag, a.frontend),
+            "config": {"workload": workload_label(a, n),
                        "frames_per_gpu_per_step": F, "nsymb": a.nsymb, "nt": a.nt, "pavg_mw": a.pavg,
                        "tx_variants": hp.nvar, "power_ladder": bool(a.power_ladder),
                        "ssfm_steps_per_frame": sample_steps / (a.steps * F * n),
@@ -479,7 +494,9 @@ def main():
                        "bits": int(world) * a.steps * F * 4 * a.nsymb, "restaged_batches": restaged,
                        "rehearsal_all_ranks_on_one_gpu": bool(rehearsal),
                        "single_frame": single},
-            "roofline": {"bound": "hbm", "kernel": dom,
+            # a PMD plan's row pass does one exponential + 20 multiply-adds per waveplate trunk and frequency: FP64-VALU-bound
+            # (exception 1), still priced in bytes against the HBM peak
+            "roofline": {"bound": "fp64-valu" if (dom == "k_row" and hp.pmd) else "hbm", "kernel": dom,
                          "achieved": kern.get(dom, {}).get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern.get(dom, {}).get("frac_of_8TBs"),
                          "algorithmic_bytes_per_launch": SWEEP_BYTES * active_frames * n,

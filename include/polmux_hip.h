@@ -13,7 +13,14 @@
  *   (A) "gateway" calls  plx_<name>(...)      host pointers, MEX-shaped: the
  *       arrays are MATLAB column-major, complex data as SEPARATE re/im planes
  *       (mxGetPr/mxGetPi; an all-real input has im == NULL).  Each call uploads,
- *       runs the kernels, downloads.  Drop-in for one MATLAB call.
+ *       runs the kernels, downloads.  Drop-in for one MATLAB call.  The plans
+ *       (twiddle / phase tables), device buffers and pinned staging memory these
+ *       calls need are OWNED BY THE LIBRARY and kept between calls (the drivers
+ *       call a filter gateway up to 299 times per frame, DspPdmCohQpsk.m:176-191,
+ *       and the propagator once per span, fiber.m:372-389): plans are found again
+ *       by a hash of the descriptor's scalars and table contents, a repeated call
+ *       allocates nothing.  plx_release_all() frees that state; a MEX shim calls
+ *       mexLock() and registers it with mexAtExit() (integration/mex/plx_mex_common.h).
  *   (B) "resident" calls plx_<name>_dev(...)  device pointers + HIP stream,
  *       interleaved complex128 (re,im), batched over frames.  This is what the
  *       Monte-Carlo runner and bench.py use; nothing crosses PCIe per call.
@@ -45,6 +52,14 @@ int plx_abi_version(void);
 /* number of visible HIP devices, and selection of the one this process uses */
 int plx_device_count(int *count);
 int plx_set_device(int device);
+
+/* Library-owned gateway state (tier A): plx_release_all() destroys the cached plans and frees the scratch and
+ * staging buffers of every gateway (safe to call at any time; the next gateway call rebuilds what it needs).
+ * plx_gateway_stats(out[8]): calls, device allocations, pinned-host allocations, plans built, plans found in the
+ * cache, device bytes held, pinned bytes held, releases -- so that a caller (and the tests) can check that a
+ * repeated call allocates nothing.                                                                               */
+int plx_release_all(void);
+int plx_gateway_stats(int64_t *out);
 
 /* ------------------------------------------------------------------ fastexp --- */
 /* fastexp.c:37-47 / fastexp.m:28: y = cos(x) + i*sin(x), x real [m x n].           */

@@ -1,11 +1,11 @@
 /* [outX,outY] = plx_cde_ofde_mex(inX,inY,fs,lambdaRef,span,D,S,fftLength,L) -- the body of CDE_OFDE.m:16-47 behind the
  * unchanged .m signature.  On a bad argument OverlapBothTrans display()s a message and returns [] (CDE_OFDE.m:63-85):
  * the shim does the same. */
-#include "mex.h"
-#include "polmux_hip.h"
+#include "plx_mex_common.h"
 static double *plane_or_zeros(const mxArray *a, size_t n) { double *p = mxGetPi(a); return p ? p : (double *)mxCalloc(n, sizeof(double)); }
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
+    plx_mex_once();
     (void)nlhs;
     if (nrhs != 9) mexErrMsgTxt("Nine inputs required.");
     size_t nx = mxGetNumberOfElements(prhs[0]);

@@ -3,8 +3,7 @@
  * check, and the UPDATED taps come back in plhs[1..2] -- the inputs are left untouched, so the drivers take their
  * any(any(h1_new)) branch (DspPdmCohQpsk.m:183-186).  size(h1,1) is the number of taps, as in the .m (:53). */
 #include <string.h>
-#include "mex.h"
-#include "polmux_hip.h"
+#include "plx_mex_common.h"
 static mxArray *complex_copy(const mxArray *a)
 {
     size_t m = mxGetM(a), n = mxGetN(a);
@@ -15,6 +14,7 @@ static mxArray *complex_copy(const mxArray *a)
 }
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
+    plx_mex_once();
     (void)nlhs;
     if (nrhs != 7) mexErrMsgTxt("Seven inputs required.");
     int Mdim = (int)mxGetM(prhs[0]), ntap = (int)mxGetM(prhs[1]);

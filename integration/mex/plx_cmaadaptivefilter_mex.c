@@ -1,8 +1,7 @@
 /* [Y,h1,h2] = cmaadaptivefilter(xx,h1,h2,taps,mu,R,sps) -- drop-in for /root/reference/cmaadaptivefilter.c:93-174.
  * Like the reference it updates h1, h2 IN THE CALLER'S ARRAYS and returns 0, 0 (:166-171); the drivers detect that with
  * any(any(h1_new)) (DspPdmCohQpsk.m:183-186). */
-#include "mex.h"
-#include "polmux_hip.h"
+#include "plx_mex_common.h"
 static double *imag_plane(const mxArray *a, size_t n)   /* the reference allocates missing imaginary planes ON THE INPUTS */
 {                                                       /* (cmaadaptivefilter.c:141-155)                                 */
     double *pi = mxGetPi(a);
@@ -11,6 +10,7 @@ static double *imag_plane(const mxArray *a, size_t n)   /* the reference allocat
 }
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
+    plx_mex_once();
     (void)nlhs;
     if (nrhs != 7) mexErrMsgTxt("Seven inputs required.");
     int Mdim = (int)mxGetM(prhs[0]), Npol = (int)mxGetN(prhs[0]);

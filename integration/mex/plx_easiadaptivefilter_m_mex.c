@@ -3,8 +3,7 @@
  * updated taps returned in plhs[1..2]; the inputs are left untouched.  The C file (easiadaptivefilter.c:81-90) only ever
  * touches the real parts of tap 0 -- the twins are not equivalent, and this shim is the .m one. */
 #include <string.h>
-#include "mex.h"
-#include "polmux_hip.h"
+#include "plx_mex_common.h"
 static mxArray *complex_copy(const mxArray *a)
 {
     size_t m = mxGetM(a), n = mxGetN(a);
@@ -15,6 +14,7 @@ static mxArray *complex_copy(const mxArray *a)
 }
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
+    plx_mex_once();
     (void)nlhs;
     if (nrhs != 6) mexErrMsgTxt("Six inputs required.");
     int Mdim = (int)mxGetM(prhs[0]), ntap = (int)mxGetM(prhs[1]);

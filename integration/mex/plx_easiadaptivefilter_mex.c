@@ -1,7 +1,6 @@
 /* [Y,h1,h2] = easiadaptivefilter(xx,h1,h2,taps,mu,sps) -- drop-in for /root/reference/easiadaptivefilter.c:95-169
  * (six inputs, sps is prhs[5]); in-place h1/h2 and 0, 0 returned, as the reference. */
-#include "mex.h"
-#include "polmux_hip.h"
+#include "plx_mex_common.h"
 static double *imag_plane(const mxArray *a, size_t n)
 {
     double *pi = mxGetPi(a);
@@ -10,6 +9,7 @@ static double *imag_plane(const mxArray *a, size_t n)
 }
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
+    plx_mex_once();
     (void)nlhs;
     if (nrhs != 6) mexErrMsgTxt("Six inputs required.");
     int Mdim = (int)mxGetM(prhs[0]), Npol = (int)mxGetN(prhs[0]);

@@ -1,9 +1,9 @@
 /* y = fastexp(x) -- drop-in for /root/reference/fastexp.c:46-67 (build: mex -R2017b -I<repo>/include plx_fastexp_mex.c
  * -L<repo>/polmux_amd/lib -lpolmux_hip -output fastexp). */
-#include "mex.h"
-#include "polmux_hip.h"
+#include "plx_mex_common.h"
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
+    plx_mex_once();
     (void)nlhs;
     if (nrhs != 1) mexErrMsgTxt("One input required.");
     size_t m = mxGetM(prhs[0]), n = mxGetN(prhs[0]);

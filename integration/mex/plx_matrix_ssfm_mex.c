@@ -1,11 +1,11 @@
 /* [firstdz,ncycle,ux,uy] = plx_matrix_ssfm_mex(ux,uy,betat,db1,dzmaxt,dphimaxt,gam,alphalin,nfc,Lf,nplates,manakov,fls,
  *                                              db0,theta,epsilon)
  * the new seam behind fiber.m:380-388: matrix_ssfm (fiber.m:459-554) with brf passed as its three vectors. */
-#include "mex.h"
-#include "polmux_hip.h"
+#include "plx_mex_common.h"
 #include <string.h>
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
+    plx_mex_once();
     (void)nlhs;
     if (nrhs != 16) mexErrMsgTxt("Sixteen inputs required.");
     plx_ssfm_desc d;

@@ -1,11 +1,11 @@
 /* RxSamples = plx_rx_front_mex(sigx, sigy, Hopt, Hel, Elo, balanced, adcbits, r, b, shift)
  * the per-sample part of RxPdmCohQpsk.m:19-72 (receiver_cohmix + ADC + fastshift + decimate + I/Q recombination) behind
  * the unchanged .m signature; the tables come from the .m code (myfilter, fastexp, fir1), see INTEGRATION.md. */
-#include "mex.h"
-#include "polmux_hip.h"
+#include "plx_mex_common.h"
 #include <string.h>
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
+    plx_mex_once();
     (void)nlhs;
     if (nrhs != 10) mexErrMsgTxt("Ten inputs required.");
     plx_front_desc d;

@@ -1,10 +1,10 @@
 /* [firstdz,ncycle,u] = plx_scalar_ssfm_mex(u,betat,dzmaxt,dphimaxt,gam,alphalin,nfc,Lf,fls)
  * the new seam behind fiber.m:384-388: scalar_ssfm (fiber.m:557-636, tolflag == 0) on a single-polarisation field. */
-#include "mex.h"
-#include "polmux_hip.h"
+#include "plx_mex_common.h"
 #include <string.h>
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
+    plx_mex_once();
     (void)nlhs;
     if (nrhs != 9) mexErrMsgTxt("Nine inputs required.");
     plx_ssfm_desc d;

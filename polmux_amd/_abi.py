@@ -57,6 +57,8 @@ SIGNATURES = {
     "plx_abi_version": [],
     "plx_device_count": [C.POINTER(C.c_int)],
     "plx_set_device": [C.c_int],
+    "plx_release_all": [],
+    "plx_gateway_stats": [_vp],
     "plx_fastexp": [_vp, _vp, _vp, _sz],
     "plx_fastexp_dev": [_vp, _vp, _sz, _vp],
     "plx_ssfm_create": [C.POINTER(_vp), C.POINTER(SsfmDesc)],

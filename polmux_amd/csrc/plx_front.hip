@@ -13,6 +13,7 @@
 // quantisation, the circular timing shift and the decimating FIR are fused into the final gather, which
 // touches only the 17 taps around every r-th sample.
 #include "plx_internal.h"
+#include "plx_gateway.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -309,32 +310,28 @@ extern "C" int plx_rx_front(const double *xr, const double *xi, const double *yr
     d.max_frames = 1;
     const int dual = d.dual_pol ? 1 : 0;
     if (dual && !yr) PLX_FAIL(PLX_ERR_ARG, "plx_rx_front: dual-polarisation descriptor needs the y field");
-    plx_front *P = nullptr;
-    int rc = plx_front_create(&P, &d);
-    if (rc != PLX_OK) return rc;
+    // plan (content hash of the descriptor and its tables), device buffers, pinned staging: the library's (plx_gateway.h)
+    std::lock_guard<std::mutex> lk(plxgw::mutex());
+    plxgw::count_call();
+    int rc = PLX_OK;
+    plx_front *P = plxgw::front_plan(d, &rc);
+    if (!P) return rc;
     const size_t N = (size_t)d.nfft, nout = (size_t)plx_front_out_len(P);
-    std::vector<cplx> h(N * (dual + 1));
+    const size_t nh = N * (dual + 1), no = nout * (dual + 1);
+    cplx *h = (cplx *)plxgw::pinned(plxgw::S_IN, nh * sizeof(cplx)), *o = (cplx *)plxgw::pinned(plxgw::S_OUT, no * sizeof(cplx));
+    cplx *d_u = (cplx *)plxgw::dev(plxgw::S_IN, nh * sizeof(cplx)), *d_o = (cplx *)plxgw::dev(plxgw::S_OUT, no * sizeof(cplx));
+    if (!h || !o || !d_u || !d_o) return PLX_ERR_HIP;
     for (size_t i = 0; i < N; i++) {
         h[i] = make_double2(xr[i], xi ? xi[i] : 0.0);
         if (dual) h[N + i] = make_double2(yr[i], yi ? yi[i] : 0.0);
     }
-    cplx *d_u = nullptr, *d_o = nullptr;
-    std::vector<cplx> o(nout * (dual + 1));
-    bool ok = hipMalloc((void **)&d_u, h.size() * sizeof(cplx)) == hipSuccess &&
-              hipMalloc((void **)&d_o, o.size() * sizeof(cplx)) == hipSuccess &&
-              hipMemcpy(d_u, h.data(), h.size() * sizeof(cplx), hipMemcpyHostToDevice) == hipSuccess;
-    if (ok) {
-        rc = plx_front_run_dev(P, (double *)d_u, dual ? (double *)(d_u + N) : nullptr, 1, shift, (double *)d_o, nullptr);
-        ok = rc == PLX_OK && hipDeviceSynchronize() == hipSuccess &&
-             hipMemcpy(o.data(), d_o, o.size() * sizeof(cplx), hipMemcpyDeviceToHost) == hipSuccess &&
-             hipMemcpy(h.data(), d_u, h.size() * sizeof(cplx), hipMemcpyDeviceToHost) == hipSuccess;
-    }
-    if (d_u) (void)hipFree(d_u);
-    if (d_o) (void)hipFree(d_o);
-    plx_front_destroy(P);
+    PLX_HIP(hipMemcpyAsync(d_u, h, nh * sizeof(cplx), hipMemcpyHostToDevice, nullptr));
+    rc = plx_front_run_dev(P, (double *)d_u, dual ? (double *)(d_u + N) : nullptr, 1, shift, (double *)d_o, nullptr);
     if (rc != PLX_OK) return rc;
-    if (!ok) PLX_FAIL(PLX_ERR_HIP, "plx_rx_front: HIP allocation or transfer failed");
-    for (size_t i = 0; i < o.size(); i++) { outr[i] = o[i].x; outi[i] = o[i].y; }          // [nout x (1 + dual)] column-major
+    if (hipMemcpyAsync(o, d_o, no * sizeof(cplx), hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+        hipMemcpyAsync(h, d_u, nh * sizeof(cplx), hipMemcpyDeviceToHost, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
+        PLX_FAIL(PLX_ERR_HIP, "plx_rx_front: HIP allocation or transfer failed");
+    for (size_t i = 0; i < no; i++) { outr[i] = o[i].x; outi[i] = o[i].y; }          // [nout x (1 + dual)] column-major
     if (cur_r && cur_i)                                                                      // photocurrents [nfft x 2(1 + dual)]: I, Q per pol
         for (int p = 0; p <= dual; p++)
             for (size_t i = 0; i < N; i++) {

@@ -1,6 +1,9 @@
 // plx_misc.hip -- error plumbing, device selection, fastexp and small helpers.
 #include "../../include/polmux_hip.h"
 #include "plx_common.h"
+#include "plx_gateway.h"
+
+#include <cstring>
 
 #include <vector>
 
@@ -124,23 +127,18 @@ extern "C" int plx_fastexp(const double *x, double *yr, double *yi, size_t count
 {
     if (count == 0) return PLX_OK;
     if (!x || !yr || !yi) PLX_FAIL(PLX_ERR_ARG, "plx_fastexp: null argument");
-    double *dx = nullptr, *dy = nullptr;
-    PLX_HIP(hipMalloc((void **)&dx, count * sizeof(double)));
-    if (hipMalloc((void **)&dy, 2 * count * sizeof(double)) != hipSuccess) {
-        hipFree(dx);
-        PLX_FAIL(PLX_ERR_HIP, "plx_fastexp: device allocation failed");
-    }
-    std::vector<double> h(2 * count);
-    int rc = PLX_OK;
-    if (hipMemcpy(dx, x, count * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = PLX_ERR_HIP;
-    if (!rc) rc = plx_fastexp_dev(dx, dy, count, nullptr);
-    if (!rc && hipMemcpy(h.data(), dy, 2 * count * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = PLX_ERR_HIP;
-    hipFree(dx);
-    hipFree(dy);
-    if (rc) {
-        if (rc == PLX_ERR_HIP) plx_set_error("plx_fastexp: HIP transfer failed");
-        return rc;
-    }
+    // device buffers and pinned staging are the library's (plx_gateway.h): a call allocates nothing once they have grown
+    std::lock_guard<std::mutex> lk(plxgw::mutex());
+    plxgw::count_call();
+    double *h = (double *)plxgw::pinned(plxgw::S_IN, 2 * count * sizeof(double));
+    double *dx = (double *)plxgw::dev(plxgw::S_IN, count * sizeof(double)), *dy = (double *)plxgw::dev(plxgw::S_OUT, 2 * count * sizeof(double));
+    if (!h || !dx || !dy) return PLX_ERR_HIP;
+    std::memcpy(h, x, count * sizeof(double));
+    if (hipMemcpyAsync(dx, h, count * sizeof(double), hipMemcpyHostToDevice, nullptr) != hipSuccess) PLX_FAIL(PLX_ERR_HIP, "plx_fastexp: HIP transfer failed");
+    int rc = plx_fastexp_dev(dx, dy, count, nullptr);
+    if (rc) return rc;
+    if (hipMemcpyAsync(h, dy, 2 * count * sizeof(double), hipMemcpyDeviceToHost, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
+        PLX_FAIL(PLX_ERR_HIP, "plx_fastexp: HIP transfer failed");
     for (size_t i = 0; i < count; i++) { yr[i] = h[2 * i]; yi[i] = h[2 * i + 1]; }
     return PLX_OK;
 }

@@ -21,6 +21,7 @@
 //     block scans.
 #include "../../include/polmux_hip.h"
 #include "plx_fft.h"
+#include "plx_gateway.h"
 
 #include <cmath>
 #include <cstring>
@@ -879,28 +880,25 @@ extern "C" int plx_cde_ofde(const double *xr, const double *xi, const double *yr
         H[2 * i + 1] = sin(hd + hs);
     }
     if (nx < fft_len) PLX_FAIL(PLX_ERR_ARG, kCdeMsg[5]);
-    plx_cde *P = nullptr;
-    int rc = plx_cde_create(&P, fft_len, L, H.data());
-    if (rc) return rc;
-    std::vector<double> h(4 * (size_t)nx);
+    // plan (keyed by fft_len, L and the transfer function), device buffers and pinned staging: the library's (plx_gateway.h)
+    std::lock_guard<std::mutex> lk(plxgw::mutex());
+    plxgw::count_call();
+    int rc = PLX_OK;
+    plx_cde *P = plxgw::cde_plan(fft_len, L, H.data(), &rc);
+    if (!P) return rc;
+    const size_t bytes = 4 * (size_t)nx * sizeof(double);
+    double *h = (double *)plxgw::pinned(plxgw::S_IN, bytes);
+    double *dx = (double *)plxgw::dev(plxgw::S_IN, bytes), *dy = (double *)plxgw::dev(plxgw::S_OUT, bytes);
+    if (!h || !dx || !dy) return PLX_ERR_HIP;
     for (int64_t i = 0; i < nx; i++) {
         h[2 * i] = xr[i]; h[2 * i + 1] = xi ? xi[i] : 0.0;
         h[2 * (nx + i)] = yr[i]; h[2 * (nx + i) + 1] = yi ? yi[i] : 0.0;
     }
-    double *dx = nullptr, *dy = nullptr;
-    const size_t bytes = h.size() * sizeof(double);
-    if (hipMalloc((void **)&dx, bytes) != hipSuccess || hipMalloc((void **)&dy, bytes) != hipSuccess) {
-        hipFree(dx); hipFree(dy); plx_cde_destroy(P);
-        PLX_FAIL(PLX_ERR_HIP, "plx_cde_ofde: device allocation failed");
-    }
-    hipMemcpy(dx, h.data(), bytes, hipMemcpyHostToDevice);
+    PLX_HIP(hipMemcpyAsync(dx, h, bytes, hipMemcpyHostToDevice, nullptr));
     rc = plx_cde_apply_dev(P, dx, dy, nx, 2, nullptr);
-    if (!rc && hipMemcpy(h.data(), dy, bytes, hipMemcpyDeviceToHost) != hipSuccess) {
-        plx_set_error("plx_cde_ofde: download failed");
-        rc = PLX_ERR_HIP;
-    }
-    hipFree(dx); hipFree(dy); plx_cde_destroy(P);
     if (rc) return rc;
+    if (hipMemcpyAsync(h, dy, bytes, hipMemcpyDeviceToHost, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
+        PLX_FAIL(PLX_ERR_HIP, "plx_cde_ofde: download failed");
     for (int64_t i = 0; i < nx; i++) {
         oxr[i] = h[2 * i]; oxi[i] = h[2 * i + 1];
         oyr[i] = h[2 * (nx + i)]; oyi[i] = h[2 * (nx + i) + 1];
@@ -926,6 +924,9 @@ static int launch_demux(int method, DemuxArgs &a, void *stream)
         const unsigned gx = (unsigned)((a.nframes + frames_per_block - 1) / frames_per_block);
         PLX_LAUNCH(k_cma, dim3(gx), dim3(256), 0, stream, a);
     } else if (method == PLX_DEMUX_EASI_M) {
+        // the driver form (pass loop + convergence test on the four taps) exists for taps == 1 only, as easipolardemux
+        // fixes it (DspPdmCohQpsk.m:197); the single-pass gateway form takes any number of taps
+        if (!a.single_pass && a.taps != 1) PLX_FAIL(PLX_ERR_ARG, "pol-demux: the EASI driver loop runs with one tap (DspPdmCohQpsk.m:197)");
         const unsigned gx = (unsigned)((a.nframes + 63) / 64);
         PLX_LAUNCH(k_easi_m, dim3(gx), dim3(64), 0, stream, a);
     } else {
@@ -982,7 +983,17 @@ static int gateway_filter(int method, const double *xr, const double *xi, int32_
     if (taps < 1 || Mdim < taps) PLX_FAIL(PLX_ERR_ARG, "adaptive filter gateway: input shorter than the filter");
     if (method == PLX_DEMUX_CMA && taps > 64) PLX_FAIL(PLX_ERR_UNSUPPORTED, "pol-demux: at most 64 taps are supported");
     const int dimY = Mdim - taps + 1;
-    std::vector<double> hx(4 * (size_t)Mdim), hh(8 * (size_t)taps), hy(4 * (size_t)Mdim, 0.0);
+    // One call = ONE pass of the filter; the unchanged drivers make up to 299 of them per frame (DspPdmCohQpsk.m:176-191).
+    // Device buffers and the pinned staging area are the library's (plx_gateway.h): a pass allocates nothing, moves
+    // x | h up in one copy and h | y down in one copy.
+    std::lock_guard<std::mutex> lk(plxgw::mutex());
+    plxgw::count_call();
+    const size_t nx = 4 * (size_t)Mdim, nh = 8 * (size_t)taps;          // doubles: x [2][Mdim] complex, h [4][taps] complex
+    double *hst = (double *)plxgw::pinned(plxgw::S_IN, (2 * nx + nh) * sizeof(double));
+    double *dbuf = (double *)plxgw::dev(plxgw::S_IN, (2 * nx + nh) * sizeof(double));
+    if (!hst || !dbuf) return PLX_ERR_HIP;
+    double *hx = hst, *hh = hst + nx, *hy = hst + nx + nh;                 // staging: x | h | y
+    double *dx = dbuf, *dh = dbuf + nx, *dy = dbuf + nx + nh;
     for (int p = 0; p < 2; p++)
         for (int i = 0; i < Mdim; i++) {
             hx[2 * ((size_t)p * Mdim + i)] = xr[(size_t)p * Mdim + i];
@@ -992,16 +1003,8 @@ static int gateway_filter(int method, const double *xr, const double *xi, int32_
         hh[2 * j] = h1r[j]; hh[2 * j + 1] = h1i ? h1i[j] : 0.0;
         hh[2 * (2 * taps + j)] = h2r[j]; hh[2 * (2 * taps + j) + 1] = h2i ? h2i[j] : 0.0;
     }
-    double *dx = nullptr, *dy = nullptr, *dh = nullptr;
-    auto cleanup = [&]() { hipFree(dx); hipFree(dy); hipFree(dh); };
-    if (hipMalloc((void **)&dx, hx.size() * 8) != hipSuccess || hipMalloc((void **)&dy, hy.size() * 8) != hipSuccess ||
-        hipMalloc((void **)&dh, hh.size() * 8) != hipSuccess) {
-        cleanup();
-        PLX_FAIL(PLX_ERR_HIP, "adaptive filter gateway: device allocation failed");
-    }
-    hipMemcpy(dx, hx.data(), hx.size() * 8, hipMemcpyHostToDevice);
-    hipMemcpy(dh, hh.data(), hh.size() * 8, hipMemcpyHostToDevice);
-    hipMemset(dy, 0, hy.size() * 8);
+    PLX_HIP(hipMemcpyAsync(dx, hx, (nx + nh) * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    PLX_HIP(hipMemsetAsync(dy, 0, nx * sizeof(double), nullptr));
     DemuxArgs a;
     std::memset(&a, 0, sizeof(a));
     a.x = (const cplx *)dx; a.y = (cplx *)dy; a.h = (cplx *)dh; a.L = Mdim; a.nframes = 1; a.taps = taps;
@@ -1010,23 +1013,21 @@ static int gateway_filter(int method, const double *xr, const double *xi, int32_
     a.skipk = ((taps - 1) / 2) % 2; // cmaadaptivefilter.c:64
     if (R) { a.R1 = R[0]; a.R2 = R[1]; }
     int rc = launch_demux(method, a, nullptr);
-    if (!rc) {
-        hipMemcpy(hy.data(), dy, hy.size() * 8, hipMemcpyDeviceToHost);
-        hipMemcpy(hh.data(), dh, hh.size() * 8, hipMemcpyDeviceToHost);
-        // y is [dimY x 2]; the kernel wrote column p at offset p*Mdim
-        for (int p = 0; p < 2; p++)
-            for (int i = 0; i < dimY; i++) {
-                yr[(size_t)p * dimY + i] = hy[2 * ((size_t)p * Mdim + i)];
-                yi[(size_t)p * dimY + i] = hy[2 * ((size_t)p * Mdim + i) + 1];
-            }
-        // in-place tap update, as the reference MEX does through prhs[1..2] (:87-88)
-        for (int j = 0; j < 2 * taps; j++) {
-            h1r[j] = hh[2 * j]; if (h1i) h1i[j] = hh[2 * j + 1];
-            h2r[j] = hh[2 * (2 * taps + j)]; if (h2i) h2i[j] = hh[2 * (2 * taps + j) + 1];
+    if (rc) return rc;
+    PLX_HIP(hipMemcpyAsync(hh, dh, (nh + nx) * sizeof(double), hipMemcpyDeviceToHost, nullptr));   // h | y are adjacent
+    PLX_HIP(hipStreamSynchronize(nullptr));
+    // y is [dimY x 2]; the kernel wrote column p at offset p*Mdim
+    for (int p = 0; p < 2; p++)
+        for (int i = 0; i < dimY; i++) {
+            yr[(size_t)p * dimY + i] = hy[2 * ((size_t)p * Mdim + i)];
+            yi[(size_t)p * dimY + i] = hy[2 * ((size_t)p * Mdim + i) + 1];
         }
+    // in-place tap update, as the reference MEX does through prhs[1..2] (:87-88)
+    for (int j = 0; j < 2 * taps; j++) {
+        h1r[j] = hh[2 * j]; if (h1i) h1i[j] = hh[2 * j + 1];
+        h2r[j] = hh[2 * (2 * taps + j)]; if (h2i) h2i[j] = hh[2 * (2 * taps + j) + 1];
     }
-    cleanup();
-    return rc;
+    return PLX_OK;
 }
 
 extern "C" int plx_cmaadaptivefilter(const double *xr, const double *xi, int32_t Mdim, double *h1r, double *h1i,

@@ -30,6 +30,7 @@
 #include "plx_fft.h"
 #include <type_traits>
 #include "plx_internal.h"
+#include "plx_gateway.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -47,9 +48,11 @@ struct FrameCtl {
     double firstdz;
     double dzb_first, dzb_last;
     int ntot, nmem, ntrunk; // waveplate bookkeeping (:524-529)
-    int started, last, done, ncycle;
-    int pad_[3];
+    int started, last, ncycle;
+    int pad_[7];
+    int done;               // LAST word of the record: k_colx16 lands its copy by LDS-DMA and spins on this word (sentinel)
 };
+static_assert(sizeof(FrameCtl) == 128 && offsetof(FrameCtl, done) == 124, "done is the last word of the last 16-byte piece");
 
 struct SsfmArgs {
     cplx *ux, *uy;
@@ -68,6 +71,7 @@ struct SsfmArgs {
     int *nactive;                  // [0] length of the list, [1] running sum of it over the steps (utilisation accounting)
     long long spin_ticks;          // frame-barrier timeout in ticks of plx_clock() (10 ns)
     unsigned long long *slots;     // [2][nframes][tiles per frame] per-tile max |u|^2 by launch parity (k_colx16), ~0 = not arrived
+    int safe_land;                 // PLX_SSFM_SAFE_LANDING=1: the staged tile is also waited for with s_waitcnt vmcnt(0) (checks the sentinel landing)
     int round;                     // launch index of the fused sweep within this propagate call
     int *grab;                     // [2] frames claimed beyond the first of every team, by launch parity (k_colx16)
     unsigned long long *mbox;      // [teams][mbox_stride] the team's frame of iteration k, posted by its first workgroup: (launch, k, frame)
@@ -960,14 +964,6 @@ __device__ __forceinline__ void lds_settle() { asm volatile("s_waitcnt lgkmcnt(0
 __device__ __forceinline__ void emu_lockstep() {}
 #endif
 
-#ifdef PLX_STAMPS   // dev build only (scripts/experiments/stamps.sh): where a workgroup's tile time goes, 10 ns wall-clock stamps of thread 0
-__device__ long long g_stamps[32];
-__device__ long long g_wgwait[1024];
-__device__ long long g_wgend[1024], g_t0;    // per workgroup: wall clock at its exit of the last launch; earliest start   // per workgroup: time between its slot store and the frame's last arrival
-#define PLX_STAMP(i) do { if (tid == 0) { long long now_ = wall_clock64(); long long *st_ = (long long *)(red + 20); const long long d_ = now_ - st_[0]; st_[1 + (i)] += d_; ((long long *)((char *)(lctl + 8) + 128 + COLX_NFC * sizeof(double)))[i] += d_ * d_; st_[0] = now_; } } while (0)
-#else
-#define PLX_STAMP(i) do { } while (0)
-#endif
 
 __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf)
 {
@@ -1027,9 +1023,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         pin(ln);                           // (the address is formed here: kept across the tile loop it would sit in scratch)
         if (ln < (int)(sizeof(FrameCtl) / 16)) glds16((const cplx *)(a.ctl + f) + ln, (cplx *)rec, ln);
     };
-#ifdef PLX_STAMPS
-    if (tid == 0) { long long *st_ = (long long *)(red + 20); for (int i = 1; i < 12; i++) st_[i] = 0;   /* red[20..31] */ for (int i = 0; i < 16; i++) ((long long *)((char *)(lctl + 8) + 128 + COLX_NFC * sizeof(double)))[i] = 0; st_[0] = wall_clock64(); }
-#endif
+    // [stamps:init]
     double *const gaml = (double *)((char *)(lctl + 8) + 128);    // gam[channel] (at most COLX_NFC channels: checked by the plan)
     for (int k = tid; k < a.nfc; k += 256) gaml[k] = a.gam[k];
     int f = team < nact ? a.active[team] : -1;
@@ -1058,10 +1052,11 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     for (;; it++) {
         FrameCtl *const wrec = lctl + 4 * (it & 1) + (tid >> 6);
         const int fc = f * a.nfc + c;
-        PLX_STAMP(0);                      // loop top
+        // [phase 0] loop top
+        if (a.safe_land) drain_vmem();     // (checking mode: the ordinary wait as well -- results must not depend on it)
         while (lds_peek(&wrec->done) == PLX_REC_SENTINEL) nap();   // this wave's rows of the tile and its copy of the record are in LDS
         emu_lockstep();
-        PLX_STAMP(1);                      // wait for the staged tile
+        // [phase 1] wait for the staged tile
         if (wrec->done) {                  // a listed frame that has finished meanwhile (the same answer in every wave)
             if (tid == 0) {
                 settle((it & 1) ^ 1);
@@ -1101,7 +1096,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             }
         }
         lds_barrier();
-        PLX_STAMP(2);                      // r16_dit + exchange write + workgroup barrier
+        // [phase 2] r16_dit + exchange write + workgroup barrier
         cplx y[16];                        // point j + 16k
 #pragma unroll
         for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
@@ -1123,7 +1118,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         m = wave_max(m);
         if ((tid & 63) == 0) red[tid >> 6] = m;
         lds_barrier();
-        PLX_STAMP(3);                      // exchange read + lvl2_dit + scale + max
+        // [phase 3] exchange read + lvl2_dit + scale + max
         // Frame barrier (dz of the next step needs the frame-wide maximum, fiber.m:694-698): an all-gather.  Every workgroup
         // stores its tile maximum into its own slot, then its first wave polls the slots of the whole frame and runs the
         // step controller itself on its copy of the record (the same inputs, the same instructions: the same step in every
@@ -1159,13 +1154,8 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                     if (b == ~0ull) all = false;
                     else { const double gp = gaml[i / tiles_x] * __longlong_as_double((long long)b); pm = gp > pm ? gp : pm; }
                 }
-#ifdef PLX_STAMPS
-                if (tid == 0) ((long long *)(red + 20))[11] += 1;       // (dev) polls
-#endif
+    // [stamps:poll]
                 if (__all(all)) break;
-#ifdef PLX_NOWAIT   // dev build, TIMING ONLY (wrong results): nobody waits for the rest of the frame
-                break;
-#endif
                 nap();
                 if ((++spins & 255u) == 0) {           // (wave-uniform: every lane evaluates the same test)
                     const int late = ld_agent((const unsigned *)a.ndone + 1) != 0 || plx_clock() - t0 > a.spin_ticks;
@@ -1173,7 +1163,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                 }
             }
             pm = wave_max(pm);
-            PLX_STAMP(8);                  // (dev) slot store -> every slot of the frame seen
+            // [phase 8] (dev) slot store -> every slot of the frame seen
             if (tid == 0) {
                 red[10 + (it & 1)] = (double)((int)(mv & 0x3fffffull) - 1);
                 if (dead) {
@@ -1189,7 +1179,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             post(it + 2);                  // (this wave only waits for the first one here)
         }
         lds_barrier();
-        PLX_STAMP(4);                      // frame barrier
+        // [phase 4] frame barrier
         if (red[19] != 0.0) return;        // barrier timed out (uniform over the workgroup): no store, no control update
         const double leff = red[16];
         const bool finished = red[17] != 0.0;
@@ -1256,7 +1246,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                     lds_barrier();
                 }
             }
-            PLX_STAMP(5);                  // Kerr step
+            // [phase 5] Kerr step
             lvl2_dif256(y, j, tw);
 #pragma unroll
             for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
@@ -1265,7 +1255,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
 #pragma unroll
             for (int k = 0; k < 16; k++) x[k] = s[((16 * j + k) << 4) + t];
             lds_barrier();               // the exchange buffer is free: the next tile may land in it ...
-            PLX_STAMP(6);                  // lvl2_dif + exchange
+            // [phase 6] lvl2_dif + exchange
             {
                 const int nf = (int)red[10 + (it & 1)];
                 if (nf >= 0) stage(nf, (it & 1) ^ 1);
@@ -1273,19 +1263,14 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             r16_dif(x);                    // ... during the last register transform and the stores of this one
 #pragma unroll
             for (int k = 0; k < 16; k++) fld[cbase + (size_t)(16 * j + k) * N2] = x[k];
-            PLX_STAMP(7);                  // staging issue + r16_dif + stores issued
+            // [phase 7] staging issue + r16_dif + stores issued
         }
         f = (int)red[10 + (it & 1)];
-#ifdef PLX_STAMPS
-        if (tid == 0) ((long long *)(red + 20))[10] += 1;
-#endif
+    // [stamps:iter]
         if (f < 0) { it++; break; }
     }
     if (tid == 0) settle((it & 1) ^ 1);
-#ifdef PLX_STAMPS
-    if (tid == 0 && blockIdx.x < 1024) { g_wgwait[blockIdx.x] += ((const long long *)(red + 20))[1 + 8]; g_wgend[blockIdx.x] = wall_clock64(); }
-    if (tid == 0) { const long long *st_ = (const long long *)(red + 20); for (int i = 0; i < 11; i++) atomicAdd((unsigned long long *)&g_stamps[i], (unsigned long long)st_[1 + i]); for (int i = 0; i < 9; i++) atomicAdd((unsigned long long *)&g_stamps[16 + i], (unsigned long long)((const long long *)(lctl + 8))[i]); }
-#endif
+    // [stamps:exit]
 }
 
 } // namespace
@@ -1319,6 +1304,8 @@ struct plx_ssfm {
     double *h_brf[2] = {nullptr, nullptr}; // pinned staging of the waveplate tables
     hipEvent_t brf_ev[2] = {nullptr, nullptr};
     int brf_slot = 0;
+    int group_frames = 0;          // frames per cache-resident group of a propagate call (0: the whole batch at once)
+    int last_group_steps = 0;      // launches the previous group of the current call needed (sizes the next group's first chunk)
     int64_t row_launches = 0, sample_steps = 0;
     int64_t slots_launched = 0, slots_listed = 0, frame_steps = 0;   // utilisation accounting of the last propagate
     // optional per-kernel timing of the step loop (plx_ssfm_profile): one event between consecutive launches
@@ -1330,6 +1317,7 @@ struct plx_ssfm {
 };
 
 static const double kInv2Pi = 0.15915494309189533577;
+static const double kDefaultGroupMiB = 0.0;   // field MiB per cache-resident frame group (0: off); PLX_SSFM_GROUP_MIB overrides
 
 static int ilog2(int64_t v)
 {
@@ -1384,8 +1372,8 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0;
-    double barrier_timeout_ms = 500.0;
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0;
+    double barrier_timeout_ms = 500.0, group_mib = -1.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
     {
@@ -1396,7 +1384,9 @@ struct Tune {
         row_threads = geti("PLX_SSFM_ROW_THREADS", -1);
         col_threads = geti("PLX_SSFM_COL_THREADS", -1);
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
+        safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
         if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
+        if (const char *e = getenv("PLX_SSFM_GROUP_MIB")) group_mib = atof(e);
     }
 };
 bool pow2_in(int v, int lo, int hi) { return v >= lo && v <= hi && (v & (v - 1)) == 0; }
@@ -1486,6 +1476,9 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     a.lcorr = desc->length / desc->nplates; // fiber.m:507
     a.invN = 1.0 / (double)N;
     a.spin_ticks = (long long)(tune.barrier_timeout_ms * 1e5);
+    a.safe_land = tune.safe_landing;
+    // (the mailbox entries of k_colx16 pack frame + 1 and iteration + 1 into 22-bit fields)
+    if ((int64_t)desc->max_frames + 4 >= ((int64_t)1 << 22)) { free_plan(P); PLX_FAIL(PLX_ERR_UNSUPPORTED, "plx_ssfm_create: max_frames must be below 2^22 - 4"); }
 
     // ---- tables: spectral multipliers in the order the row pass sees them ----
     std::vector<double> bt((size_t)nfc * N), d1;
@@ -1550,9 +1543,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     P->h_ctl.resize(F);
 
     P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double) + 8 * sizeof(FrameCtl) + 128 + COLX_NFC * sizeof(double);   // (128: CtrlK)
-#ifdef PLX_STAMPS
-    P->lds_col += 128;
-#endif
+    // [stamps:lds]
     P->lds_row = ((size_t)(a.dual ? 2 : 1) * a.R * (N2 + N2 / 16) + N2 / 2) * sizeof(cplx);
     P->col_threads = P->lds_col > 80 * 1024 ? 1024 : 512;   // measured: 512-thread column workgroups (2 per CU, 16 waves) beat
                                                             // 256 by 3-12 %; tall tiles of large frames: one workgroup per CU, 16 waves
@@ -1595,6 +1586,19 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             a.mbox_stride = mstride;
             a.grab = (int *)(P->d_mbox + (size_t)mstride * (P->fused_grid / tiles_pf));
         }
+    }
+    // Cache-resident frame groups (plx_ssfm_propagate_dev): group_mib MiB of field per group, a whole number of rounds of
+    // the fused sweep's teams.  0 / unset groups: the whole batch at once.
+    {
+        const double frame_mib = (double)nfc * (double)N * (a.dual ? 32.0 : 16.0) / (1024.0 * 1024.0);
+        const double mib = tune.group_mib >= 0 ? tune.group_mib : kDefaultGroupMiB;
+        int G = mib > 0 ? (int)(mib / frame_mib) : 0;
+        if (G > 0) {
+            const int teams = P->fused ? P->fused_grid / P->tiles_pf : 1;
+            if (G > teams) G -= G % teams;
+            if (G < 1) G = 1;
+        }
+        P->group_frames = G;
     }
     if (a.pmd && !a.dual) { free_plan(P); PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: PMD needs a dual-polarisation plan"); }
     if (!a.pmd) { // fiber.m:291-297: birefringence off
@@ -1689,26 +1693,25 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
     PLX_LAUNCH(k_row, dim3((unsigned)(N1 / a.R), FC), dim3((unsigned)P->row_threads), P->lds_row, st, a);
 }
 
-extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, int nframes, void *stream)
+// One GROUP of frames through the whole step loop (fiber.m:518-552).  g0: first frame of the group within the call.
+static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nframes, hipStream_t st)
 {
-    if (!P || !d_ux) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: null argument");
-    if (nframes < 1 || nframes > P->d.max_frames) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: nframes out of range");
-    if (P->a.dual && !d_uy) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: dual-polarisation plan needs d_uy");
-    if (P->a.brf_per_frame && P->brf_sets < nframes)
-        PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: fewer birefringence sets than frames");
-    hipStream_t st = (hipStream_t)stream;
     SsfmArgs a = P->a;
-    a.ux = (cplx *)d_ux;
-    a.uy = (cplx *)d_uy;
+    const int nfc = a.nfc, N1 = 1 << a.p1, N2 = 1 << a.p2;
+    // everything indexed by frame is addressed from the group's first frame: the kernels see frames 0 .. nframes-1
+    a.ux = d_ux + (size_t)g0 * nfc * P->N;
+    a.uy = d_uy ? d_uy + (size_t)g0 * nfc * P->N : nullptr;
+    a.ctl = P->d_ctl + g0;
+    a.umax = P->d_umax + (size_t)g0 * nfc;
+    if (a.brf_per_frame) a.brf = P->d_brf + (size_t)g0 * a.nplates * BRF_STRIDE;
+    if (a.psum) a.psum = P->d_psum + (size_t)g0 * P->N;
     a.nframes = nframes;
     a.active = P->d_active;
     a.nactive = P->d_ndone + 2;
-    const int nfc = a.nfc, N1 = 1 << a.p1, N2 = 1 << a.p2;
     unsigned FC = (unsigned)nframes * nfc;      // frame-channels launched: shrinks with the host's (lagging) view of the active list
-    PLX_HIP(hipMemsetAsync(P->d_ctl, 0, sizeof(FrameCtl) * nframes, st));
-    PLX_HIP(hipMemsetAsync(P->d_umax, 0, sizeof(unsigned long long) * FC, st));
+    PLX_HIP(hipMemsetAsync(a.ctl, 0, sizeof(FrameCtl) * nframes, st));
+    PLX_HIP(hipMemsetAsync(a.umax, 0, sizeof(unsigned long long) * FC, st));
     PLX_HIP(hipMemsetAsync(P->d_ndone, 0, 64, st));
-    P->slots_launched = 0;
     const bool fused = P->fused != 0;
     if (fused) { // the first fused launch also forms nextstep's initial maximum
         PLX_HIP(hipMemsetAsync(P->d_slots, 0xFF, sizeof(unsigned long long) * 2 * (size_t)nframes * P->tiles_pf, st));   // ~0 = "not arrived"; [parity][frame][tile]
@@ -1721,8 +1724,6 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     const dim3 blk(256);
     const dim3 gctl((unsigned)((nframes + 63) / 64)), bctl(64);
     const dim3 bcol((unsigned)P->col_threads);
-    const int rowthr = P->row_threads;
-    P->row_launches = 0;
     // Data-dependent trip count (fiber.m:518): steps are enqueued in chunks; the completed-frame counter and the
     // abort word of chunk k are read back while chunk k+1 executes.
     // The sweeps of a step cover the frames of the active list (k_compact, once per step); their grids follow the
@@ -1731,7 +1732,10 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     // steps are launch-bound: the sweeps skip a listed frame that has finished meanwhile)
     const bool compact_every_step = nframes >= 64;
     int chunk = 4, steps = 0;
-    const int kMaxSteps = getenv("PLX_DBG_MAX_STEPS") ? atoi(getenv("PLX_DBG_MAX_STEPS")) : (1 << 22);
+    // (a group that follows another one of the same call starts with the steps the previous group needed, less a
+    //  margin: frames of a batch usually resemble each other, and every launch past a group's end is an idle one)
+    if (g0 > 0 && P->last_group_steps > 12) chunk = P->last_group_steps - 4;
+    const int kMaxSteps = 1 << 19;      // (far beyond any physical span; also below the period of the mailbox tags of k_colx16)
     bool pending = false, aborted = false;
     // profiling: an event in front of every launch of the loop (and one after the last); intervals are attributed to
     // the kernel class that follows the event.  Classes: 0 k_colx16 / k_col_fwd, 1 k_row, 2 k_col_inv, 3 control.
@@ -1758,7 +1762,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
                 const dim3 gx((unsigned)(tct < P->fused_grid ? tct : P->fused_grid));
                 if (compact_every_step || sidx == 0) {
                     PLX_MARK(3, steps + sidx);
-                    PLX_LAUNCH(k_compact, dim3(1), dim3(COMPACT_THREADS), COMPACT_THREADS * sizeof(int), st, (const FrameCtl *)P->d_ctl, nframes, P->d_active, P->d_ndone + 2,
+                    PLX_LAUNCH(k_compact, dim3(1), dim3(COMPACT_THREADS), COMPACT_THREADS * sizeof(int), st, (const FrameCtl *)a.ctl, nframes, P->d_active, P->d_ndone + 2,
                                compact_every_step ? 1 : chunk);
                 }
 #ifdef PLX_EMU
@@ -1779,7 +1783,7 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
             PLX_MARK(3, steps + sidx);
             PLX_LAUNCH(k_ctrl, gctl, bctl, 0, st, a, nframes);
             if (compact_every_step || sidx == 0)
-                PLX_LAUNCH(k_compact, dim3(1), dim3(COMPACT_THREADS), COMPACT_THREADS * sizeof(int), st, (const FrameCtl *)P->d_ctl, nframes, P->d_active, P->d_ndone + 2,
+                PLX_LAUNCH(k_compact, dim3(1), dim3(COMPACT_THREADS), COMPACT_THREADS * sizeof(int), st, (const FrameCtl *)a.ctl, nframes, P->d_active, P->d_ndone + 2,
                                compact_every_step ? 1 : chunk);
             if (!a.dual && a.xpm) {
                 unsigned gx = (unsigned)((P->N + 255) / 256);
@@ -1806,43 +1810,30 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
         PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         PLX_HIP(hipEventRecord(P->ev, st));
         pending = true;
-        if (chunk < (compact_every_step ? 8 : 16)) chunk *= 2;   // (small batches are launch-bound: longer chunks keep the queue fed)
-        if (steps > kMaxSteps) {
-            if (getenv("PLX_DBG_MAX_STEPS")) {
-                hipStreamSynchronize(st);
-                std::vector<FrameCtl> hc(nframes);
-                hipMemcpy(hc.data(), P->d_ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost);
-                int hd[4]; hipMemcpy(hd, P->d_ndone, sizeof(hd), hipMemcpyDeviceToHost);
-                fprintf(stderr, "DBG steps %d ndone %d abort %d nactive %d FC %u\n", steps, hd[0], hd[1], hd[2], FC);
-                for (int i = 0; i < nframes; i++)
-                    fprintf(stderr, "DBG frame %d: started %d last %d done %d ncycle %d zprop %.6g dz %.6g cur %.6g leff %.6g att %.6g\n", i, hc[i].started, hc[i].last,
-                            hc[i].done, hc[i].ncycle, hc[i].zprop, hc[i].dz, hc[i].cur, hc[i].leff, hc[i].att);
-            }
-            PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate");
-        }
+        if (chunk > 8) chunk = 4;                                     // (after a predicted first chunk)
+        else if (chunk < (compact_every_step ? 8 : 16)) chunk *= 2;   // (small batches are launch-bound: longer chunks keep the queue fed)
+        if (steps > kMaxSteps) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate");
     }
-    PLX_HIP(hipMemcpyAsync(P->h_ctl.data(), P->d_ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost, st));
+    PLX_HIP(hipMemcpyAsync(P->h_ctl.data() + g0, a.ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost, st));
     PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     PLX_HIP(hipStreamSynchronize(st));
-    P->slots_listed = P->h_ndone[3];
+    P->slots_listed += P->h_ndone[3];
     if (aborted || P->h_ndone[1])
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: frame barrier timed out (the workgroups of a frame were not co-resident: "
                               "another kernel holds the GPU); nothing was stored after the timeout -- create the plan with "
                               "PLX_SSFM_NO_FUSE=1 to share the device");
-    P->sample_steps = 0;
-    P->frame_steps = 0;
     int maxnc = 0;
-    for (int f = 0; f < nframes; f++) {
+    for (int f = g0; f < g0 + nframes; f++) {
         P->frame_steps += P->h_ctl[f].ncycle + (fused ? 1 : 0);   // (the fused sweep's last round writes the field out)
         if (!P->h_ctl[f].done) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: a frame did not reach the fibre end");
         P->sample_steps += (int64_t)P->h_ctl[f].ncycle * (int64_t)P->N * nfc;
         if (P->h_ctl[f].ncycle > maxnc) maxnc = P->h_ctl[f].ncycle;
     }
+    P->last_group_steps = maxnc + (fused ? 1 : 0);
     if (P->profile) {
         // ACTIVE launches only: the chunked loop also issues launches after every frame has finished (they return at
         // once).  Step s of the slowest frame is its (s+1)-th; the fused column sweep needs one more round to finish
         // the last step and write the field out.
-        for (int k = 0; k < 4; k++) { P->k_ms[k] = 0; P->k_launches[k] = 0; }
         for (size_t i = 0; i + 1 < nev; i++) {
             const int cls = P->ev_class[i], step = P->ev_step[i];
             const bool active = (fused && cls == 0) ? step <= maxnc : step < maxnc;
@@ -1854,6 +1845,27 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
         }
     }
 #undef PLX_MARK
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, int nframes, void *stream)
+{
+    if (!P || !d_ux) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: null argument");
+    if (nframes < 1 || nframes > P->d.max_frames) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: nframes out of range");
+    if (P->a.dual && !d_uy) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: dual-polarisation plan needs d_uy");
+    if (P->a.brf_per_frame && P->brf_sets < nframes)
+        PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: fewer birefringence sets than frames");
+    P->slots_launched = 0; P->slots_listed = 0; P->row_launches = 0; P->sample_steps = 0; P->frame_steps = 0;
+    for (int k = 0; k < 4; k++) { P->k_ms[k] = 0; P->k_launches[k] = 0; }
+    // Frames are independent (fiber.m:518: each has its own step sequence), so a large batch is taken through the span in
+    // GROUPS whose fields fit the 256 MiB Infinity Cache: a group's ~50 steps x 2 sweeps then re-read what the previous
+    // sweep left on the die instead of streaming the whole batch from HBM twice per step (plan: group_frames).
+    const int G = P->group_frames > 0 ? P->group_frames : nframes;
+    for (int g0 = 0; g0 < nframes; g0 += G) {
+        const int nf = nframes - g0 < G ? nframes - g0 : G;
+        const int rc = propagate_group(P, (cplx *)d_ux, (cplx *)d_uy, g0, nf, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     PLX_HIP(hipGetLastError());
     return PLX_OK;
 }
@@ -1956,6 +1968,9 @@ extern "C" int plx_ssfm_stats(plx_ssfm *P, int64_t *row_pass_launches, int64_t *
 }
 
 // ---- gateway forms (one frame, split planes, host memory) --------------------------
+// One call = one `fiber()` span of the unchanged MATLAB wrapper (fiber.m:372-389).  The plan, the device field buffers
+// and the pinned staging area belong to the library (plx_gateway.h): a span on the same fibre type and grid finds its
+// plan (content hash of the descriptor's scalars and tables) and allocates nothing.
 static int gateway_ssfm(double *uxr, double *uxi, double *uyr, double *uyi, const plx_ssfm_desc *desc,
                         const double *db0, const double *theta, const double *epsilon, double *firstdz,
                         int32_t *ncycle)
@@ -1966,40 +1981,35 @@ static int gateway_ssfm(double *uxr, double *uxi, double *uyr, double *uyi, cons
     const bool dual = d.dual_pol != 0;
     if (dual && !uyr) PLX_FAIL(PLX_ERR_ARG, "matrix_ssfm gateway: missing y field");
     if (!uxi || (dual && !uyi)) PLX_FAIL(PLX_ERR_ARG, "ssfm gateway: output imaginary planes are required");
-    plx_ssfm *P = nullptr;
-    int rc = plx_ssfm_create(&P, &d);
-    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(plxgw::mutex());
+    plxgw::count_call();
+    int rc = PLX_OK;
+    plx_ssfm *P = plxgw::ssfm_plan(d, &rc);
+    if (!P) return rc;
     if (dual && d.fls[1]) {
-        rc = plx_ssfm_set_birefringence(P, db0, theta, epsilon, 1);
-        if (rc) { plx_ssfm_destroy(P); return rc; }
+        rc = set_brf(P, db0, theta, epsilon, 1, nullptr, false);
+        if (rc) return rc;
     }
-    const size_t n = (size_t)d.nfft * d.nfc;
-    std::vector<double> hx(2 * n), hy(dual ? 2 * n : 0);
+    const size_t n = (size_t)d.nfft * d.nfc, npol = dual ? 2 : 1;
+    const size_t bytes = npol * 2 * n * sizeof(double);
+    double *h = (double *)plxgw::pinned(plxgw::S_IN, bytes);
+    double *dx = (double *)plxgw::dev(plxgw::S_IN, bytes);
+    if (!h || !dx) return PLX_ERR_HIP;
+    double *dy = dual ? dx + 2 * n : nullptr, *hy = h + 2 * n;
     for (size_t i = 0; i < n; i++) {
-        hx[2 * i] = uxr[i]; hx[2 * i + 1] = uxi[i];
+        h[2 * i] = uxr[i]; h[2 * i + 1] = uxi[i];
         if (dual) { hy[2 * i] = uyr[i]; hy[2 * i + 1] = uyi[i]; }
     }
-    double *dx = nullptr, *dy = nullptr;
-    auto cleanup = [&]() { hipFree(dx); hipFree(dy); plx_ssfm_destroy(P); };
-    if (hipMalloc((void **)&dx, 2 * n * sizeof(double)) != hipSuccess ||
-        (dual && hipMalloc((void **)&dy, 2 * n * sizeof(double)) != hipSuccess)) {
-        cleanup();
-        PLX_FAIL(PLX_ERR_HIP, "ssfm gateway: device allocation failed");
-    }
-    hipMemcpy(dx, hx.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice);
-    if (dual) hipMemcpy(dy, hy.data(), 2 * n * sizeof(double), hipMemcpyHostToDevice);
+    PLX_HIP(hipMemcpyAsync(dx, h, bytes, hipMemcpyHostToDevice, nullptr));
     rc = plx_ssfm_propagate_dev(P, dx, dy, 1, nullptr);
-    if (!rc) {
-        hipMemcpy(hx.data(), dx, 2 * n * sizeof(double), hipMemcpyDeviceToHost);
-        if (dual) hipMemcpy(hy.data(), dy, 2 * n * sizeof(double), hipMemcpyDeviceToHost);
-        for (size_t i = 0; i < n; i++) {
-            uxr[i] = hx[2 * i]; uxi[i] = hx[2 * i + 1];
-            if (dual) { uyr[i] = hy[2 * i]; uyi[i] = hy[2 * i + 1]; }
-        }
-        plx_ssfm_results(P, 1, firstdz, ncycle);
+    if (rc) return rc;
+    PLX_HIP(hipMemcpyAsync(h, dx, bytes, hipMemcpyDeviceToHost, nullptr));
+    PLX_HIP(hipStreamSynchronize(nullptr));
+    for (size_t i = 0; i < n; i++) {
+        uxr[i] = h[2 * i]; uxi[i] = h[2 * i + 1];
+        if (dual) { uyr[i] = hy[2 * i]; uyi[i] = hy[2 * i + 1]; }
     }
-    cleanup();
-    return rc;
+    return plx_ssfm_results(P, 1, firstdz, ncycle);
 }
 
 extern "C" int plx_matrix_ssfm(double *uxr, double *uxi, double *uyr, double *uyi, const plx_ssfm_desc *desc,
@@ -2103,19 +2113,24 @@ extern "C" int plx_scalar_ssfm_adaptive(double *ur, double *ui, const plx_ssfm_d
     if (tolflag != 1 && tolflag != 2) PLX_FAIL(PLX_ERR_ARG, "plx_scalar_ssfm_adaptive: tolflag must be 1 or 2");
     plx_ssfm_desc d = *desc;
     d.max_frames = 1;
-    plx_ssfm *P = nullptr;
-    int rc = plx_ssfm_create(&P, &d);
-    if (rc) return rc;
+    // plan, the three field copies of adaptssfm and the staging area come from the library's gateway workspace
+    std::lock_guard<std::mutex> lk(plxgw::mutex());
+    plxgw::count_call();
+    int rc = PLX_OK;
+    plx_ssfm *P = plxgw::ssfm_plan(d, &rc);
+    if (!P) return rc;
+    const SsfmArgs saved = P->a;          // (the resume fields below are per call: the cached plan is handed back as it was)
     const size_t n = (size_t)d.nfft * d.nfc;
-    std::vector<double> h(2 * n);
+    double *h = (double *)plxgw::pinned(plxgw::S_IN, 2 * n * sizeof(double));
+    cplx *fld = (cplx *)plxgw::dev(plxgw::S_IN, (3 * n + 8) * sizeof(cplx));
+    if (!h || !fld) return PLX_ERR_HIP;
     for (size_t i = 0; i < n; i++) { h[2 * i] = ur[i]; h[2 * i + 1] = ui[i]; }
     Adaptive A;
-    A.P = P; A.a = P->a; A.st = nullptr; A.n = n; A.u = A.uh = A.stack = nullptr; A.d_max = nullptr;
+    A.P = P; A.a = P->a; A.st = nullptr; A.n = n; A.u = fld; A.uh = fld + n; A.stack = fld + 2 * n;
+    A.d_max = (unsigned long long *)(fld + 3 * n);
     A.a.nframes = 1; A.alphalin = d.alphalin; A.fls2 = d.fls[2]; A.fls3 = d.fls[3];
-    auto cleanup = [&]() { hipFree(A.u); hipFree(A.uh); hipFree(A.stack); hipFree(A.d_max); plx_ssfm_destroy(P); };
-    if (hipMalloc((void **)&A.u, n * sizeof(cplx)) != hipSuccess || hipMalloc((void **)&A.uh, n * sizeof(cplx)) != hipSuccess ||
-        hipMalloc((void **)&A.stack, n * sizeof(cplx)) != hipSuccess || hipMalloc((void **)&A.d_max, 64) != hipSuccess ||
-        hipMemcpy(A.u, h.data(), n * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
+    auto cleanup = [&]() { P->a = saved; };
+    if (hipMemcpy(A.u, h, n * sizeof(cplx), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(P->d_ctl, 0, sizeof(FrameCtl)) != hipSuccess || hipMemset(P->d_ndone, 0, 64) != hipSuccess ||
         hipMemset(P->d_umax, 0, sizeof(unsigned long long) * d.nfc) != hipSuccess) {
         cleanup();
@@ -2149,7 +2164,7 @@ extern "C" int plx_scalar_ssfm_adaptive(double *ur, double *ui, const plx_ssfm_d
             if (A.trial(zdone, dz, ltol, safety, nrej, ncycle)) { cleanup(); PLX_FAIL(PLX_ERR_HIP, "plx_scalar_ssfm_adaptive: HIP failure in adaptssfm"); }
             if (dz > d.dzmaxt) dz = d.dzmaxt;
         }
-        rc = (hipMemcpy(h.data(), A.u, n * sizeof(cplx), hipMemcpyDeviceToHost) == hipSuccess) ? PLX_OK : PLX_ERR_HIP;
+        rc = (hipMemcpy(h, A.u, n * sizeof(cplx), hipMemcpyDeviceToHost) == hipSuccess) ? PLX_OK : PLX_ERR_HIP;
     } else { // dphiadapt: adaptive first step, then the constant-phase loop (:588-636)
         if (dz >= d.dzmaxt) { // :589-597
             if (d.alphalin == 0) dphimaxt = maxpow * dz;
@@ -2168,7 +2183,7 @@ extern "C" int plx_scalar_ssfm_adaptive(double *ur, double *ui, const plx_ssfm_d
         P->a.resume = 1; P->a.dz0 = dz; P->a.zdone0 = zdone; P->a.ncycle0 = ncycle; P->a.dphimax = dphimaxt;
         rc = plx_ssfm_propagate_dev(P, (double *)A.u, nullptr, 1, nullptr);
         if (!rc) {
-            rc = (hipMemcpy(h.data(), A.u, n * sizeof(cplx), hipMemcpyDeviceToHost) == hipSuccess) ? PLX_OK : PLX_ERR_HIP;
+            rc = (hipMemcpy(h, A.u, n * sizeof(cplx), hipMemcpyDeviceToHost) == hipSuccess) ? PLX_OK : PLX_ERR_HIP;
             *firstdz = P->h_ctl[0].firstdz;
             ncycle = P->h_ctl[0].ncycle;
         }
@@ -2182,14 +2197,3 @@ extern "C" int plx_scalar_ssfm_adaptive(double *ur, double *ui, const plx_ssfm_d
     return PLX_OK;
 }
 
-#ifdef PLX_STAMPS
-extern "C" void plx_ssfm_stamps(long long *out, int reset)
-{
-    hipDeviceSynchronize();
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 32);
-    hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_wgwait), sizeof(long long) * 1024);
-    hipMemcpyFromSymbol(out + 32 + 1024, HIP_SYMBOL(g_wgend), sizeof(long long) * 1024);
-    if (reset) { static long long zz[1024]; hipMemcpyToSymbol(HIP_SYMBOL(g_wgwait), zz, sizeof(zz)); }
-    if (reset) { long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }
-}
-#endif

@@ -1,15 +1,17 @@
 #!/bin/bash
-# dev experiment: where a k_colx16 workgroup's tile time goes (PLX_STAMPS build of the library, thread-0 wall-clock stamps).
-# usage: scripts/experiments/stamps.sh build   (here: cross-compiles polmux_amd/lib/libpolmux_hip_stamps.so)
+# dev experiment: where a k_colx16 workgroup's tile time goes (instrumented copy of the library, thread-0 wall-clock stamps).
+# usage: scripts/experiments/stamps.sh build [--nowait]   (here: instruments a COPY of plx_ssfm.hip with stamps_patch.py and cross-compiles polmux_amd/lib/libpolmux_hip_stamps.so)
 #        gpurun -- bash scripts/experiments/stamps.sh run [frames]
 set -e
 cd "$(dirname "$0")/../.."
 if [ "$1" = build ]; then
   mkdir -p build_stamps
+  python3 scripts/experiments/stamps_patch.py $2 > /dev/null
   OBJS=""
   for f in polmux_amd/csrc/*.hip; do
     o=build_stamps/$(basename ${f%.hip}).o
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-unused-result -DPLX_STAMPS $PLX_EXTRA_HIPCC_FLAGS -c $f -o $o &
+    [ $(basename $f) = plx_ssfm.hip ] && f=build_stamps/plx_ssfm.hip
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -I polmux_amd/csrc $PLX_EXTRA_HIPCC_FLAGS -c $f -o $o &
     OBJS="$OBJS $o"
   done
   wait

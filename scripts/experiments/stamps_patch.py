@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""dev tool: make the STAMPS copy of plx_ssfm.hip (thread-0 wall-clock stamps of k_colx16's phases).
+
+The product source carries only marker comments (`// [phase N] ...`, `// [stamps:init|poll|iter|exit|lds]`); this script
+writes an instrumented copy to build_stamps/plx_ssfm.hip (git-ignored) in which the markers are replaced by the
+stamping code below.  scripts/experiments/stamps.sh builds libpolmux_hip_stamps.so from that copy.
+--nowait additionally makes nobody wait at the frame barrier (TIMING ONLY: wrong results)."""
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+SRC = os.path.join(ROOT, "polmux_amd", "csrc", "plx_ssfm.hip")
+DST = os.path.join(ROOT, "build_stamps", "plx_ssfm.hip")
+
+DEFS = "__device__ long long g_stamps[32];\n__device__ long long g_wgwait[1024];\n__device__ long long g_wgend[1024], g_t0;    // per workgroup: wall clock at its exit of the last launch; earliest start   // per workgroup: time between its slot store and the frame's last arrival\n#define PLX_STAMP(i) do { if (tid == 0) { long long now_ = wall_clock64(); long long *st_ = (long long *)(red + 20); const long long d_ = now_ - st_[0]; st_[1 + (i)] += d_; ((long long *)((char *)(lctl + 8) + 128 + COLX_NFC * sizeof(double)))[i] += d_ * d_; st_[0] = now_; } } while (0)"
+BLOCKS = {'init': '    if (tid == 0) { long long *st_ = (long long *)(red + 20); for (int i = 1; i < 12; i++) st_[i] = 0;   /* red[20..31] */ for (int i = 0; i < 16; i++) ((long long *)((char *)(lctl + 8) + 128 + COLX_NFC * sizeof(double)))[i] = 0; st_[0] = wall_clock64(); }', 'poll': '                if (tid == 0) ((long long *)(red + 20))[11] += 1;       // (dev) polls', 'iter': '        if (tid == 0) ((long long *)(red + 20))[10] += 1;', 'exit': '    if (tid == 0 && blockIdx.x < 1024) { g_wgwait[blockIdx.x] += ((const long long *)(red + 20))[1 + 8]; g_wgend[blockIdx.x] = wall_clock64(); }\n    if (tid == 0) { const long long *st_ = (const long long *)(red + 20); for (int i = 0; i < 11; i++) atomicAdd((unsigned long long *)&g_stamps[i], (unsigned long long)st_[1 + i]); for (int i = 0; i < 9; i++) atomicAdd((unsigned long long *)&g_stamps[16 + i], (unsigned long long)((const long long *)(lctl + 8))[i]); }', 'lds': '    P->lds_col += 128;'}
+HOST = 'extern "C" void plx_ssfm_stamps(long long *out, int reset)\n{\n    hipDeviceSynchronize();\n    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(long long) * 32);\n    hipMemcpyFromSymbol(out + 32, HIP_SYMBOL(g_wgwait), sizeof(long long) * 1024);\n    hipMemcpyFromSymbol(out + 32 + 1024, HIP_SYMBOL(g_wgend), sizeof(long long) * 1024);\n    if (reset) { static long long zz[1024]; hipMemcpyToSymbol(HIP_SYMBOL(g_wgwait), zz, sizeof(zz)); }\n    if (reset) { long long z[32] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)); }\n}'
+
+
+def main():
+    s = open(SRC).read()
+    anchor = "__global__ __launch_bounds__(256, 2) void k_colx16("
+    assert anchor in s
+    s = s.replace(anchor, DEFS + "\n" + anchor, 1)
+    s, n = re.subn(r"^(\s*)// \[phase (\d+)\]", lambda m: "%sPLX_STAMP(%s); //" % (m.group(1), m.group(2)), s, flags=re.M)
+    assert n >= 9, n
+    for name, body in BLOCKS.items():
+        mark = "    // [stamps:%s]\n" % name
+        assert mark in s, name
+        s = s.replace(mark, body + "\n")
+    if "--nowait" in sys.argv:
+        s = s.replace("                if (__all(all)) break;\n", "                if (__all(all)) break;\n                break;   // NOWAIT: timing only\n", 1)
+    s += "\n" + HOST + "\n"
+    csrc = os.path.join(ROOT, "polmux_amd", "csrc")
+    s = s.replace('#include "../../include/polmux_hip.h"', '#include "%s"' % os.path.join(ROOT, "include", "polmux_hip.h"))
+    for h in ("plx_fft.h", "plx_internal.h"):
+        s = s.replace('#include "%s"' % h, '#include "%s"' % os.path.join(csrc, h))
+    os.makedirs(os.path.dirname(DST), exist_ok=True)
+    open(DST, "w").write(s)
+    print(DST)
+
+
+if __name__ == "__main__":
+    main()

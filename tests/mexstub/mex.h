@@ -25,10 +25,16 @@ void *mxCalloc(size_t n, size_t size);
 void mexErrMsgTxt(const char *msg);                       /* does not return (long jump to the caller of the gateway) */
 void mexErrMsgIdAndTxt(const char *id, const char *fmt, ...);
 void mexPrintf(const char *fmt, ...);
+void mexLock(void);                                       /* keep the MEX file (and the library state behind it) in memory */
+void mexUnlock(void);
+int mexIsLocked(void);
+int mexAtExit(void (*fn)(void));                          /* called when the MEX file is cleared / MATLAB exits */
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]);
 /* harness side (tests/test_mex_shims.py): run a gateway, catching mexErrMsgTxt; returns 0 or 1 and the message */
 int mexstub_call(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]);
 const char *mexstub_last_error(void);
+int mexstub_lock_count(void);                             /* mexLock() calls minus mexUnlock() calls */
+int mexstub_run_atexit(void);                             /* what `clear mex` does: run the registered function; 1 if there was one */
 #ifdef __cplusplus
 }
 #endif

@@ -51,3 +51,16 @@ int mexstub_call(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
     return 0;
 }
 const char *mexstub_last_error(void) { return g_err; }
+static int g_locks;
+static void (*g_atexit)(void);
+void mexLock(void) { g_locks++; }
+void mexUnlock(void) { if (g_locks > 0) g_locks--; }
+int mexIsLocked(void) { return g_locks > 0; }
+int mexAtExit(void (*fn)(void)) { g_atexit = fn; return 0; }
+int mexstub_lock_count(void) { return g_locks; }
+int mexstub_run_atexit(void)
+{
+    if (!g_atexit) return 0;
+    g_atexit();
+    return 1;
+}

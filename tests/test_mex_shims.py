@@ -43,6 +43,8 @@ def _load(shim):
     lib.mxCreateDoubleMatrix.argtypes = [C.c_size_t, C.c_size_t, C.c_int]
     lib.mexstub_call.argtypes = [C.c_int, C.POINTER(C.POINTER(MxArray)), C.c_int, C.POINTER(C.POINTER(MxArray))]
     lib.mexstub_last_error.restype = C.c_char_p
+    lib.mexstub_lock_count.restype = C.c_int
+    lib.mexstub_run_atexit.restype = C.c_int
     return lib
 
 
@@ -250,3 +252,76 @@ def test_mfile_twin_shims_return_the_updated_taps():
     np.testing.assert_allclose(_np(out[1]), g1, atol=1e-11)
     np.testing.assert_allclose(_np(out[2]), g2, atol=1e-11)
     assert np.abs(_np(out[1]).imag - k1.imag).max() > 1e-5
+
+
+def _gw_stats():
+    from polmux_amd import _abi
+    out = np.zeros(8, np.int64)
+    _abi.get().call("plx_gateway_stats", out.ctypes.data)
+    return dict(zip(("calls", "dev_allocs", "host_allocs", "plan_builds", "plan_hits", "dev_bytes", "host_bytes", "releases"), out.tolist()))
+
+
+@pytest.mark.gpu
+def test_gateway_state_is_kept_between_calls_and_released_at_exit():
+    """SURVEY 8(b) "Ownership": the unchanged drivers call the filter MEX once per pass (DspPdmCohQpsk.m:176-191) and the
+    propagator once per span (fiber.m:372-389).  The SECOND call of a gateway allocates nothing and builds no plan (the
+    library keeps plans, device buffers and pinned staging); the shim holds the MEX file with mexLock and releases the
+    state from mexAtExit; after a release the next call works again and gives the same result."""
+    from polmux_amd import _abi, synth
+    lib = _load("plx_cmaadaptivefilter_mex")
+    _abi.get().call("plx_release_all")
+    r = np.random.default_rng(11)
+    xx = (r.standard_normal((1024, 2)) + 1j * r.standard_normal((1024, 2))) / np.sqrt(2)
+    taps = 7
+    h1 = np.zeros((taps, 2)); h1[taps // 2, 0] = 1.0
+    h2 = np.zeros((taps, 2)); h2[taps // 2, 1] = 1.0
+
+    def one_pass():
+        mh1, mh2 = _mx(lib, h1), _mx(lib, h2)
+        rc, out, err = _call(lib, 3, _mx(lib, xx), mh1, mh2, _mx(lib, [[taps]]), _mx(lib, [[1e-3]]), _mx(lib, [[1.0, 1.0]]), _mx(lib, [[1]]))
+        assert rc == 0, err
+        return _np(out[0]), _np(mh1), _np(mh2)
+    first = one_pass()
+    s1 = _gw_stats()
+    assert s1["dev_allocs"] >= 1 and s1["host_allocs"] >= 1 and s1["dev_bytes"] > 0
+    for _ in range(5):                                    # the driver's pass loop
+        again = one_pass()
+    s2 = _gw_stats()
+    assert s2["calls"] == s1["calls"] + 5
+    assert (s2["dev_allocs"], s2["host_allocs"], s2["plan_builds"]) == (s1["dev_allocs"], s1["host_allocs"], s1["plan_builds"])
+    for a, b in zip(first, again):
+        np.testing.assert_array_equal(a, b)
+    assert lib.mexstub_lock_count() == 1                  # mexLock once, not once per call
+    # the propagator: one plan per fibre type and grid, found again by content
+    lib2 = _load("plx_matrix_ssfm_mex")
+    nsymb, nt = 64, 16
+    ux, uy, _, _ = synth.pdm_qpsk_field(nsymb, nt, 6.0)
+    omega = 2 * np.pi * 28 * synth.fn_grid(nsymb, nt)
+    betat = (0.5 * omega ** 2 * -2.17e-8).reshape(-1, 1)
+
+    def span(bt):
+        args = [_mx(lib2, ux.reshape(-1, 1)), _mx(lib2, uy.reshape(-1, 1)), _mx(lib2, bt), _mx(lib2, np.zeros_like(bt)), _mx(lib2, [[2e4]]),
+                _mx(lib2, [[5e-3]]), _mx(lib2, [[1.3e-6]]), _mx(lib2, [[4.6e-5]]), _mx(lib2, [[1]]), _mx(lib2, [[2e4]]), _mx(lib2, [[1]]),
+                _mx(lib2, [[0]]), _mx(lib2, [[1, 0, 1, 0]]), _mx(lib2, [[0.0]]), _mx(lib2, [[0.0]]), _mx(lib2, [[0.0]])]
+        rc, out, err = _call(lib2, 4, *args)
+        assert rc == 0, err
+        return _np(out[2]), _np(out[3]), _np(out[1])[0, 0]
+    a = span(betat)
+    s3 = _gw_stats()
+    assert s3["plan_builds"] == s2["plan_builds"] + 1
+    b = span(betat.copy())                                # the same fibre in ANOTHER host array: found by content
+    s4 = _gw_stats()
+    assert s4["plan_builds"] == s3["plan_builds"] and s4["plan_hits"] == s3["plan_hits"] + 1
+    assert (s4["dev_allocs"], s4["host_allocs"]) == (s3["dev_allocs"], s3["host_allocs"])
+    np.testing.assert_array_equal(a[0], b[0]); np.testing.assert_array_equal(a[1], b[1]); assert a[2] == b[2]
+    c = span(betat * 1.01)                                # another fibre: its own plan
+    assert _gw_stats()["plan_builds"] == s4["plan_builds"] + 1 and np.abs(c[0] - a[0]).max() > 0
+    # `clear mex`: the registered exit function releases everything; the library rebuilds on demand
+    assert lib.mexstub_run_atexit() == 1
+    s5 = _gw_stats()
+    assert s5["releases"] == s4["releases"] + 1 and s5["dev_bytes"] == 0 and s5["host_bytes"] == 0
+    for x_, y_ in zip(first, one_pass()):
+        np.testing.assert_array_equal(x_, y_)
+    d = span(betat)
+    np.testing.assert_array_equal(a[0], d[0])
+    _abi.get().call("plx_release_all")
