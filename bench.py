@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="run the receiver on the fibre stream (no stream overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame latency measurement after the timed region")
+    ap.add_argument("--no-gateway", action="store_true", help="skip the per-call timing of the MEX-shaped gateway tier")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the batch the one-core CPU baseline processes (~0.5 s each)")
     return ap.parse_args()
 
@@ -221,6 +222,95 @@ def cpu_baseline(cfg, hp, nframes, noise):
     res = cpu_chain.run_parallel(p, per, cores)
     allc = None if res is None else (cores * per * cfg.nfft / res[1] / 1e9, res[1], res[0], cores, per)
     return one, allc
+
+
+def gateway_bench(cfg, hp):
+    """Per-call cost of the DROP-IN tier (include/polmux_hip.h, tier A): what the unchanged MATLAB drivers would pay per MEX
+    call -- host arrays in, host arrays out, PCIe both ways, the library's cached plan and buffers (plx_gateway.h) -- each
+    beside oracle/ doing the same call on one host core.  Outside the timed region; never the reported value."""
+    from oracle import plxo
+    from polmux_amd import _abi
+    lib = _abi.get()
+    out = {}
+
+    def stats():
+        v = np.zeros(8, np.int64)
+        lib.call("plx_gateway_stats", v.ctypes.data)
+        return v
+
+    def timed(fn, n):
+        t0 = time.perf_counter()
+        fn()
+        first = (time.perf_counter() - t0) * 1e3
+        s0 = stats()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        per = (time.perf_counter() - t0) * 1e3 / n
+        s1 = stats()
+        return first, per, int(s1[1] - s0[1] + s1[2] - s0[2] + s1[3] - s0[3])    # allocations + plan builds of the repeats
+
+    lib.call("plx_release_all")
+    # -- cmaadaptivefilter: ONE pass over 1024 dual-pol samples, 7 taps (the driver makes up to 299 per frame, DspPdmCohQpsk.m:176-191)
+    r = np.random.default_rng(5)
+    L, taps = 1024, 7
+    xx = (r.standard_normal((L, 2)) + 1j * r.standard_normal((L, 2))) / math.sqrt(2)
+    xr, xi = np.asfortranarray(xx.real), np.asfortranarray(xx.imag)
+    h0 = np.zeros((taps, 2)); h0[taps // 2, 0] = 1.0
+    g0 = np.zeros((taps, 2)); g0[taps // 2, 1] = 1.0
+    R = np.array([1.0, 1.0])
+    yr, yi = np.zeros((L - taps + 1, 2), order="F"), np.zeros((L - taps + 1, 2), order="F")
+
+    def cma():
+        h1r, h1i, h2r, h2i = np.asfortranarray(h0), np.zeros((taps, 2), order="F"), np.asfortranarray(g0), np.zeros((taps, 2), order="F")
+        lib.call("plx_cmaadaptivefilter", xr.ctypes.data, xi.ctypes.data, L, h1r.ctypes.data, h1i.ctypes.data, h2r.ctypes.data,
+                 h2i.ctypes.data, float(taps), 1e-3, R.ctypes.data, 1.0, yr.ctypes.data, yi.ctypes.data)
+    first, per, allocs = timed(cma, 100)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        plxo.cmaadaptivefilter(xx, h0.astype(complex), g0.astype(complex), taps, 1e-3, [1.0, 1.0], 1)
+    out["plx_cmaadaptivefilter"] = {"what": "one pass, 1024 x 2 samples, 7 taps", "first_call_ms": first, "ms_per_call": per,
+                                    "allocations_in_repeats": allocs, "oracle_ms_per_call": (time.perf_counter() - t0) * 1e3 / 20}
+    # -- fastexp on 2^16 phases (fastexp.c:37-47)
+    x = r.standard_normal(65536) * 100.0
+    er, ei = np.empty_like(x), np.empty_like(x)
+    first, per, allocs = timed(lambda: lib.call("plx_fastexp", x.ctypes.data, er.ctypes.data, ei.ctypes.data, x.size), 100)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        plxo.fastexp(x)
+    out["plx_fastexp"] = {"what": "2^16 phases", "first_call_ms": first, "ms_per_call": per, "allocations_in_repeats": allocs,
+                          "oracle_ms_per_call": (time.perf_counter() - t0) * 1e3 / 20}
+    # -- matrix_ssfm: one frame of this run through one span (fiber.m:372-389)
+    gam, betat, db1 = hp._keep
+    d = _abi.SsfmDesc()
+    d.nfft, d.nfc, d.dual_pol, d.max_frames = cfg.nfft, 1, 1, 1
+    for i in range(4):
+        d.fls[i] = hp.fls[i]
+    d.dzmaxt, d.dphimaxt, d.alphalin, d.length = min(cfg.dzmax, cfg.length), cfg.dphimax, hp.alphalin, cfg.length
+    d.nplates, d.manakov = 1, int(str(cfg.manakov).lower() == "yes")
+    d.gam, d.betat, d.db1 = gam.ctypes.data, betat.ctypes.data, db1.ctypes.data
+    z = np.zeros(1)
+    fd, nc = C.c_double(), C.c_int32()
+    tx, ty = hp.tx_host
+
+    def span():
+        uxr, uxi = np.ascontiguousarray(tx.real), np.ascontiguousarray(tx.imag)
+        uyr, uyi = np.ascontiguousarray(ty.real), np.ascontiguousarray(ty.imag)
+        lib.call("plx_matrix_ssfm", uxr.ctypes.data, uxi.ctypes.data, uyr.ctypes.data, uyi.ctypes.data, C.byref(d), z.ctypes.data,
+                 z.ctypes.data, z.ctypes.data, C.byref(fd), C.byref(nc))
+    if not hp.pmd:
+        first, per, allocs = timed(span, 10)
+        t0 = time.perf_counter()
+        plxo.matrix_ssfm(tx, ty, betat, db1, d.dzmaxt, d.dphimaxt, gam, hp.alphalin, cfg.length, 1, d.manakov, hp.fls, [0.0], [0.0], [0.0])
+        out["plx_matrix_ssfm"] = {"what": "one 2^%d-sample frame, one span, %d steps" % (int(np.log2(cfg.nfft)), nc.value),
+                                  "first_call_ms": first, "ms_per_call": per, "allocations_in_repeats": allocs,
+                                  "oracle_ms_per_call": (time.perf_counter() - t0) * 1e3}
+    v = stats()
+    out["library_state"] = {"device_bytes": int(v[5]), "pinned_bytes": int(v[6]), "plans_built": int(v[3]), "plans_found": int(v[4])}
+    out["note"] = ("host arrays in and out (PCIe both ways) with the library's cached plans and buffers; first_call_ms includes "
+                   "the plan build and the buffers' first growth; oracle = the CPU restatement doing the same call on one core")
+    lib.call("plx_release_all")
+    return out
 
 
 def ladder_scales(nframes, pavg_mw, rank=0, world=1):
@@ -433,6 +523,20 @@ def main():
                                  "%.1f dB with ASE of NF %.1f dB (ampliflat.m:91-136, device Philox keyed by realisation), "
                                  "receiver_cohmix + ADC + decimate, CDE_OFDE, CMA + CPE, decisions with pol-swap / pi/2 "
                                  "resolution (ex20_coherent_polmux.m:160-173)" % (10 * math.log10(math.exp(camp.hp.alphalin * mcfg.length)), a.mc_nf)}
+        # the SAME realisation on the host cores (reported baseline; N = 1 only): oracle chain with fresh waveplates, the
+        # amplifier's ASE, receiver_cohmix front end and the CMA's full pass budget, one stream of realisations per core
+        if rank == 0 and world == 1 and not a.no_cpu_baseline:
+            from oracle import cpu_chain
+            from polmux_amd.ampliflat import ase_sigma
+            pm = cpu_params(mcfg, camp.hp, 0.0)
+            pm["mc"] = {"nplates": camp.hp.nplates, "amp_sigma": float(ase_sigma(a.mc_nf, math.exp(camp.hp.alphalin * mcfg.length), 1)[0])}
+            cores, per = host_cores(), 2
+            res_cpu = cpu_chain.run_parallel(pm, per, cores)
+            if res_cpu is not None:
+                mc_out["cpu_baseline"] = {"realisations_per_s": cores * per / res_cpu[1], "cores": cores, "kind": "port",
+                                          "sample": "%d processes x %d realisations of the same kind through oracle/ (fibre 'gps-' with %d fresh "
+                                                    "waveplates, amplifier ASE, receiver_cohmix + ADC + decimate, CDE, CMA + CPE), busiest "
+                                                    "process %.1f s" % (cores, per, camp.hp.nplates, res_cpu[1])}
         camp.close()
 
     # SURVEY 8d's M1 read literally -- ONE frame through fibre + receiver, nothing else on the GPU (outside the timed region)
@@ -448,6 +552,9 @@ def main():
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         single = {"fibre_ms": (t2 - t1) * 1e3, "rx_ms": (t3 - t2) * 1e3, "gsample_per_s": n / (t3 - t1) / 1e9}
+    gateway = None
+    if rank == 0 and world == 1 and not a.no_gateway:
+        gateway = gateway_bench(cfg, hp)
     if rank == 0:
         samples = float(world) * a.steps * F * n
         value = samples / dt / 1e9
@@ -521,6 +628,7 @@ def main():
                                                "note": "SURVEY 8(d)'s four-sweep budget; this implementation moves %d B" % int(group_bytes)},
                          "launches": int(row_launches)},
             "mc": mc_out,
+            "gateway": gateway,
         }
         if not a.no_cpu_baseline and world == 1:      # a reported baseline, timed at N = 1 only
             (v, cdt, nc), allc = cpu_baseline(cfg, hp, a.cpu_frames, a.noise)
@@ -530,7 +638,7 @@ def main():
             if allc is not None:
                 va, busiest, wall, cores, per = allc
                 out["cpu_baseline_all_cores"] = {"value": va, "unit": "Gsample/s", "cores": cores, "kind": "port",
-                                                 "realisations_per_s": cores * per / busiest,
+                                                 "frames_per_s": cores * per / busiest,     # (frames of THIS line's workload; the Monte-Carlo realisation is timed in mc.cpu_baseline)
                                                  "sample": "%d processes x %d frame(s) each, busiest process %.1f s (%.1f s "
                                                            "wall incl. process start)" % (cores, per, busiest, wall)}
         print(json.dumps(out))

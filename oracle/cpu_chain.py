@@ -19,10 +19,21 @@ def run_frames(p, nframes, seed):
         nc = 0
         ox, oy = p["tx_x"], p["tx_y"]
         nspans = int(p.get("nspans", 1))
+        mc = p.get("mc")                 # a Monte-Carlo realisation (BASELINE config[3]): fresh waveplates, amplifier ASE after the span
         for span in range(nspans):
+            nplates, db0, th, ep = 1, [0.0], [0.0], [0.0]
+            if mc:                       # fiber.m:274-276
+                nplates = int(mc["nplates"])
+                db0 = r.random(nplates) * 2 * np.pi - np.pi
+                th = r.random(nplates) * np.pi - 0.5 * np.pi
+                ep = 0.5 * np.arcsin(r.random(nplates) * 2 - 1)
             rc, fd, k, ox, oy = plxo.matrix_ssfm(ox, oy, p["betat"], p["db1"], p["dzmax"], p["dphimax"], p["gam"],
-                                                 p["alphalin"], p["length"], 1, 0, p["fls"], [0.0], [0.0], [0.0])
+                                                 p["alphalin"], p["length"], nplates, 0, p["fls"], db0, th, ep)
             nc += k
+            if mc and span + 1 == nspans:                              # ampliflat(G,'gain',{f}) behind the span, ampliflat.m:91-143
+                g = np.exp(p["alphalin"] * p["length"])
+                ox = np.sqrt(g) * ox + mc["amp_sigma"] * (r.standard_normal(ox.shape) + 1j * r.standard_normal(ox.shape))
+                oy = np.sqrt(g) * oy + mc["amp_sigma"] * (r.standard_normal(oy.shape) + 1j * r.standard_normal(oy.shape))
             if span + 1 < nspans:                                      # in-line amplifier, ampliflat.m:123-143
                 g = np.exp(p["alphalin"] * p["length"])
                 ox, oy = np.sqrt(g) * ox, np.sqrt(g) * oy

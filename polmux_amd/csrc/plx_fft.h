@@ -123,6 +123,14 @@ __device__ __forceinline__ void lds_fft_dit(cplx *s, int logM, int IS, int TS, i
 // remaining stages (sub-block length >= 16) keep the radix-4 scheme on 16-aligned runs.
 __device__ __forceinline__ int row_phys(int i) { return i + (i >> 4); }
 __device__ __forceinline__ int row_pitch(int M) { return M + (M >> 4); }
+// Which point a lane takes when consecutive lanes sweep consecutive points of a padded row.  A wave's ds_read_b128 is
+// served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 -- chosen so that 64
+// lanes reading 64 CONSECUTIVE 16-byte slots meet no bank conflict.  Behind the pad slots lane l would read slot
+// l + (l >> 4): lanes 20-27 land on slots 5..12 (mod 16) and collide with lane 12 -- every stride-1 read of a padded row
+// then takes twice its cycles (measured: 32 % of k_row's LDS cycles were conflicts).  So within every aligned block of 16
+// points the lanes are ROTATED by the block's pad count: lane l takes point (l & ~15) | ((l - pads) & 15), whose slot is
+// congruent to l again (mod 16).  i: the lane's linear point index, M: the (power-of-two) row length.
+__device__ __forceinline__ int row_lane_point(int i, int M) { return (i & ~15) | ((i - ((i & (M - 1)) >> 4)) & 15); }
 
 #define PLX_C8 0.92387953251128673848  /* cos(pi/8) */
 #define PLX_S8 0.38268343236508978178  /* sin(pi/8) */
@@ -297,7 +305,7 @@ __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const c
     if (logM & 1) { // radix-2 head (halfM >= 16)
         const int total = T * halfM, hp = row_phys(halfM);
         for (int b = tid; b < total; b += nthr) {
-            const int j = b & (halfM - 1), t = b >> (logM - 1);
+            const int j = row_lane_point(b & (halfM - 1), M), t = b >> (logM - 1);
             cplx *p = s + t * TSp + row_phys(j);
             const cplx a = p[0], c = p[hp];
             p[0] = cadd(a, c);
@@ -311,8 +319,10 @@ __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const c
         const int total = T << (logM - 2);
         for (int b = tid; b < total; b += nthr) {
             const int bi = b & ((M >> 2) - 1), t = b >> (logM - 2);
-            const int j = bi & (q - 1);
-            const int base = ((bi >> lq) << lm) + j;
+            // (q >= 16: the lanes of a block of 16 butterflies are rotated by the block's pad count, see row_lane_point)
+            const int blk0 = ((bi >> lq) << lm) + (bi & (q - 1) & ~15);
+            const int base = blk0 + ((bi - (blk0 >> 4)) & 15);
+            const int j = base & (q - 1);
             cplx *p = s + t * TSp + row_phys(base);
             cplx a0 = p[0], a1 = p[qs], a2 = p[2 * qs], a3 = p[3 * qs];
             cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
@@ -364,8 +374,10 @@ __device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const c
         const int total = T << (logM - 2);
         for (int b = tid; b < total; b += nthr) {
             const int bi = b & ((M >> 2) - 1), t = b >> (logM - 2);
-            const int j = bi & (q - 1);
-            const int base = ((bi >> lq) << lm) + j;
+            // (q >= 16: the lanes of a block of 16 butterflies are rotated by the block's pad count, see row_lane_point)
+            const int blk0 = ((bi >> lq) << lm) + (bi & (q - 1) & ~15);
+            const int base = blk0 + ((bi - (blk0 >> 4)) & 15);
+            const int j = base & (q - 1);
             cplx *p = s + t * TSp + row_phys(base);
             cplx c0 = p[0], c2 = p[qs], c1 = p[2 * qs], c3 = p[3 * qs];
             const int k = j << sh;
@@ -380,7 +392,7 @@ __device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const c
     if (logM & 1) {
         const int total = T * halfM, hp = row_phys(halfM);
         for (int b = tid; b < total; b += nthr) {
-            const int j = b & (halfM - 1), t = b >> (logM - 1);
+            const int j = row_lane_point(b & (halfM - 1), M), t = b >> (logM - 1);
             cplx *p = s + t * TSp + row_phys(j);
             const cplx a = p[0], c = cmulc(p[hp], tw[j]);
             p[0] = cadd(a, c);

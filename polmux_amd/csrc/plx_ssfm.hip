@@ -56,6 +56,11 @@ static_assert(sizeof(FrameCtl) == 128 && offsetof(FrameCtl, done) == 124, "done 
 
 struct SsfmArgs {
     cplx *ux, *uy;
+    // the plan's WORKING COPY of the field (fused sweep with 4096-point rows): [frame][channel][N1][wpitch] with a row
+    // pitch that is NOT a multiple of 64 KiB.  The first fused launch of a span reads the caller's arrays and stores here,
+    // the sweeps in between work here in place, the launch that finishes a frame stores it back into the caller's arrays.
+    cplx *wx, *wy;
+    int wpitch;                    // complex samples between consecutive rows of the working copy
     const double *betat_p, *db1_p; // [nfc][N], bit-reversed/transposed order
     const cplx *tpass;             // [N] inter-pass twiddles W_N^(n2*k1), same order
     const cplx *hmul;              // [N] general spectral multiplier replacing exp(-i betat dz) (filter passes), same order
@@ -603,13 +608,13 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     double btk[ROW_CH];
     if (fastmul) {
 #pragma unroll
-        for (int k = 0; k < ROW_CH; k++) btk[k] = bt[tid + k * nthr];
+        for (int k = 0; k < ROW_CH; k++) btk[k] = bt[row_lane_point(tid + k * nthr, N2)];
     }
     for (int e0 = tid; e0 < nel; e0 += nthr * ROW_CH) {
         cplx tv[ROW_CH], xv[ROW_CH], yv[ROW_CH];
 #pragma unroll
         for (int k = 0; k < ROW_CH; k++) {
-            const int e = min(e0 + k * nthr, nel - 1);
+            const int e = row_lane_point(min(e0 + k * nthr, nel - 1), N2);   // (the lane's point: rotated within blocks of 16, see plx_fft.h)
             tv[k] = a.tpass[rowbase + e];
             xv[k] = a.ux[base + rowbase + e];
             yv[k] = uyp[base + rowbase + e];
@@ -618,9 +623,9 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         for (int k = 0; k < ROW_CH; k++) { pin(tv[k]); pin(xv[k]); pin(yv[k]); }
 #pragma unroll
         for (int k = 0; k < ROW_CH; k++) {
-            const int e = e0 + k * nthr;
+            const int el = e0 + k * nthr, e = row_lane_point(el, N2);
             tkeep[k] = tv[k];
-            if (e < nel) {
+            if (el < nel) {
                 const int r = e >> a.p2, i = e & (N2 - 1);
                 s[r * TSp + row_phys(i)] = cmul(xv[k], tv[k]);
                 if (a.dual) s[(R + r) * TSp + row_phys(i)] = cmul(yv[k], tv[k]);
@@ -632,7 +637,8 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     row_fft_dif(s, a.p2, a.logR + (a.dual ? 1 : 0), tw, tid, nthr);
     const double cur = a.force ? a.f_cur : ctl->cur;
     if (!a.dual) {
-        for (int e = tid; e < nel; e += nthr) { // Hf = fastexp(-betat*dz) :771
+        for (int el = tid; el < nel; el += nthr) {
+            const int e = row_lane_point(el, N2); // Hf = fastexp(-betat*dz) :771
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
             s[o] = cmul(s[o], a.hmul ? a.hmul[rowbase + e] : cexp_neg_turns(bt[e] * cur));
         }
@@ -640,7 +646,8 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         // zero birefringence, one trunk (fiber.m:291-297): matR = I, deltabeta = 0
         // (one loop per kind of multiplier: the step's exp(-i beta dz) loop stays a single basic block)
         if (a.umat) { // Uinv = conj(Hgvd) [conj(U11) -U12; conj(U12) U11] applied to [x; y]  (inverse_pmd.m:130-141)
-            for (int e = tid; e < nel; e += nthr) {
+            for (int el = tid; el < nel; el += nthr) {
+            const int e = row_lane_point(el, N2);
                 const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
                 const cplx *um = a.umat + 3 * ((size_t)f * N + rowbase + e);
                 const cplx u11 = um[0], u12 = um[1], hg = um[2], x = s[o], y = s[o + R * TSp];
@@ -648,7 +655,8 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
                 s[o + R * TSp] = cmulc(cadd(cmulc(x, u12), cmul(u11, y)), hg);
             }
         } else if (a.hmul) {
-            for (int e = tid; e < nel; e += nthr) {
+            for (int el = tid; el < nel; el += nthr) {
+            const int e = row_lane_point(el, N2);
                 const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
                 const cplx h = a.hmul[rowbase + e];
                 s[o] = cmul(h, s[o]);
@@ -657,14 +665,15 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         } else if (fastmul) {
 #pragma unroll
             for (int k = 0; k < ROW_CH; k++) {
-                const int e = tid + k * nthr;
+                const int e = row_lane_point(tid + k * nthr, N2);
                 const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
                 const cplx h = cexp_neg_turns(btk[k] * cur);
                 s[o] = cmul(h, s[o]);
                 s[o + R * TSp] = cmul(h, s[o + R * TSp]);
             }
         } else {
-            for (int e = tid; e < nel; e += nthr) {
+            for (int el = tid; el < nel; el += nthr) {
+            const int e = row_lane_point(el, N2);
                 const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
                 const cplx h = cexp_neg_turns(bt[e] * cur);
                 s[o] = cmul(h, s[o]);
@@ -676,7 +685,8 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * BRF_STRIDE : 0);
         const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem; // plate of piece k: n0+k (1-based) :908
         const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last, lcorr = a.lcorr;
-        for (int e = tid; e < nel; e += nthr) {
+        for (int el = tid; el < nel; el += nthr) {
+            const int e = row_lane_point(el, N2);
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
             cplx x = s[o], y = s[o + R * TSp];
             pmd_trunks(x, y, bt[e], d1[e], brf, a.nplates, n0, ntrunk, dzb_first, dzb_last, lcorr, cur);
@@ -689,14 +699,15 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     if (keep_tw) {
 #pragma unroll
         for (int k = 0; k < ROW_CH; k++) {
-            const int e = tid + k * nthr;
+            const int e = row_lane_point(tid + k * nthr, N2);
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
             a.ux[base + rowbase + e] = cmulc(s[o], tkeep[k]);
             if (a.dual) a.uy[base + rowbase + e] = cmulc(s[o + R * TSp], tkeep[k]);
         }
         return;
     }
-    for (int e = tid; e < nel; e += nthr) {
+    for (int el = tid; el < nel; el += nthr) {
+            const int e = row_lane_point(el, N2);
         const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
         const cplx t = a.tpass[rowbase + e];
         a.ux[base + rowbase + e] = cmulc(s[o], t);
@@ -732,7 +743,9 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     cplx *bk = tw + 516;                         // tpass[256 k], k < 16
     const size_t N = (size_t)1 << (a.p1 + a.p2);
     const size_t rowbase = (size_t)blockIdx.x << 12;
-    cplx *const u = (blockIdx.z ? a.uy : a.ux) + (size_t)fc * N + rowbase;   // (grid.z: the polarisation)
+    // (grid.z: the polarisation; a.wx: the plan's working copy with its own row pitch, see SsfmArgs)
+    cplx *const u = a.wx ? (blockIdx.z ? a.wy : a.wx) + ((size_t)fc << a.p1) * a.wpitch + (size_t)blockIdx.x * a.wpitch
+                         : (blockIdx.z ? a.uy : a.ux) + (size_t)fc * N + rowbase;
     const cplx *const tp = a.tpass + rowbase;
 
     const Tw4096 w1{tw};
@@ -965,18 +978,29 @@ __device__ __forceinline__ void emu_lockstep() {}
 #endif
 
 
-__global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf)
+// WORK: the plan keeps a working copy of the field with its own row pitch (SsfmArgs::wx; 2^20-sample frames).
+template <bool WORK> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf)
 {
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, t = tid & 15, j = tid >> 4;
-    const int N2 = 1 << a.p2;
+    // (WORK plans are single-field frames of 256 x 4096 samples: geometry by construction, not from the arguments)
+    const int N2 = WORK ? 4096 : 1 << a.p2;
+    const int LOGN = WORK ? 20 : a.p1 + a.p2;
     cplx *s = (cplx *)lds;                 // [256][16] exchange buffer
     cplx *tw = s + 4096;                   // W_256^k, k < 128
     double *red = (double *)(tw + 128);
     FrameCtl *lctl = (FrameCtl *)(red + 32);
     lds_load_twiddles(tw, a.tw1, 128, tid, 256);
     cplx *const fld = (t < 8) ? a.ux : a.uy;
+    // Where a tile is read and written.  Round 0 of a span reads the caller's arrays (every listed frame is unstarted then,
+    // and started in every later round); a frame's last round writes them.  In between the field lives in the plan's
+    // working copy when there is one (WORK: row pitch a.wpitch), else in the caller's arrays as well.  The working copy's
+    // addresses are formed where they are used (this kernel has no register to spare for loop invariants).
+    const bool first_round = !WORK || a.round == 0;
+    const size_t wp = WORK ? (size_t)a.wpitch : (size_t)N2;                                      // row pitch of the copy worked on
+    const size_t wfs = WORK ? ((size_t)a.wpitch << 8) : ((size_t)1 << LOGN);                     // its frame-channel stride
+    const size_t sp = first_round ? (size_t)N2 : wp, sfs = first_round ? ((size_t)1 << LOGN) : wfs;   // the same for this launch's SOURCE
     const int colt = t & 7;
     const bool isx = t < 8;
     const int lane = tid & 63, row0 = (tid >> 6) * 64;     // this wave stages rows row0 .. row0+63
@@ -991,7 +1015,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     // team's workgroups run without meeting, and its first may be any number of iterations ahead of its slowest.
     const int nact = a.nactive[0];
     const int NT = gridDim.x / tiles_pf, team = blockIdx.x / tiles_pf, ti = blockIdx.x - team * tiles_pf;
-    const int c = ti / tiles_x, bx = ti - c * tiles_x;
+    const int c = WORK ? 0 : ti / tiles_x, bx = ti - c * tiles_x;
     const unsigned long long rtag = (unsigned long long)(((unsigned)a.round + 1u) & 0xfffffu) << 22;
     unsigned long long *const mbox = a.mbox + (size_t)a.mbox_stride * team;
     if (blockIdx.x == 0 && tid == 0) a.grab[(a.round & 1) ^ 1] = 0;        // (the other parity's counter: for the next launch)
@@ -1009,15 +1033,17 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     // (record copies: [iteration parity][wave] -- the copy of the tile in hand is still needed while the next one lands)
     int it = 0;
     auto stage = [&](int f, int par) {
-        const int fc = f * a.nfc + c;
+        const int fc = WORK ? f : f * a.nfc + c;
         // (lane & 15 == t: the lane stages a piece of the same column of the same polarisation it later works on)
         int lq = lane >> 4;
         pin(lq);                           // (addresses are formed where they are used: hoisted out of the tile loop they end up in scratch)
-        const cplx *src = fld + ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt + (size_t)(row0 + lq) * N2;
+        const cplx *sfld = fld;
+        if (WORK && !first_round) { int tq = t; pin(tq); sfld = tq < 8 ? a.wx : a.wy; }
+        const cplx *src = sfld + (size_t)fc * sfs + (size_t)bx * 8 + colt + (size_t)(row0 + lq) * sp;
         FrameCtl *const rec = lctl + 4 * par + (tid >> 6);
         if (lane == (int)(offsetof(FrameCtl, done) / 16)) rec->done = PLX_REC_SENTINEL;   // (the lane whose piece of the record holds the word)
         lds_settle();                      // (the sentinel is in place before the copy that replaces it can land)
-        glds_rows(src, (size_t)4 * N2, s + (size_t)row0 * 16, lane);
+        glds_rows(src, (size_t)4 * sp, s + (size_t)row0 * 16, lane);
         static_assert(sizeof(FrameCtl) % 16 == 0, "the record travels as 16-byte pieces");
         int ln = lane;
         pin(ln);                           // (the address is formed here: kept across the tile loop it would sit in scratch)
@@ -1051,7 +1077,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     //  end of an iteration, and the next iteration may write its successor with no workgroup barrier in between)
     for (;; it++) {
         FrameCtl *const wrec = lctl + 4 * (it & 1) + (tid >> 6);
-        const int fc = f * a.nfc + c;
+        const int fc = WORK ? f : f * a.nfc + c;
         // [phase 0] loop top
         if (a.safe_land) drain_vmem();     // (checking mode: the ordinary wait as well -- results must not depend on it)
         while (lds_peek(&wrec->done) == PLX_REC_SENTINEL) nap();   // this wave's rows of the tile and its copy of the record are in LDS
@@ -1083,7 +1109,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             stage(f, (it & 1) ^ 1);        // (s is free here: every path below ends past its last read of s, and so far
             continue;                      //  each wave has only touched its own rows)
         }
-        const size_t cbase = ((size_t)fc << (a.p1 + a.p2)) + (size_t)bx * 8 + colt;
+        const size_t cbase = ((size_t)fc << LOGN) + (size_t)bx * 8 + colt;   // in the caller's arrays
         const bool started = wrec->started != 0;
         {
             cplx x[16];
@@ -1261,8 +1287,16 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                 if (nf >= 0) stage(nf, (it & 1) ^ 1);
             }
             r16_dif(x);                    // ... during the last register transform and the stores of this one
+            if (WORK) {
+                int tq = t;
+                pin(tq);
+                cplx *const wd = (tq < 8 ? a.wx : a.wy) + (size_t)fc * wfs + (size_t)bx * 8 + colt;
 #pragma unroll
-            for (int k = 0; k < 16; k++) fld[cbase + (size_t)(16 * j + k) * N2] = x[k];
+                for (int k = 0; k < 16; k++) wd[(size_t)(16 * j + k) * wp] = x[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; k++) fld[cbase + (size_t)(16 * j + k) * N2] = x[k];
+            }
             // [phase 7] staging issue + r16_dif + stores issued
         }
         f = (int)red[10 + (it & 1)];
@@ -1292,6 +1326,8 @@ struct plx_ssfm {
     std::vector<FrameCtl> h_ctl;
     int brf_sets = 0;
     size_t lds_col = 0, lds_row = 0;
+    cplx *d_work = nullptr;                  // working copy of the field with a padded row pitch (fused sweep, 4096-point rows), x then y
+    int wpitch = 0;
     unsigned long long *d_slots = nullptr;   // slot barrier of the fused column sweep: [launch parity][frame][tile]
     unsigned long long *d_mbox = nullptr;    // [teams][frames + 4] mailboxes of the fused column sweep's teams, then the two claim counters
     size_t mbox_bytes = 0;
@@ -1317,6 +1353,7 @@ struct plx_ssfm {
 };
 
 static const double kInv2Pi = 0.15915494309189533577;
+static const int kDefaultWorkPad = 8;         // complex samples (128 B) added to the row pitch of the working copy; PLX_SSFM_WPAD overrides (-1: none)
 static const double kDefaultGroupMiB = 0.0;   // field MiB per cache-resident frame group (0: off); PLX_SSFM_GROUP_MIB overrides
 
 static int ilog2(int64_t v)
@@ -1331,7 +1368,7 @@ static void free_plan(plx_ssfm *P)
     if (!P) return;
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
-    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active);
+    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active); hipFree(P->d_work);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     if (P->ev) hipEventDestroy(P->ev);
     for (hipEvent_t e : P->evpool) hipEventDestroy(e);
@@ -1372,7 +1409,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0;
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2;
     double barrier_timeout_ms = 500.0, group_mib = -1.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -1385,6 +1422,7 @@ struct Tune {
         col_threads = geti("PLX_SSFM_COL_THREADS", -1);
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
+        wpad = geti("PLX_SSFM_WPAD", -2);         // complex samples added to the working copy's row pitch; -1: no working copy
         if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
         if (const char *e = getenv("PLX_SSFM_GROUP_MIB")) group_mib = atof(e);
     }
@@ -1548,7 +1586,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     P->col_threads = P->lds_col > 80 * 1024 ? 1024 : 512;   // measured: 512-thread column workgroups (2 per CU, 16 waves) beat
                                                             // 256 by 3-12 %; tall tiles of large frames: one workgroup per CU, 16 waves
     if (tune.col_threads == 128 || tune.col_threads == 256 || tune.col_threads == 512 || tune.col_threads == 1024) P->col_threads = tune.col_threads;
-    if (allow_lds(k_colx16, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
+    if (allow_lds(k_colx16<false>, P->lds_col) != hipSuccess || allow_lds(k_colx16<true>, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
         allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
         (!P->tw_compact && allow_lds(k_row, P->lds_row > P->rs_lds ? P->lds_row : P->rs_lds) != hipSuccess) ||
         (P->tw_compact && allow_lds(k_row4k, P->rs_lds) != hipSuccess)) {
@@ -1569,7 +1607,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
                 ncu = v;
         }
         const int tiles_pf = nfc * (N2 / a.W);
-        const int cap = ncu * blocks_per_cu(k_colx16, 256, P->lds_col);
+        const int cap = ncu * std::min(blocks_per_cu(k_colx16<false>, 256, P->lds_col), blocks_per_cu(k_colx16<true>, 256, P->lds_col));
         if (tiles_pf <= cap) {
             P->fused = 1;
             P->tiles_pf = tiles_pf;
@@ -1585,6 +1623,20 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             a.mbox = P->d_mbox;
             a.mbox_stride = mstride;
             a.grab = (int *)(P->d_mbox + (size_t)mstride * (P->fused_grid / tiles_pf));
+        }
+    }
+    // Working copy with a padded row pitch for the fused sweep over 4096-point rows (2^20-sample frames): rows 64 KiB apart
+    // put every row of a column tile on the same L2 channel, and the tile's store burst queues there (measured: issuing a
+    // tile's stores takes 6 us at 2^20 against 3 us at 2^16, profiles/r03_notes.md).
+    if (P->fused && P->tw_compact) {
+        const int pad = tune.wpad >= -1 ? tune.wpad : kDefaultWorkPad;
+        if (pad >= 0) {
+            P->wpitch = N2 + pad;
+            const size_t per_pol = (size_t)F * nfc * N1 * P->wpitch;
+            if (hipMalloc((void **)&P->d_work, 2 * per_pol * sizeof(cplx)) != hipSuccess) {
+                free_plan(P);
+                PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed (working copy of the field)");
+            }
         }
     }
     // Cache-resident frame groups (plx_ssfm_propagate_dev): group_mib MiB of field per group, a whole number of rounds of
@@ -1705,6 +1757,12 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
     a.umax = P->d_umax + (size_t)g0 * nfc;
     if (a.brf_per_frame) a.brf = P->d_brf + (size_t)g0 * a.nplates * BRF_STRIDE;
     if (a.psum) a.psum = P->d_psum + (size_t)g0 * P->N;
+    if (P->d_work) {
+        const size_t per_pol = (size_t)P->d.max_frames * nfc * N1 * P->wpitch;
+        a.wx = P->d_work + (size_t)g0 * nfc * N1 * P->wpitch;
+        a.wy = a.wx + per_pol;
+        a.wpitch = P->wpitch;
+    }
     a.nframes = nframes;
     a.active = P->d_active;
     a.nactive = P->d_ndone + 2;
@@ -1771,7 +1829,8 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
 #endif
                 a.round = steps + sidx;
                 PLX_MARK(0, steps + sidx);
-                PLX_LAUNCH(k_colx16, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
+                if (a.wx) PLX_LAUNCH(k_colx16<true>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
+                else PLX_LAUNCH(k_colx16<false>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
 #endif

@@ -288,8 +288,10 @@ def test_power_ladder_batch_every_frame_keeps_the_reference_step_count(lib, orac
     hp.close()
 
 
-def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monkeypatch):
-    """Config[4]'s shape in small: 8 frames of 2^20 samples on a steep launch-power ladder, three spans.  A 2^20 frame is ONE
+@pytest.mark.parametrize("nspans", [3, 40])
+def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monkeypatch, nspans):
+    """Config[4]'s shape: 8 frames of 2^20 samples on a steep launch-power ladder, three spans -- and the FORTY spans
+    config[4] states (the shape whose stale-list walk once stalled the fused sweep).  A 2^20 frame is ONE
     team of the fused column sweep (512 tiles = the whole grid), and batches under 64 frames rebuild the active list only once
     per chunk of steps -- so most of the time the team walks a STALE list, running through finished frames without meeting at
     a barrier while its first workgroup posts the next frames ahead.  (A ring of four mailbox entries used to be overwritten
@@ -303,7 +305,7 @@ def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monk
     for env in ({}, {"PLX_SSFM_NO_FUSE": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, nspans=3)
+        cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, nspans=nspans)
         hp = pipeline.HotPath(cfg, max_frames=F)
         for k in env:
             monkeypatch.delenv(k)
@@ -319,9 +321,11 @@ def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monk
     (nc0, st0, x0, y0), (nc1, st1, x1, y1) = out
     assert nc0.tolist() == nc1.tolist() and st0 == st1
     assert max(nc0) >= 4 * min(nc0)
+    # (forty strongly nonlinear spans amplify the two transforms' different rounding: the bar grows with the span count)
+    bar = FIELD_RTOL * (1 if nspans <= 3 else 1e3)
     for f in range(F):
-        assert np.abs(x0[f] - x1[f]).max() <= FIELD_RTOL * np.abs(x1[f]).max()
-        assert np.abs(y0[f] - y1[f]).max() <= FIELD_RTOL * np.abs(y1[f]).max()
+        assert np.abs(x0[f] - x1[f]).max() <= bar * np.abs(x1[f]).max()
+        assert np.abs(y0[f] - y1[f]).max() <= bar * np.abs(y1[f]).max()
 
 
 def test_fibre_beside_a_busy_stream_is_bit_identical_to_the_fibre_alone(lib):

@@ -761,10 +761,14 @@ def test_ampliflat_function_surface(lib):
     assert p == pytest.approx(2.0, rel=1e-9)
 
 
-def test_wdm_16ch_multispan_chain_vs_oracle_c2(lib, oracle):
+@pytest.mark.parametrize("nspans", [3, 10])
+def test_wdm_16ch_multispan_chain_vs_oracle_c2(lib, oracle, nspans):
     """BASELINE config[2] shape at a size the oracle finishes in seconds: 16 'sepfields' channels, dual-pol,
     'gps-' (per-channel SPM, shared dz from the max over channels fiber.m:694-698, per-channel beta1 walk-off and
-    gamma :327-328), three spans each followed by ampliflat with injected ASE (ampliflat.m:123-129).
+    gamma :327-328), three spans -- and config[2]'s TEN spans as stated -- each followed by ampliflat with injected ASE
+    (ampliflat.m:123-129).  With ten spans of accumulated ASE the oracle's own 1e-15 sensitivity reaches 1e-3 (measured:
+    1e-13, 1e-13, 2e-7, 1e-7, 2e-7, 1e-6, 2e-4, 4e-4, 1e-3, 5e-4 per span): the field bar follows it, while the step
+    count, the first step and the span's power balance (independent of where the steps fall) stay tight.
 
     Every span starts from bit-identical inputs on both sides.  Once ASE is in the field the reference's step-size
     rule is ill-conditioned: dz(k+1) depends on max|u|^2 at z(k), which for a noise-loaded, walking-off WDM comb
@@ -775,7 +779,7 @@ def test_wdm_16ch_multispan_chain_vs_oracle_c2(lib, oracle):
     from polmux_amd import synth
     from polmux_amd.ampliflat import ase_sigma
     from polmux_amd.gstate import GSTATE, to_device_field, to_host_field
-    nsymb, nt, nch, nspans, nplates = 64, 32, 16, 3, 10
+    nsymb, nt, nch, nplates = 64, 32, 16, 10
     n = nsymb * nt
     px.reset_all(nsymb, nt, nch)
     GSTATE.SYMBOLRATE = 28.0
@@ -800,13 +804,23 @@ def test_wdm_16ch_multispan_chain_vs_oracle_c2(lib, oracle):
         rc, fd, nc, ox, oy = oracle.matrix_ssfm(hx, hy, *args)
         _, _, nc2, px2, _ = oracle.matrix_ssfm(hx * (1 + 1e-15), hy, *args)
         cond = np.abs(px2 - ox).max() / np.abs(ox).max()                           # oracle vs oracle, 1e-15 apart
+        if nspans > 3:       # (one probe is one draw of the amplification; the long chain takes the worse of two directions)
+            _, _, nc3, px3, _ = oracle.matrix_ssfm(hx, hy * (1 - 1e-15), *args)
+            cond = max(cond, np.abs(px3 - ox).max() / np.abs(ox).max())
+            assert nc3 == nc
         assert rc == 0 and nc == brf["ncycle"] == nc2
         assert brf["firstdz"] == pytest.approx(fd, rel=1e-12)
-        bar = max(FIELD_RTOL, 100 * cond)
+        # a 1e-15 probe moves the result by `cond`; the device's transforms differ from the oracle's by a few 1e-16 at every
+        # one of ~150 steps, not once: three decades over the probe, and never looser than the stated 1e-6 while cond < 1e-9
+        bar = max(FIELD_RTOL, (100 if nspans <= 3 else 1000) * cond)
         ex = np.abs(to_host_field(GSTATE.FIELDX) - ox).max() / np.abs(ox).max()
         ey = np.abs(to_host_field(GSTATE.FIELDY) - oy).max() / np.abs(oy).max()
         worst.append((ex, cond))
-        assert max(ex, ey) <= bar and bar < 1e-4, "span %d: field %.3g / %.3g, oracle conditioning %.3g" % (s, ex, ey, cond)
+        assert max(ex, ey) <= bar and bar < (1e-4 if s < 3 else 1.0), "span %d: field %.3g / %.3g, oracle conditioning %.3g" % (s, ex, ey, cond)
+        # what does not depend on where the steps fall: the span's power balance (unitary steps x exp(-alpha L))
+        pg = (np.abs(to_host_field(GSTATE.FIELDX)) ** 2 + np.abs(to_host_field(GSTATE.FIELDY)) ** 2).sum()
+        po = (np.abs(ox) ** 2 + np.abs(oy) ** 2).sum()
+        assert abs(pg - po) <= 1e-10 * po
         noise = r.standard_normal((n, 2 * nch)) + 1j * r.standard_normal((n, 2 * nch))
         gx0, gy0 = to_host_field(GSTATE.FIELDX), to_host_field(GSTATE.FIELDY)
         g = px.ampliflat(16.0, "gain", dict(f=5.0, noise=noise))
