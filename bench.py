@@ -68,7 +68,7 @@ def parse():
                     help="timed region in BASELINE config[3] style: fiber('gps-') with a fresh random-birefringence draw per "
                          "frame and per step; the Monte-Carlo leg proper (ShardedBer) runs after the timed region in every mode")
     ap.add_argument("--mc-rounds", type=int, default=8, help="rounds of the Monte-Carlo leg (0: skip it; 8 x 128 = config[3]'s 1024 realisations per GPU)")
-    ap.add_argument("--mc-depth", type=int, default=3, help="Monte-Carlo rounds enqueued ahead of the one being reduced (their receivers run beside each other)")
+    ap.add_argument("--mc-depth", type=int, default=7, help="Monte-Carlo rounds enqueued ahead of the one being reduced (their receivers run beside each other)")
     ap.add_argument("--mc-frames", type=int, default=128, help="realisations per GPU per round (config[3]: 1024 over 8 GPUs)")
     ap.add_argument("--mc-nf", type=float, default=31.0, help="noise figure [dB] of the amplifier in the Monte-Carlo leg")
     ap.add_argument("--spans", type=int, default=1, help="spans per step, with in-line amplifiers between them (config[4]: 40)")
@@ -340,12 +340,16 @@ def workload_label(a, n):
 def offline_traffic(fused, F, n):
     """HBM bytes per launch of the dominant kernel from the PMC counters.  Counters need their own rocprofv3 passes
     (FETCH_SIZE, WRITE_SIZE: MI355X_MICROARCH.md, HBM section), so this is NOT measured in this run: it is read from the
-    summary of scripts/traffic_pmc.sh on this round's build, if one is committed."""
-    for name in ("r02_traffic.json",):
+    summary of scripts/traffic_pmc.sh on this round's build, if one is committed (2^16- and 2^20-sample frames)."""
+    for name in ("r03_traffic.json", "r02_traffic.json"):
         tj = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tj):
             continue
         tr = json.load(open(tj))
+        if n == 1 << 20:
+            tr = tr.get("frames_2pow20", {})
+        elif n != 65536:
+            return None, None
         if not fused:
             tr = tr.get("plain_three_sweep", {})
         per = tr.get("bytes_per_sample_by_kernel")
@@ -543,6 +547,8 @@ def main():
     single = None
     if rank == 0 and not a.mc and not a.no_single_frame:
         sx, sy = hp.make_batch(1)
+        hp.profile(False)              # (no HIP event between the launches: a lone frame's step loop is launch-bound)
+        hp.fibre(sx.clone(), sy.clone())
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         hp.fibre(sx, sy)
@@ -576,7 +582,7 @@ def main():
         sweeps = 2 if fused else 3
         group_bytes = SWEEP_BYTES * sweeps
         group_gbs = group_bytes * sample_steps / (fib * 1e-3) / 1e9
-        traffic, traffic_src = offline_traffic(fused, F, n) if (a.flag == "g-s-" and n == 65536) else (None, None)
+        traffic, traffic_src = offline_traffic(fused, F, n) if a.flag == "g-s-" else (None, None)
         active_frames = float(np.mean([(ncyc > s).sum() for s in range(int(ncyc.max()))])) if len(ncyc) else float(F)
         out = {
             "metric": "dual-pol Gsample/s through SSFM+Rx-DSP", "value": value, "unit": "Gsample/s",

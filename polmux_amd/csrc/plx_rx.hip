@@ -24,6 +24,7 @@
 #include "plx_gateway.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -907,12 +908,15 @@ extern "C" int plx_cde_ofde(const double *xr, const double *xi, const double *yr
 }
 
 // ================================================================ pol-demux host ===
+// batches of this many frames and more run k_cma16 in four-wave workgroups (fewer CUs carry a CMA wave: see k_cma16)
+static const int kCmaPackMin = 64;    // (measured with four Monte-Carlo rounds of 128 in flight: +2...8 %, profiles/r03_mc.txt)
 static int launch_demux(int method, DemuxArgs &a, void *stream)
 {
     if (method == PLX_DEMUX_CMA && !a.single_pass && a.taps <= 8 && a.dontskip && a.L >= 16) {
         // big batches travel four waves to a workgroup (see k_cma16); a few frames keep a CU per wave (sharing one costs the
         // recurrence ~14 %: 16 frames of 2^20 samples, 148 -> 170 ms)
-        const int thr = a.nframes >= 256 ? CMA16_THREADS : 64, fpw = thr / 16;
+        static const int pack_min = getenv("PLX_CMA_PACK_MIN") ? atoi(getenv("PLX_CMA_PACK_MIN")) : kCmaPackMin;   // (read once)
+        const int thr = a.nframes >= pack_min ? CMA16_THREADS : 64, fpw = thr / 16;
         const unsigned gx = (unsigned)((a.nframes + fpw - 1) / fpw);
         PLX_LAUNCH(k_cma16, dim3(gx), dim3(thr), 0, stream, a);
     } else if (method == PLX_DEMUX_CMA) {

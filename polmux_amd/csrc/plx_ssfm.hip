@@ -1353,7 +1353,9 @@ struct plx_ssfm {
 };
 
 static const double kInv2Pi = 0.15915494309189533577;
-static const int kDefaultWorkPad = 8;         // complex samples (128 B) added to the row pitch of the working copy; PLX_SSFM_WPAD overrides (-1: none)
+static const int kDefaultWorkPad = -1;        // working copy of 2^20-sample frames: off.  Measured (profiles/r03_wpad_ab.txt): pads of 0 / 8 / 72 / 264 /
+                                              // 2056 samples leave k_colx16 at 360-373 us per 16 frames against 361-365 without the copy -- rows 64 KiB
+                                              // apart are NOT what slows the 2^20 sweep; PLX_SSFM_WPAD=<pad> keeps the path testable
 static const double kDefaultGroupMiB = 0.0;   // field MiB per cache-resident frame group (0: off); PLX_SSFM_GROUP_MIB overrides
 
 static int ilog2(int64_t v)
@@ -1625,9 +1627,9 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             a.grab = (int *)(P->d_mbox + (size_t)mstride * (P->fused_grid / tiles_pf));
         }
     }
-    // Working copy with a padded row pitch for the fused sweep over 4096-point rows (2^20-sample frames): rows 64 KiB apart
-    // put every row of a column tile on the same L2 channel, and the tile's store burst queues there (measured: issuing a
-    // tile's stores takes 6 us at 2^20 against 3 us at 2^16, profiles/r03_notes.md).
+    // Optional working copy with a padded row pitch for the fused sweep over 4096-point rows (2^20-sample frames).  The
+    // hypothesis it was built to test -- rows 64 KiB apart put a column tile's rows on one L2 channel -- did not hold
+    // (profiles/r03_notes.md): off unless PLX_SSFM_WPAD >= 0.
     if (P->fused && P->tw_compact) {
         const int pad = tune.wpad >= -1 ? tune.wpad : kDefaultWorkPad;
         if (pad >= 0) {

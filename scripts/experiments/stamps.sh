@@ -1,12 +1,12 @@
 #!/bin/bash
 # dev experiment: where a k_colx16 workgroup's tile time goes (instrumented copy of the library, thread-0 wall-clock stamps).
-# usage: scripts/experiments/stamps.sh build [--nowait]   (here: instruments a COPY of plx_ssfm.hip with stamps_patch.py and cross-compiles polmux_amd/lib/libpolmux_hip_stamps.so)
+# usage: scripts/experiments/stamps.sh build   (here: instruments a COPY of plx_ssfm.hip with stamps_patch.py and cross-compiles polmux_amd/lib/libpolmux_hip_stamps.so)
 #        gpurun -- bash scripts/experiments/stamps.sh run [frames]
 set -e
 cd "$(dirname "$0")/../.."
 if [ "$1" = build ]; then
   mkdir -p build_stamps
-  python3 scripts/experiments/stamps_patch.py $2 > /dev/null
+  python3 scripts/experiments/stamps_patch.py > /dev/null
   OBJS=""
   for f in polmux_amd/csrc/*.hip; do
     o=build_stamps/$(basename ${f%.hip}).o

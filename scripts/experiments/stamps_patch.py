@@ -4,7 +4,8 @@
 The product source carries only marker comments (`// [phase N] ...`, `// [stamps:init|poll|iter|exit|lds]`); this script
 writes an instrumented copy to build_stamps/plx_ssfm.hip (git-ignored) in which the markers are replaced by the
 stamping code below.  scripts/experiments/stamps.sh builds libpolmux_hip_stamps.so from that copy.
---nowait additionally makes nobody wait at the frame barrier (TIMING ONLY: wrong results)."""
+(A --nowait variant, nobody waiting at the frame barrier, existed in round 2; with the controller run by every workgroup on
+its own maximum it no longer terminates -- the step sequence diverges -- and was removed.)"""
 import os
 import re
 import sys
@@ -20,7 +21,7 @@ HOST = 'extern "C" void plx_ssfm_stamps(long long *out, int reset)\n{\n    hipDe
 
 def main():
     s = open(SRC).read()
-    anchor = "__global__ __launch_bounds__(256, 2) void k_colx16("
+    anchor = "template <bool WORK> __global__ __launch_bounds__(256, 2) void k_colx16("
     assert anchor in s
     s = s.replace(anchor, DEFS + "\n" + anchor, 1)
     s, n = re.subn(r"^(\s*)// \[phase (\d+)\]", lambda m: "%sPLX_STAMP(%s); //" % (m.group(1), m.group(2)), s, flags=re.M)
@@ -29,8 +30,6 @@ def main():
         mark = "    // [stamps:%s]\n" % name
         assert mark in s, name
         s = s.replace(mark, body + "\n")
-    if "--nowait" in sys.argv:
-        s = s.replace("                if (__all(all)) break;\n", "                if (__all(all)) break;\n                break;   // NOWAIT: timing only\n", 1)
     s += "\n" + HOST + "\n"
     csrc = os.path.join(ROOT, "polmux_amd", "csrc")
     s = s.replace('#include "../../include/polmux_hip.h"', '#include "%s"' % os.path.join(ROOT, "include", "polmux_hip.h"))

@@ -36,4 +36,13 @@ for mode, key, kernels in (("fused", None, ["k_colx16", "k_row"]), ("plain", "pl
     else:
         blk["selected_by"] = "PLX_SSFM_NO_FUSE=1"
         res[key] = blk
+if os.path.exists(os.path.join(d, "big_FETCH_SIZE.txt")):      # 2^20-sample frames, 16 per launch (k_row4k reports as k_row4k)
+    fe, wr = read("big", "FETCH_SIZE"), read("big", "WRITE_SIZE")
+    sb = 16 * (1 << 20)
+    names = {"k_colx16": "k_colx16", "k_row4k": "k_row"}
+    per = {names[k]: (2 * fe[k] + wr[k]) * 1024 / sb for k in names if k in fe and k in wr}
+    res["frames_2pow20"] = {"samples_per_launch": sb, "kernels": ["k_colx16", "k_row4k"], "fetch_kb": [fe.get("k_colx16"), fe.get("k_row4k")],
+                            "write_kb": [wr.get("k_colx16"), wr.get("k_row4k")], "bytes_per_sample_by_kernel": per,
+                            "bytes_per_sample_step": sum(per.values()),
+                            "note": "k_row4k re-reads betat (8 MiB per frame and polarisation) and the inter-pass twiddles from HBM at this size"}
 print(json.dumps(res, indent=1))

@@ -288,8 +288,8 @@ def test_power_ladder_batch_every_frame_keeps_the_reference_step_count(lib, orac
     hp.close()
 
 
-@pytest.mark.parametrize("nspans", [3, 40])
-def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monkeypatch, nspans):
+@pytest.mark.parametrize("nspans,wpad", [(3, None), (40, None), (3, "8")])
+def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monkeypatch, nspans, wpad):
     """Config[4]'s shape: 8 frames of 2^20 samples on a steep launch-power ladder, three spans -- and the FORTY spans
     config[4] states (the shape whose stale-list walk once stalled the fused sweep).  A 2^20 frame is ONE
     team of the fused column sweep (512 tiles = the whole grid), and batches under 64 frames rebuild the active list only once
@@ -302,14 +302,15 @@ def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monk
     F = 8
     dbm = -4.0 + 12.0 * np.arange(F) / (F - 1)
     out = []
-    for env in ({}, {"PLX_SSFM_NO_FUSE": "1"}):
+    # (wpad: the fused sweep on the plan's own working copy of the field, rows 64 KiB + 128 B apart: PLX_SSFM_WPAD)
+    for env in (({"PLX_SSFM_WPAD": wpad} if wpad else {}), {"PLX_SSFM_NO_FUSE": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, nspans=nspans)
         hp = pipeline.HotPath(cfg, max_frames=F)
         for k in env:
             monkeypatch.delenv(k)
-        assert hp.fused() == (not env)
+        assert hp.fused() == ("PLX_SSFM_NO_FUSE" not in env)
         scale = 10 ** (dbm / 10) / cfg.pavg_mw
         ux, uy = hp.make_batch(F, scale)
         hp.fibre(ux, uy)
