@@ -231,15 +231,24 @@ __global__ __launch_bounds__(CMA16_THREADS) void k_cma16(DemuxArgs a)
     const cplx *x1 = a.x + (size_t)f * 2 * L, *x2 = x1 + L;
     cplx *yo = a.y + (size_t)f * 2 * L + (size_t)r * L;
     cplx ha = make_double2(0, 0), hb = ha; // h_r(t,1), h_r(t,2)
-    if (t == a.halftaps) {
+    // single_pass: ONE call of the MEX gateway (cmaadaptivefilter.c:57-91 as called by the unchanged driver): the taps come
+    // from the caller, output i uses samples i .. i+taps-1 (no cyclic extension), Mdim - Ntap + 1 outputs, one pass
+    const bool single = a.single_pass != 0;
+    if (single) {
+        if (tap_ok) {
+            const cplx *hh = a.h + (size_t)f * 4 * a.taps + (size_t)r * 2 * a.taps;
+            ha = hh[t]; hb = hh[a.taps + t];
+        }
+    } else if (t == a.halftaps) {
         const cplx *M = a.M + (size_t)f * a.m_stride;
         ha = M[2 * r]; hb = M[2 * r + 1];
     }
     const double Rr = r ? a.R2 : a.R1, mu = a.mu;
-    const int64_t off = (int64_t)t - a.halftaps;
+    const int64_t off = single ? (int64_t)t : (int64_t)t - a.halftaps;
+    const int64_t nout = single ? L - a.taps + 1 : L;
     int c = 1, npass = 0;
     bool active = c < a.max_passes;
-    const int64_t nchunks = L / CMA_U, tail0 = nchunks * CMA_U;
+    const int64_t nchunks = nout / CMA_U, tail0 = nchunks * CMA_U;
     while (__any(active)) {
         const cplx oa = ha, ob = hb;
         const double mua = active ? mu : 0.0;
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(CMA16_THREADS) void k_cma16(DemuxArgs a)
 #pragma unroll
             for (int u = 0; u < CMA_U; u++) { ca[u] = na[u]; cb[u] = nb[u]; }
         }
-        for (int64_t i = tail0; i < L; i++) { // L not a multiple of the chunk
+        for (int64_t i = tail0; i < nout; i++) { // the outputs beyond the last whole chunk
             int64_t idx = i + off;
             if (idx < 0) idx += L; else if (idx >= L) idx -= L;
             const cplx xa = tap_ok ? x1[idx] : make_double2(0, 0), xb = tap_ok ? x2[idx] : make_double2(0, 0);
@@ -304,7 +313,7 @@ __global__ __launch_bounds__(CMA16_THREADS) void k_cma16(DemuxArgs a)
         if (active) {
             npass++;
             c++;
-            if (d < 5e-5 || !(c < a.max_passes)) active = false;
+            if (single || d < 5e-5 || !(c < a.max_passes)) active = false;
         }
     }
     if (frame_ok && tap_ok && a.h) { // [h1(:,1) h1(:,2) | h2(:,1) h2(:,2)]
@@ -912,7 +921,7 @@ extern "C" int plx_cde_ofde(const double *xr, const double *xi, const double *yr
 static const int kCmaPackMin = 64;    // (measured with four Monte-Carlo rounds of 128 in flight: +2...8 %, profiles/r03_mc.txt)
 static int launch_demux(int method, DemuxArgs &a, void *stream)
 {
-    if (method == PLX_DEMUX_CMA && !a.single_pass && a.taps <= 8 && a.dontskip && a.L >= 16) {
+    if (method == PLX_DEMUX_CMA && a.taps <= 8 && a.dontskip && a.L >= 16 && (!a.single_pass || a.L - a.taps + 1 >= 1)) {
         // big batches travel four waves to a workgroup (see k_cma16); a few frames keep a CU per wave (sharing one costs the
         // recurrence ~14 %: 16 frames of 2^20 samples, 148 -> 170 ms)
         static const int pack_min = getenv("PLX_CMA_PACK_MIN") ? atoi(getenv("PLX_CMA_PACK_MIN")) : kCmaPackMin;   // (read once)

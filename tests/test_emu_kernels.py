@@ -313,7 +313,9 @@ def test_emu_sweep_variants(emu, oracle, monkeypatch):
     ref = [oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0]) for f in fields]
     # (PLX_EMU_CUS=1: a one-CU device -- the fused grid is two workgroups, so each walks the tiles of all three frames, with the
     # emulator's two-entry window of the frame list moving on under it)
-    for env in ({}, {"PLX_EMU_CUS": "1"}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_P1": "4"}):
+    # (one CU also makes the grid ONE team: the one-team form k_colx16_solo, which asks for the next tile ahead of the frame
+    #  barrier and makes its second exchange in rounds; PLX_SSFM_NO_SOLO keeps k_colx16 walking the three frames instead)
+    for env in ({}, {"PLX_EMU_CUS": "1"}, {"PLX_EMU_CUS": "1", "PLX_SSFM_NO_SOLO": "1"}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_P1": "4"}):
         nf = 1 if "PLX_SSFM_P1" in env else 3
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -334,6 +336,41 @@ def test_emu_sweep_variants(emu, oracle, monkeypatch):
             assert ncyc[f] == onc
             assert np.abs(gx[f] - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
             assert np.abs(gy[f] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
+
+
+def test_emu_one_team_sweep_exact_nonlinear_step(emu, oracle, monkeypatch):
+    """k_colx16_solo's rare paths: the '--s-' exact single step (fiber.m:172-174: nonlinear phases of radians, so the Kerr step
+    takes the full-range sincos through the small exchange buffer, two rows at a time) and a stale frame list (a batch under
+    64 frames rebuilds it once per chunk: the second launch meets finished frames) -- against the oracle, and against k_colx16
+    on the same plan geometry bit for bit."""
+    n, nt, L = 4096, 64, 2e4
+    fls = [0, 0, 1, 0]
+    betat, db1 = _tables(n, nt, fls, 1)
+    fields = [_qpsk_field(n, nt, p)[:2] for p in (30.0, 60.0)]
+    ref = [oracle.matrix_ssfm(f[0], f[1], betat, db1, L, np.inf, [1.3e-3], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0]) for f in fields]
+    got = []
+    for env in ({"PLX_EMU_CUS": "1"}, {"PLX_EMU_CUS": "1", "PLX_SSFM_NO_SOLO": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-3], L, np.inf, betat, db1, frames=2)
+        plan = C.c_void_p()
+        emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+        for k in env:
+            monkeypatch.delenv(k)
+        ux = _il(np.stack([f[0] for f in fields])); uy = _il(np.stack([f[1] for f in fields]))
+        emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 2, None)
+        ncyc = np.zeros(2, np.int32)
+        emu.call("plx_ssfm_results", plan, 2, None, _vp(ncyc))
+        emu.call("plx_ssfm_destroy", plan)
+        got.append((ux.copy(), uy.copy(), ncyc.copy()))
+    np.testing.assert_array_equal(got[0][0], got[1][0]); np.testing.assert_array_equal(got[0][1], got[1][1])
+    gx, gy = got[0][0].view(np.complex128).reshape(2, n), got[0][1].view(np.complex128).reshape(2, n)
+    for f in range(2):
+        rc, ofd, onc, ox, oy = ref[f]
+        assert got[0][2][f] == onc == 1
+        assert np.abs(ox).max() > 0 and np.abs(np.angle(gx[f] * np.conj(fields[f][0]))).max() > 0.5      # radians of nonlinear phase
+        assert np.abs(gx[f] - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
+        assert np.abs(gy[f] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
 
 
 def test_emu_long_rows_compact_twiddles(emu, oracle, monkeypatch):

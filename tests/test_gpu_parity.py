@@ -811,12 +811,13 @@ def test_wdm_16ch_multispan_chain_vs_oracle_c2(lib, oracle, nspans):
         assert rc == 0 and nc == brf["ncycle"] == nc2
         assert brf["firstdz"] == pytest.approx(fd, rel=1e-12)
         # a 1e-15 probe moves the result by `cond`; the device's transforms differ from the oracle's by a few 1e-16 at every
-        # one of ~150 steps, not once: three decades over the probe, and never looser than the stated 1e-6 while cond < 1e-9
-        bar = max(FIELD_RTOL, (100 if nspans <= 3 else 1000) * cond)
+        # one of ~150 steps, not once: a floor of 3e-8 (observed 8e-9 where the probe said 3e-11) plus 30 x the probe
+        # (observed ratios 1.1 ... 3 once cond > 1e-7)
+        bar = max(FIELD_RTOL, 100 * cond) if nspans <= 3 else max(FIELD_RTOL, 3e-8 + 30 * cond)
         ex = np.abs(to_host_field(GSTATE.FIELDX) - ox).max() / np.abs(ox).max()
         ey = np.abs(to_host_field(GSTATE.FIELDY) - oy).max() / np.abs(oy).max()
         worst.append((ex, cond))
-        assert max(ex, ey) <= bar and bar < (1e-4 if s < 3 else 1.0), "span %d: field %.3g / %.3g, oracle conditioning %.3g" % (s, ex, ey, cond)
+        assert max(ex, ey) <= bar and bar < (1e-4 if nspans <= 3 else 0.1), "span %d: field %.3g / %.3g, oracle conditioning %.3g" % (s, ex, ey, cond)
         # what does not depend on where the steps fall: the span's power balance (unitary steps x exp(-alpha L))
         pg = (np.abs(to_host_field(GSTATE.FIELDX)) ** 2 + np.abs(to_host_field(GSTATE.FIELDY)) ** 2).sum()
         po = (np.abs(ox) ** 2 + np.abs(oy) ** 2).sum()
