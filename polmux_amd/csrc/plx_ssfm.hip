@@ -1308,307 +1308,6 @@ template <bool WORK> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs
 }
 
 
-// The full-range Kerr step of k_colx16_solo on two rows of the tile parked in the small exchange buffer xb ([2][16][16]:
-// (row pair, j, t)), one lane per polarisation pair (see kerr_full_range).
-__device__ __noinline__ void kerr_full_range_rows(cplx *xb, int j, int t, double gamleff, int manakov)
-{
-    for (int kk = 0; kk < 2; kk++) {
-        cplx X = xb[((kk * 16 + j) << 4) + t], Y = xb[((kk * 16 + j) << 4) + t + 8];
-        const double P = X.x * X.x + X.y * X.y + Y.x * Y.x + Y.y * Y.y;
-        const cplx nl = cexpi(-gamleff * P);
-        X = cmul(X, nl);
-        Y = cmul(Y, nl);
-        if (!manakov) {
-            const double s3 = 2 * (X.x * Y.y - X.y * Y.x);
-            double sp, cp;
-            sincos(gamleff * s3 / 3, &sp, &cp);
-            const cplx xx = make_double2(cp * X.x + sp * Y.x, cp * X.y + sp * Y.y);
-            const cplx yy = make_double2(cp * Y.x - sp * X.x, cp * Y.y - sp * X.y);
-            X = xx; Y = yy;
-        }
-        xb[((kk * 16 + j) << 4) + t] = X;
-        xb[((kk * 16 + j) << 4) + t + 8] = Y;
-    }
-}
-
-// ----------------------------------------------------------------------------------------------
-// k_colx16_solo: the fused column sweep when ONE frame's tiles are the whole grid (2^20-sample frames: 512 tiles, one
-// team).  Same arithmetic as k_colx16, to the bit; what differs is WHEN the next tile is asked for.
-//
-// In a one-team launch every workgroup is in the same phase at the same time.  k_colx16 requests the next tile once the
-// second exchange has left the buffer, i.e. together with the stores of the current tile: 512 workgroups then put 64 MiB
-// on the memory system in one burst (12.8 us at the 5 TB/s the part streams), compute with it idle, and meet at a
-// 512-party barrier (measured: stores 5.9 us to issue instead of 2.9, 8.7 us of barrier skew instead of 4.9,
-// profiles/r03_notes.md).  Here the next tile is requested as soon as the FIRST exchange has been read out -- before the
-// frame barrier, the controller, the Kerr step and the forward transform -- so that it lands during the wait, and the
-// stores have the memory system to themselves.  That needs the 64 KiB buffer free from then on, so the second exchange goes
-// through a small buffer xb (8 KiB) in eight rounds: every thread writes two of its points, the 32 threads whose points
-// these are read them.  One team takes the listed frames in order (no claims, no mailbox: the next frame is known up front).
-// The polling wave (wave 0) does not stage -- its agent-scope polls would queue behind its own copies in the one vmcnt --
-// wave 1 stages rows 0..127 and both of their record copies; the record copies rotate over THREE slots (the copy of
-// iteration it-1 is still owed its controller tail when the one of it+1 starts to land).
-template <bool WORK> __global__ __launch_bounds__(256, 2) void k_colx16_solo(SsfmArgs a, int tiles_x)
-{
-    PLX_DYN_LDS(lds);
-    if (all_done_or_aborted(a)) return;
-    const int tid = threadIdx.x, t = tid & 15, j = tid >> 4;
-    const int N2 = WORK ? 4096 : 1 << a.p2;
-    const int LOGN = WORK ? 20 : a.p1 + a.p2;
-    cplx *s = (cplx *)lds;                 // [256][16] landing zone of the staged tile + first exchange
-    cplx *xb = s + 4096;                   // [2][16][16] second exchange, two points per thread and round
-    cplx *tw = xb + 512;                   // W_256^k, k < 128
-    double *red = (double *)(tw + 128);
-    FrameCtl *lctl = (FrameCtl *)(red + 32);   // [3 slots][4 copies]
-    CtrlK *const kk = (CtrlK *)(lctl + 12);
-    double *const gaml = (double *)((char *)(lctl + 12) + 128);
-    lds_load_twiddles(tw, a.tw1, 128, tid, 256);
-    cplx *const fld = (t < 8) ? a.ux : a.uy;
-    const bool first_round = !WORK || a.round == 0;
-    const size_t wp = WORK ? (size_t)a.wpitch : (size_t)N2;
-    const size_t wfs = WORK ? ((size_t)a.wpitch << 8) : ((size_t)1 << LOGN);
-    const size_t sp = first_round ? (size_t)N2 : wp, sfs = first_round ? ((size_t)1 << LOGN) : wfs;
-    const int colt = t & 7;
-    const bool isx = t < 8;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int nact = a.nactive[0];
-    const int tiles_pf = gridDim.x, ti = blockIdx.x;
-    const int c = WORK ? 0 : ti / tiles_x, bx = ti - c * tiles_x;
-    // rows r0 .. r0+63 of this workgroup's tile of frame f -> s (16 copies of 4 rows each)
-    auto stage_rows = [&](int f, int r0) {
-        const int fc = WORK ? f : f * a.nfc + c;
-        int lq = lane >> 4;
-        pin(lq);
-        const cplx *sfld = fld;
-        if (WORK && !first_round) { int tq = t; pin(tq); sfld = tq < 8 ? a.wx : a.wy; }
-        const cplx *src = sfld + (size_t)fc * sfs + (size_t)bx * 8 + colt + (size_t)(r0 + lq) * sp;
-        glds_rows(src, (size_t)4 * sp, s + (size_t)r0 * 16, lane);
-    };
-    auto stage_rec = [&](int f, FrameCtl *rec) {
-        int ln = lane;
-        pin(ln);
-        if (ln < (int)(sizeof(FrameCtl) / 16)) glds16((const cplx *)(a.ctl + f) + ln, (cplx *)rec, ln);
-    };
-    // waves 1..3 (wave 0 polls): the tile and the record of frame f into slot `slot`; the wave's own record copy goes LAST and
-    // carries the sentinel the wave (and, for wave 1's copy, wave 0) spins on at the loop top
-    auto stage = [&](int f, int slot) {
-        if (wave == 0) return;
-        FrameCtl *const rec = lctl + 4 * slot + wave;
-        if (lane == (int)(offsetof(FrameCtl, done) / 16)) rec->done = PLX_REC_SENTINEL;
-        lds_settle();
-        if (wave == 1) {
-            stage_rows(f, 0);
-            stage_rows(f, 64);
-            stage_rec(f, lctl + 4 * slot);          // copy 0: the one the controller works on
-        } else {
-            stage_rows(f, 64 * wave);
-        }
-        stage_rec(f, rec);
-    };
-    for (int k = tid; k < a.nfc; k += 256) gaml[k] = a.gam[k];
-    int f = nact > 0 ? a.active[0] : -1;
-    if (f < 0) return;
-    stage(f, 0);
-    if (tid == 0) {
-        red[8] = -1.0;
-        kk->dphimax = a.dphimax; kk->alphalin = a.alphalin; kk->dzmax = a.dzmax; kk->dz0 = a.dz0; kk->zdone0 = a.zdone0; kk->Lf = a.Lf; kk->lcorr = a.lcorr;
-        kk->dual = a.dual ? 1 : 0; kk->resume = a.resume ? 1 : 0; kk->ncycle0 = a.ncycle0; kk->nfc = 0; kk->ndone = a.ndone; kk->umax = nullptr; kk->gam = nullptr;
-    }
-    auto settle = [&](int slot) {          // tid 0 only; slot: where the owed record was staged
-        const int pf = (int)red[8];
-        if (pf < 0) return;
-        FrameCtl *pr = lctl + 4 * slot;
-        if (!pr->done) ctrl_tail_call((const PLX_LDS_QUAL CtrlK *)kk, (PLX_LDS_QUAL FrameCtl *)pr);
-        a.ctl[pf] = *pr;
-        red[8] = -1.0;
-    };
-    __syncthreads();                       // twiddles staged; wave 1's sentinel is in place before wave 0 looks at it
-    int it = 0, slot = 0;                  // slot = it mod 3
-    for (;; it++, slot = slot == 2 ? 0 : slot + 1) {
-        const int nslot = slot == 2 ? 0 : slot + 1, pslot = slot == 0 ? 2 : slot - 1;
-        FrameCtl *const wrec = lctl + 4 * slot + wave;
-        const int fc = WORK ? f : f * a.nfc + c;
-        const int fnext = it + 1 < nact ? a.active[it + 1] : -1;      // (one team: the listed frames in order)
-        if (a.safe_land) drain_vmem();
-        while (lds_peek(&(lctl + 4 * slot + (wave == 0 ? 1 : wave))->done) == PLX_REC_SENTINEL) nap();
-        emu_lockstep();
-        if (wrec->done) {                  // a listed frame that has finished meanwhile (the same answer in every wave)
-            if (tid == 0) settle(pslot);
-            lds_barrier();
-            f = fnext;
-            if (f < 0) { it++; slot = nslot; break; }
-            stage(f, nslot);
-            lds_barrier();                 // (wave 0 must not look at the new slot before wave 1 has put its sentinel there)
-            continue;
-        }
-        const size_t cbase = ((size_t)fc << LOGN) + (size_t)bx * 8 + colt;
-        const bool started = wrec->started != 0;
-        {
-            cplx x[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = s[((16 * j + k) << 4) + t];
-            if (started) {
-                r16_dit(x);
-#pragma unroll
-                for (int k = 0; k < 16; k++) s[((16 * j + k) << 4) + t] = x[k];
-            }
-        }
-        lds_barrier();
-        cplx y[16];                        // point j + 16k
-#pragma unroll
-        for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
-        double sc = 1.0;
-        if (started) {
-            lvl2_dit256(y, j, tw);
-            sc = wrec->att * a.invN;
-        }
-        double m = 0;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            y[k] = cscale(y[k], sc);
-            const double po = fma(y[k].y, y[k].y, y[k].x * y[k].x);
-            const double p = po + lane_xchg<8>(po);
-            m = fmax(p, m);
-        }
-        m = wave_max(m);
-        if ((tid & 63) == 0) red[tid >> 6] = m;
-        lds_barrier();                     // every wave has read the tile out of s: the landing zone is free ...
-        if (fnext >= 0) stage(fnext, nslot);   // ... and the next tile is asked for NOW, ahead of the frame barrier
-        // Frame barrier: as in k_colx16 (all-gather of the tile maxima, the controller's head in every workgroup)
-        if (tid < 64) {
-            const unsigned par = (unsigned)a.round & 1u;
-            unsigned long long *slots = a.slots + ((size_t)par * a.nframes + f) * tiles_pf;
-            double mm = red[0];
-            for (int w = 1; w < 4; w++) mm = red[w] > mm ? red[w] : mm;
-            const unsigned long long mine = (unsigned long long)__double_as_longlong(mm);
-            if (tid == 0) {
-                st_agent(slots + ti, mine);
-                st_agent(a.slots + ((size_t)(par ^ 1u) * a.nframes + f) * tiles_pf + ti, ~0ull);
-                settle(pslot);             // (the wait below hides it)
-            }
-            double pm;
-            unsigned spins = 0;
-            bool dead = false;
-            const long long t0 = plx_clock();
-            for (;;) {
-                bool all = true;
-                pm = -INFINITY;
-                int i0 = tid;
-                pin(i0);
-                for (int i = i0; i < tiles_pf; i += 64) {
-                    const unsigned long long b = (i == ti) ? mine : ld_agent(slots + i);
-                    if (b == ~0ull) all = false;
-                    else { const double gp = gaml[i / tiles_x] * __longlong_as_double((long long)b); pm = gp > pm ? gp : pm; }
-                }
-                if (__all(all)) break;
-                nap();
-                if ((++spins & 255u) == 0) {
-                    const int late = ld_agent((const unsigned *)a.ndone + 1) != 0 || plx_clock() - t0 > a.spin_ticks;
-                    if (__any(late)) { dead = true; break; }
-                }
-            }
-            pm = wave_max(pm);
-            if (tid == 0) {
-                if (dead) {
-                    st_agent((unsigned *)a.ndone + 1, 1u);
-                    red[19] = 1.0;
-                } else {
-                    const double pv = ctrl_head_call((const PLX_LDS_QUAL CtrlK *)kk, (PLX_LDS_QUAL FrameCtl *)wrec, ti == 0, pm);
-                    if (ti == 0) red[8] = (double)f;
-                    red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm; red[19] = 0.0;
-                }
-            }
-        }
-        lds_barrier();
-        if (red[19] != 0.0) return;        // barrier timed out (uniform over the workgroup): no store, no control update
-        const double leff = red[16];
-        const bool finished = red[17] != 0.0;
-        if (finished) {                    // the frame has reached the fibre end: write the field out
-#pragma unroll
-            for (int k = 0; k < 16; k++) fld[cbase + (size_t)(j + 16 * k) * N2] = y[k];
-        } else {
-            if (a.spm) {                   // Kerr step of step s+1 (:832-852) on registers, as in k_colx16
-                const double gamleff = gaml[c] * leff;
-                int tq = t;
-                pin(tq);
-                const double sgn = tq < 8 ? 1.0 : -1.0, sgn2 = tq < 8 ? 2.0 : -2.0;
-                if (fabs(gamleff) * red[18] < 0.0625) {
-                    auto kerr16 = [&](auto cn) {
-                        constexpr bool CNLSE = decltype(cn)::value;
-#pragma unroll
-                        for (int k = 0; k < 8; k++) {
-                            int tk = tq;
-                            pin(tk);
-                            const bool ix = tk < 8;
-                            const cplx own = ix ? y[k] : y[k + 8], snd = ix ? y[k + 8] : y[k];
-                            const cplx oth = make_double2(lane_xchg<8>(snd.x), lane_xchg<8>(snd.y));
-                            const double P = fma(own.y, own.y, own.x * own.x) + fma(oth.y, oth.y, oth.x * oth.x);
-                            double sn, cs;
-                            sincos_taylor(-gamleff * P, &sn, &cs);
-                            const cplx nl = make_double2(cs, sn);
-                            cplx A = cmul(own, nl), B = cmul(oth, nl);
-                            if (CNLSE) {
-                                const double s3 = sgn2 * __dsub_rn(__dmul_rn(A.x, B.y), __dmul_rn(A.y, B.x));
-                                double sp_, cp_;
-                                sincos_taylor(div3(gamleff * s3), &sp_, &cp_);
-                                const double sg = sgn * sp_, ng = -sg;
-                                const cplx A2 = make_double2(cp_ * A.x + sg * B.x, cp_ * A.y + sg * B.y);
-                                B = make_double2(cp_ * B.x + ng * A.x, cp_ * B.y + ng * A.y);
-                                A = A2;
-                            }
-                            const cplx back = make_double2(lane_xchg<8>(B.x), lane_xchg<8>(B.y));
-                            y[k] = ix ? A : back;
-                            y[k + 8] = ix ? back : A;
-                            sched_fence();
-                        }
-                    };
-                    if (a.manakov) kerr16(std::false_type{}); else kerr16(std::true_type{});
-                } else {                   // the rare full-range step, two rows at a time through xb (s belongs to the next tile)
-#pragma unroll
-                    for (int r = 0; r < 8; r++) {
-                        xb[((0 * 16 + j) << 4) + t] = y[2 * r];
-                        xb[((1 * 16 + j) << 4) + t] = y[2 * r + 1];
-                        lds_barrier();
-                        if (isx) kerr_full_range_rows(xb, j, t, gamleff, a.manakov);
-                        lds_barrier();
-                        y[2 * r] = xb[((0 * 16 + j) << 4) + t];
-                        y[2 * r + 1] = xb[((1 * 16 + j) << 4) + t];
-                        lds_barrier();
-                    }
-                }
-            }
-            lvl2_dif256(y, j, tw);
-            // second exchange, in rounds: point j + 16k of thread j becomes point 16 j' + k' of thread j' = k, k' = j.  Round r:
-            // the threads j = 2r, 2r+1 put all sixteen of their points into xb, EVERY thread takes its two (k' = 2r, 2r+1) out.
-            cplx x[16];
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                if ((j >> 1) == r) {
-#pragma unroll
-                    for (int k = 0; k < 16; k++) xb[((((j & 1) << 4) + k) << 4) + t] = y[k];
-                }
-                lds_barrier();
-                x[2 * r] = xb[((0 * 16 + j) << 4) + t];
-                x[2 * r + 1] = xb[((1 * 16 + j) << 4) + t];
-                lds_barrier();
-            }
-            r16_dif(x);
-            if (WORK) {
-                int tq = t;
-                pin(tq);
-                cplx *const wd = (tq < 8 ? a.wx : a.wy) + (size_t)fc * wfs + (size_t)bx * 8 + colt;
-#pragma unroll
-                for (int k = 0; k < 16; k++) wd[(size_t)(16 * j + k) * wp] = x[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; k++) fld[cbase + (size_t)(16 * j + k) * N2] = x[k];
-            }
-        }
-        f = fnext;
-        if (f < 0) { it++; slot = nslot; break; }
-    }
-    if (tid == 0) settle(slot == 0 ? 2 : slot - 1);
-}
-
 } // namespace
 
 // ================================================================= host side ===
@@ -1634,8 +1333,6 @@ struct plx_ssfm {
     unsigned long long *d_mbox = nullptr;    // [teams][frames + 4] mailboxes of the fused column sweep's teams, then the two claim counters
     size_t mbox_bytes = 0;
     int fused = 0, fused_grid = 0, tiles_pf = 0;
-    int solo = 0;                  // one frame's tiles are the whole fused grid: k_colx16_solo (next tile requested ahead of the frame barrier)
-    size_t lds_solo = 0;
     int col_threads = 512;         // workgroup size of k_col_fwd / k_col_inv
     int row_threads = ROW_THREADS; // workgroup size of k_row
     int row_split = 0, rs_threads = 0; // long rows without PMD: one polarisation per workgroup (scalar row pass twice)
@@ -1715,7 +1412,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_solo = 0;
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2;
     double barrier_timeout_ms = 500.0, group_mib = -1.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -1728,7 +1425,6 @@ struct Tune {
         col_threads = geti("PLX_SSFM_COL_THREADS", -1);
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
-        no_solo = geti("PLX_SSFM_NO_SOLO", 0);   // one-team launches through k_colx16 instead of k_colx16_solo (A/B, tests)
         wpad = geti("PLX_SSFM_WPAD", -2);         // complex samples added to the working copy's row pitch; -1: no working copy
         if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
         if (const char *e = getenv("PLX_SSFM_GROUP_MIB")) group_mib = atof(e);
@@ -1930,13 +1626,6 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             a.mbox = P->d_mbox;
             a.mbox_stride = mstride;
             a.grab = (int *)(P->d_mbox + (size_t)mstride * (P->fused_grid / tiles_pf));
-            // one team = the whole grid: the form of the sweep that requests the next tile ahead of the frame barrier
-            // (8 KiB second-exchange buffer + a third set of record copies on top of k_colx16's LDS)
-            P->lds_solo = P->lds_col + 512 * sizeof(cplx) + 4 * sizeof(FrameCtl);
-            if (!tune.no_solo && P->fused_grid == tiles_pf && allow_lds(k_colx16_solo<false>, P->lds_solo) == hipSuccess &&
-                allow_lds(k_colx16_solo<true>, P->lds_solo) == hipSuccess &&
-                ncu * std::min(blocks_per_cu(k_colx16_solo<false>, 256, P->lds_solo), blocks_per_cu(k_colx16_solo<true>, 256, P->lds_solo)) >= tiles_pf)
-                P->solo = 1;
         }
     }
     // Optional working copy with a padded row pitch for the fused sweep over 4096-point rows (2^20-sample frames).  The
@@ -2143,10 +1832,7 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
 #endif
                 a.round = steps + sidx;
                 PLX_MARK(0, steps + sidx);
-                if (P->solo) {
-                    if (a.wx) PLX_LAUNCH(k_colx16_solo<true>, dim3((unsigned)P->tiles_pf), blk, P->lds_solo, st, a, tcx);
-                    else PLX_LAUNCH(k_colx16_solo<false>, dim3((unsigned)P->tiles_pf), blk, P->lds_solo, st, a, tcx);
-                } else if (a.wx) PLX_LAUNCH(k_colx16<true>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
+                if (a.wx) PLX_LAUNCH(k_colx16<true>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
                 else PLX_LAUNCH(k_colx16<false>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
@@ -2258,7 +1944,7 @@ extern "C" int plx_ssfm_utilisation(plx_ssfm *P, int64_t *frame_steps, int64_t *
 extern "C" int plx_ssfm_info(plx_ssfm *P, int32_t *info)
 {
     if (!P || !info) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_info: null argument");
-    info[0] = P->fused; info[1] = P->p1;           // (info[0] stays 0 / 1; whether the one-team form runs is plx_ssfm_solo()) info[2] = P->p2; info[3] = P->fused_grid; info[4] = P->tiles_pf;
+    info[0] = P->fused; info[1] = P->p1; info[2] = P->p2; info[3] = P->fused_grid; info[4] = P->tiles_pf;
     info[5] = P->col_threads; info[6] = P->row_threads; info[7] = P->row_split;
     return PLX_OK;
 }
