@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="run the receiver on the fibre stream (no stream overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame latency measurement after the timed region")
+    ap.add_argument("--no-cohmix-line", action="store_true", help="skip the short side measurement with the reference's own front end")
     ap.add_argument("--no-gateway", action="store_true", help="skip the per-call timing of the MEX-shaped gateway tier")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the batch the one-core CPU baseline processes (~0.5 s each)")
     return ap.parse_args()
@@ -547,8 +548,10 @@ def main():
     single = None
     if rank == 0 and not a.mc and not a.no_single_frame:
         sx, sy = hp.make_batch(1)
-        hp.profile(False)              # (no HIP event between the launches: a lone frame's step loop is launch-bound)
-        hp.fibre(sx.clone(), sy.clone())
+        hp.profile(False)              # (no HIP event between the launches: a lone frame's step loop is replayed from a graph,
+        keep = (sx.clone(), sy.clone())  #  captured once per field buffer -- so the warm-up call uses the SAME buffers)
+        hp.fibre(sx, sy)
+        sx.copy_(keep[0]); sy.copy_(keep[1])
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         hp.fibre(sx, sy)
@@ -558,6 +561,41 @@ def main():
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         single = {"fibre_ms": (t2 - t1) * 1e3, "rx_ms": (t3 - t2) * 1e3, "gsample_per_s": n / (t3 - t1) / 1e9}
+    # the same workload with the reference's OWN front end (receiver_cohmix + 5-bit ADC + decimate on the device) instead of the
+    # harness's 2-sps pick: a short timed region of its own, reported beside the headline (never instead of it)
+    cohmix_line = None
+    if rank == 0 and world == 1 and a.frontend == "pick" and not a.mc and not a.no_cohmix_line and not a.power_ladder and a.spans == 1:
+        ccfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag=a.flag, frontend="cohmix", variants=a.variants)
+        chp = pipeline.HotPath(ccfg, max_frames=F)
+        csteps = max(2, min(4, a.steps))
+        cb = [chp.make_batch(F) for _ in range(2)]
+        cpristine = chp.make_batch(F)
+        crx = None if (a.no_overlap or not chp.overlap_ok()) else torch.cuda.Stream()
+        free_ev = [None, None]
+
+        def cstep(i):
+            ux_, uy_ = cb[i % 2]
+            if i >= 2:         # (the front end overwrites the field with the photocurrents: restage from the pristine copy)
+                if free_ev[i % 2] is not None:
+                    torch.cuda.current_stream().wait_event(free_ev[i % 2])
+                ux_.copy_(cpristine[0]); uy_.copy_(cpristine[1])
+            chp.fibre(ux_, uy_)
+            chp.receive(ux_, uy_, noise_sigma=a.noise, noise_seed=7000 + i, side_stream=crx)
+            if crx is not None:
+                free_ev[i % 2] = torch.cuda.Event(); free_ev[i % 2].record(crx)
+        cstep(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(1, 1 + csteps):
+            cstep(i)
+        torch.cuda.synchronize()
+        cdt = time.perf_counter() - t1
+        cohmix_line = {"value": csteps * F * n / cdt / 1e9, "unit": "Gsample/s", "steps": csteps, "ms_per_step": cdt / csteps * 1e3,
+                       "front_end": "receiver_cohmix (optical filter, hybrids + balanced photodiodes, electrical filter) + %d-bit ADC + decimate "
+                                    "to 2 sps on the device (RxPdmCohQpsk.m:36-72)" % ccfg.adcbits,
+                       "note": "same batch size and fibre; two field buffers, restaged from a pristine copy inside the timed region"}
+        chp.close()
+        del cb, cpristine
     gateway = None
     if rank == 0 and world == 1 and not a.no_gateway:
         gateway = gateway_bench(cfg, hp)
@@ -606,7 +644,8 @@ def main():
                        "bit_errors_resolved": int(res_total.item()) if a.mc else None,
                        "bits": int(world) * a.steps * F * 4 * a.nsymb, "restaged_batches": restaged,
                        "rehearsal_all_ranks_on_one_gpu": bool(rehearsal),
-                       "single_frame": single},
+                       "single_frame": single,
+                       "with_reference_front_end": cohmix_line},
             # a PMD plan's row pass does one exponential + 20 multiply-adds per waveplate trunk and frequency: FP64-VALU-bound
             # (exception 1), still priced in bytes against the HBM peak
             "roofline": {"bound": "fp64-valu" if (dom == "k_row" and hp.pmd) else "hbm", "kernel": dom,

@@ -381,3 +381,46 @@ def test_front_end_at_2pow20_uses_the_long_row_filter_pass(lib, oracle):
     rx = front.rx_front(cur, True, 0, hp.front_shifts, t["decim"], t["fir"])
     assert np.abs(hp.rx[0].cpu().numpy().T - rx).max() < 1e-10 * np.abs(rx).max()
     hp.close()
+
+
+def test_small_batch_graph_replay_and_safe_landing_are_bit_identical_to_the_eager_loop(lib, monkeypatch):
+    """Batches under 64 frames replay their step loop from a hipGraph (eight steps per launch, the fused sweep's launch index
+    read from device memory); PLX_SSFM_NO_GRAPH=1 keeps the eager loop, PLX_SSFM_SAFE_LANDING=1 adds the ordinary
+    s_waitcnt vmcnt(0) in front of the sentinel landing of k_colx16's staged tile.  Same kernels, same arguments: fields, step
+    counts and first steps must agree to the bit -- on a fresh buffer (capture), on the same buffer again (replay of the
+    cached graph) and on another buffer (re-capture)."""
+    import torch
+    from polmux_amd import pipeline
+    F = 5
+    dbm = np.array([-3.0, 0.0, 2.0, 4.0, 6.0])
+    res = {}
+    for name, env in (("graph", {}), ("eager", {"PLX_SSFM_NO_GRAPH": "1"}), ("safe", {"PLX_SSFM_SAFE_LANDING": "1", "PLX_SSFM_NO_GRAPH": "1"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg = pipeline.HotPathConfig(nsymb=1024, nt=64, variants=2)
+        hp = pipeline.HotPath(cfg, max_frames=F)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert hp.fused()
+        scale = 10 ** (dbm / 10) / cfg.pavg_mw
+        outs = []
+        ux, uy = hp.make_batch(F, scale)
+        keep = (ux.clone(), uy.clone())
+        for rep in range(3):
+            if rep == 1:                       # the same buffers again
+                ux.copy_(keep[0]); uy.copy_(keep[1])
+            if rep == 2:                       # other buffers
+                ux, uy = keep[0].clone(), keep[1].clone()
+            hp.fibre(ux, uy)
+            _sync()
+            fd = np.zeros(F)
+            hp.lib.call("plx_ssfm_results", hp.ssfm, F, fd.ctypes.data, None)
+            outs.append((ux.clone(), uy.clone(), hp.last_ncycle(F).copy(), fd))
+        res[name] = outs
+        hp.close()
+    ref = res["eager"][0]
+    assert max(ref[2]) > min(ref[2])           # frames leave the loop at different steps
+    for name in ("graph", "eager", "safe"):
+        for o in res[name]:
+            assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]), name
+            assert o[2].tolist() == ref[2].tolist() and np.array_equal(o[3], ref[3])

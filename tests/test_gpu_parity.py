@@ -807,8 +807,12 @@ def test_wdm_16ch_multispan_chain_vs_oracle_c2(lib, oracle, nspans):
         if nspans > 3:       # (one probe is one draw of the amplification; the long chain takes the worse of two directions)
             _, _, nc3, px3, _ = oracle.matrix_ssfm(hx, hy * (1 - 1e-15), *args)
             cond = max(cond, np.abs(px3 - ox).max() / np.abs(ox).max())
-            assert nc3 == nc
-        assert rc == 0 and nc == brf["ncycle"] == nc2
+            assert abs(nc3 - nc) <= 1
+        # the step COUNT is a function of the same ill-conditioned maxima: exact while the oracle's own sensitivity is small,
+        # within one step once a 1e-15 probe already moves the field by more than 1e-7 (observed: 147 against 146 in one
+        # late span of the ten)
+        assert rc == 0 and abs(nc - nc2) <= (0 if cond < 1e-7 else 1)
+        assert abs(brf["ncycle"] - nc) <= (0 if cond < 1e-7 else 1), "span %d: ncycle %d against %d, conditioning %.3g" % (s, brf["ncycle"], nc, cond)
         assert brf["firstdz"] == pytest.approx(fd, rel=1e-12)
         # a 1e-15 probe moves the result by `cond`; the device's transforms differ from the oracle's by a few 1e-16 at every
         # one of ~150 steps, not once: a floor of 3e-8 (observed 8e-9 where the probe said 3e-11) plus 30 x the probe
