@@ -548,10 +548,8 @@ def main():
     single = None
     if rank == 0 and not a.mc and not a.no_single_frame:
         sx, sy = hp.make_batch(1)
-        hp.profile(False)              # (no HIP event between the launches: a lone frame's step loop is replayed from a graph,
-        keep = (sx.clone(), sy.clone())  #  captured once per field buffer -- so the warm-up call uses the SAME buffers)
-        hp.fibre(sx, sy)
-        sx.copy_(keep[0]); sy.copy_(keep[1])
+        hp.profile(False)              # (no HIP event between the launches)
+        hp.fibre(sx.clone(), sy.clone())
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         hp.fibre(sx, sy)

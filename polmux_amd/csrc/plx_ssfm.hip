@@ -76,9 +76,6 @@ struct SsfmArgs {
     int *nactive;                  // [0] length of the list, [1] running sum of it over the steps (utilisation accounting)
     long long spin_ticks;          // frame-barrier timeout in ticks of plx_clock() (10 ns)
     unsigned long long *slots;     // [2][nframes][tiles per frame] per-tile max |u|^2 by launch parity (k_colx16), ~0 = not arrived
-    const int *round_dev;          // when set: the launch index of the fused sweep is read from device memory (step loops replayed as a
-                                   // hipGraph cannot carry it in their arguments); the step's LAST row launch advances it (bump_round)
-    int bump_round;
     int safe_land;                 // PLX_SSFM_SAFE_LANDING=1: the staged tile is also waited for with s_waitcnt vmcnt(0) (checks the sentinel landing)
     int round;                     // launch index of the fused sweep within this propagate call
     int *grab;                     // [2] frames claimed beyond the first of every team, by launch parity (k_colx16)
@@ -576,8 +573,6 @@ __device__ __forceinline__ void pmd_trunks(cplx &x, cplx &y, double btf, double 
 __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
-    // (graph replay: the step's last row launch advances the device-resident launch index of the fused sweep)
-    if (a.bump_round && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) atomicAdd((int *)a.round_dev, 1);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int slot = blockIdx.y / a.nfc, c = blockIdx.y - slot * a.nfc;
@@ -735,7 +730,6 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
-    if (a.bump_round && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) atomicAdd((int *)a.round_dev, 1);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x;
     const int slot = blockIdx.y / a.nfc, c = blockIdx.y - slot * a.nfc;
@@ -1003,7 +997,7 @@ template <bool WORK> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs
     // and started in every later round); a frame's last round writes them.  In between the field lives in the plan's
     // working copy when there is one (WORK: row pitch a.wpitch), else in the caller's arrays as well.  The working copy's
     // addresses are formed where they are used (this kernel has no register to spare for loop invariants).
-    const int round = a.round_dev ? a.round_dev[0] : a.round;      // (written by the previous step's row launch: kernel boundaries order it)
+    const int round = a.round;
     const bool first_round = !WORK || round == 0;
     const size_t wp = WORK ? (size_t)a.wpitch : (size_t)N2;                                      // row pitch of the copy worked on
     const size_t wfs = WORK ? ((size_t)a.wpitch << 8) : ((size_t)1 << LOGN);                     // its frame-channel stride
@@ -1334,15 +1328,6 @@ struct plx_ssfm {
     std::vector<FrameCtl> h_ctl;
     int brf_sets = 0;
     size_t lds_col = 0, lds_row = 0;
-    // small batches: the step loop as a replayed hipGraph of kGraphSteps steps (launch-bound otherwise: two dependent launches per
-    // step); captured once per (field pointers, frame count) on the plan's own stream, relaunched per chunk on the caller's
-#ifndef PLX_EMU
-    hipStream_t cap_stream = nullptr;
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-#endif
-    const void *g_ux = nullptr, *g_uy = nullptr;
-    int g_nframes = 0, g_brf_pf = -1, no_graph = 0;
     cplx *d_work = nullptr;                  // working copy of the field with a padded row pitch (fused sweep, 4096-point rows), x then y
     int wpitch = 0;
     unsigned long long *d_slots = nullptr;   // slot barrier of the fused column sweep: [launch parity][frame][tile]
@@ -1388,11 +1373,6 @@ static void free_plan(plx_ssfm *P)
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
     hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active); hipFree(P->d_work);
-#ifndef PLX_EMU
-    if (P->graph_exec) hipGraphExecDestroy(P->graph_exec);
-    if (P->graph) hipGraphDestroy(P->graph);
-    if (P->cap_stream) hipStreamDestroy(P->cap_stream);
-#endif
     if (P->h_ndone) hipHostFree(P->h_ndone);
     if (P->ev) hipEventDestroy(P->ev);
     for (hipEvent_t e : P->evpool) hipEventDestroy(e);
@@ -1433,7 +1413,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_graph = 0;
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2;
     double barrier_timeout_ms = 500.0, group_mib = -1.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -1446,7 +1426,6 @@ struct Tune {
         col_threads = geti("PLX_SSFM_COL_THREADS", -1);
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
-        no_graph = geti("PLX_SSFM_NO_GRAPH", 0);   // small batches through eager launches instead of the replayed step graph
         wpad = geti("PLX_SSFM_WPAD", -2);         // complex samples added to the working copy's row pitch; -1: no working copy
         if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
         if (const char *e = getenv("PLX_SSFM_GROUP_MIB")) group_mib = atof(e);
@@ -1540,7 +1519,6 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     a.invN = 1.0 / (double)N;
     a.spin_ticks = (long long)(tune.barrier_timeout_ms * 1e5);
     a.safe_land = tune.safe_landing;
-    P->no_graph = tune.no_graph;
     // (the mailbox entries of k_colx16 pack frame + 1 and iteration + 1 into 22-bit fields)
     if ((int64_t)desc->max_frames + 4 >= ((int64_t)1 << 22)) { free_plan(P); PLX_FAIL(PLX_ERR_UNSUPPORTED, "plx_ssfm_create: max_frames must be below 2^22 - 4"); }
 
@@ -1764,45 +1742,12 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         }
         for (int pol = 0; pol < 2; pol++) {
             if (pol) b.ux = a.uy;
-            b.bump_round = pol ? a.bump_round : 0;          // (the step's last launch advances the device-side launch index)
             PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
         }
         return;
     }
     PLX_LAUNCH(k_row, dim3((unsigned)(N1 / a.R), FC), dim3((unsigned)P->row_threads), P->lds_row, st, a);
 }
-
-#ifndef PLX_EMU
-// Small batches: kGraphSteps steps of the fused loop (one k_compact, then k_colx16 + the row launch per step) captured into a
-// graph on the plan's own stream -- the same launch code as the eager loop, the launch index read from device memory -- and
-// instantiated once per (field pointers, frame count, waveplate addressing).  Replayed per chunk on the caller's stream.
-static const int kGraphSteps = 8;
-static int build_step_graph(plx_ssfm *P, const SsfmArgs &a, int nframes)
-{
-    if (P->graph_exec && P->g_ux == (const void *)a.ux && P->g_uy == (const void *)a.uy && P->g_nframes == nframes && P->g_brf_pf == a.brf_per_frame)
-        return PLX_OK;
-    if (P->graph_exec) { PLX_HIP(hipGraphExecDestroy(P->graph_exec)); P->graph_exec = nullptr; }
-    if (P->graph) { PLX_HIP(hipGraphDestroy(P->graph)); P->graph = nullptr; }
-    if (!P->cap_stream) PLX_HIP(hipStreamCreateWithFlags(&P->cap_stream, hipStreamNonBlocking));
-    const unsigned FC = (unsigned)nframes * a.nfc;
-    const int N2 = 1 << a.p2, tcx = N2 / a.W, tct = tcx * (int)FC;
-    const dim3 gx((unsigned)(tct < P->fused_grid ? tct : P->fused_grid)), blk(256);
-    PLX_HIP(hipStreamBeginCapture(P->cap_stream, hipStreamCaptureModeRelaxed));
-    PLX_LAUNCH(k_compact, dim3(1), dim3(COMPACT_THREADS), COMPACT_THREADS * sizeof(int), P->cap_stream, (const FrameCtl *)a.ctl, nframes, P->d_active,
-               P->d_ndone + 2, kGraphSteps);
-    for (int i = 0; i < kGraphSteps; i++) {
-        if (a.wx) PLX_LAUNCH(k_colx16<true>, gx, blk, P->lds_col, P->cap_stream, a, tcx, P->tiles_pf);
-        else PLX_LAUNCH(k_colx16<false>, gx, blk, P->lds_col, P->cap_stream, a, tcx, P->tiles_pf);
-        launch_row(P, a, FC, P->cap_stream);
-    }
-    hipGraph_t g = nullptr;
-    PLX_HIP(hipStreamEndCapture(P->cap_stream, &g));
-    P->graph = g;
-    PLX_HIP(hipGraphInstantiate(&P->graph_exec, P->graph, nullptr, nullptr, 0));
-    P->g_ux = a.ux; P->g_uy = a.uy; P->g_nframes = nframes; P->g_brf_pf = a.brf_per_frame;
-    return PLX_OK;
-}
-#endif
 
 // One GROUP of frames through the whole step loop (fiber.m:518-552).  g0: first frame of the group within the call.
 static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nframes, hipStream_t st)
@@ -1849,19 +1794,6 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
     // steps are launch-bound: the sweeps skip a listed frame that has finished meanwhile)
     const bool compact_every_step = nframes >= 64;
     int chunk = 4, steps = 0;
-    bool use_graph = false;
-#ifndef PLX_EMU
-    // batches under 64 frames are launch-bound (a lone C1 frame: ~16 us of kernels per step behind two dependent launches):
-    // their step loop is replayed from a graph, kGraphSteps steps at a time
-    if (fused && !compact_every_step && !P->profile && !P->no_graph) {
-        a.round_dev = P->d_ndone + 4;           // (zeroed with the other counters above)
-        a.bump_round = 1;
-        const int rc = build_step_graph(P, a, nframes);
-        if (rc) return rc;
-        use_graph = true;
-        chunk = kGraphSteps;
-    }
-#endif
     // (a group that follows another one of the same call starts with the steps the previous group needed, less a
     //  margin: frames of a batch usually resemble each other, and every launch past a group's end is an idle one)
     if (g0 > 0 && P->last_group_steps > 12) chunk = P->last_group_steps - 4;
@@ -1884,14 +1816,7 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
     };
 #define PLX_MARK(cls, step) do { int rc_ = mark((cls), (step)); if (rc_) return rc_; } while (0)
     for (;;) {
-#ifndef PLX_EMU
-        if (use_graph) {
-            PLX_HIP(hipGraphLaunch(P->graph_exec, st));
-            P->slots_launched += (int64_t)chunk * (FC / nfc);
-            P->row_launches += chunk;
-        }
-#endif
-        for (int sidx = 0; sidx < chunk && !use_graph; sidx++) {
+        for (int sidx = 0; sidx < chunk; sidx++) {
             const dim3 gcol((unsigned)(N2 / a.W), FC);
             P->slots_launched += FC / nfc;
             if (fused) {
@@ -1948,8 +1873,7 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
         PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         PLX_HIP(hipEventRecord(P->ev, st));
         pending = true;
-        if (use_graph) { }                                            // (a graph replays a fixed number of steps)
-        else if (chunk > 8) chunk = 4;                                // (after a predicted first chunk)
+        if (chunk > 8) chunk = 4;                                     // (after a predicted first chunk)
         else if (chunk < (compact_every_step ? 8 : 16)) chunk *= 2;   // (small batches are launch-bound: longer chunks keep the queue fed)
         if (steps > kMaxSteps) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate");
     }
