@@ -67,9 +67,13 @@ def parse():
     ap.add_argument("--mc", action="store_true",
                     help="timed region in BASELINE config[3] style: fiber('gps-') with a fresh random-birefringence draw per "
                          "frame and per step; the Monte-Carlo leg proper (ShardedBer) runs after the timed region in every mode")
-    ap.add_argument("--mc-rounds", type=int, default=8, help="rounds of the Monte-Carlo leg (0: skip it; 8 x 128 = config[3]'s 1024 realisations per GPU)")
-    ap.add_argument("--mc-depth", type=int, default=7, help="Monte-Carlo rounds enqueued ahead of the one being reduced (their receivers run beside each other)")
-    ap.add_argument("--mc-frames", type=int, default=128, help="realisations per GPU per round (config[3]: 1024 over 8 GPUs)")
+    ap.add_argument("--mc-rounds", type=int, default=2, help="rounds of the Monte-Carlo leg (0: skip it; 2 x 512 = config[3]'s 1024 realisations per GPU)")
+    ap.add_argument("--mc-depth", type=int, default=1, help="Monte-Carlo rounds enqueued ahead of the one being reduced (their receivers run beside each other)")
+    ap.add_argument("--mc-frames", type=int, default=512,
+                    help="realisations per GPU per round.  The CMA of a noise-loaded realisation runs its 299 passes whatever the batch (~57 ms "
+                         "of a serial recurrence) and its waves keep column workgroups off their CUs meanwhile, so few LARGE rounds beat many "
+                         "small ones: 128 x 8 rounds, 8 in flight: 3800/s; 512 x 2, 2 in flight: 5000/s (profiles/r03_mc.txt); the statistics "
+                         "are identical (rounds are replayed in realisation order)")
     ap.add_argument("--mc-nf", type=float, default=31.0, help="noise figure [dB] of the amplifier in the Monte-Carlo leg")
     ap.add_argument("--spans", type=int, default=1, help="spans per step, with in-line amplifiers between them (config[4]: 40)")
     ap.add_argument("--nf", type=float, default=None, help="noise figure [dB] of the in-line amplifiers (default: noiseless)")

@@ -592,11 +592,17 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     if (tw_one) { if (tid < twn) twv = a.tw2[tid]; }
     else lds_load_twiddles(tw, a.tw2, twn, tid, nthr);
     const size_t N = (size_t)1 << (a.p1 + a.p2);
-    const size_t base = (size_t)fc * N;
     const int j0 = blockIdx.x * R;
     const int nel = R << a.p2;
-    const cplx *uyp = a.dual ? a.uy : a.ux;
-    const size_t rowbase = (size_t)j0 * N2;      // the R rows of this workgroup are contiguous
+    // the field: the caller's arrays (rows N2 apart: the R rows of this workgroup are contiguous), or the plan's working copy
+    // with its own row pitch (SsfmArgs::wx).  gofs(e): where element e = (row, point) of this workgroup's rows lives.
+    const bool wk = a.wx != nullptr;
+    cplx *const fx = wk ? a.wx : a.ux;
+    cplx *const fy = wk ? a.wy : (a.dual ? a.uy : a.ux);
+    const size_t base = wk ? ((size_t)fc << a.p1) * a.wpitch + (size_t)j0 * a.wpitch : (size_t)fc * N + (size_t)j0 * N2;
+    const int rowadd = wk ? a.wpitch - N2 : 0;
+    auto gofs = [&](int e) -> size_t { return base + e + (size_t)(e >> a.p2) * rowadd; };
+    const size_t rowbase = (size_t)j0 * N2;      // (position of the workgroup's rows in the per-frequency tables)
     // the inter-pass twiddles of a thread's points: with exactly ROW_CH points per thread (the usual shape) they stay
     // in registers for the conjugate multiply on the way out
     const bool keep_tw = nel == nthr * ROW_CH;
@@ -616,8 +622,8 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         for (int k = 0; k < ROW_CH; k++) {
             const int e = row_lane_point(min(e0 + k * nthr, nel - 1), N2);   // (the lane's point: rotated within blocks of 16, see plx_fft.h)
             tv[k] = a.tpass[rowbase + e];
-            xv[k] = a.ux[base + rowbase + e];
-            yv[k] = uyp[base + rowbase + e];
+            xv[k] = fx[gofs(e)];
+            yv[k] = fy[gofs(e)];
         }
 #pragma unroll
         for (int k = 0; k < ROW_CH; k++) { pin(tv[k]); pin(xv[k]); pin(yv[k]); }
@@ -701,8 +707,8 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         for (int k = 0; k < ROW_CH; k++) {
             const int e = row_lane_point(tid + k * nthr, N2);
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
-            a.ux[base + rowbase + e] = cmulc(s[o], tkeep[k]);
-            if (a.dual) a.uy[base + rowbase + e] = cmulc(s[o + R * TSp], tkeep[k]);
+            fx[gofs(e)] = cmulc(s[o], tkeep[k]);
+            if (a.dual) fy[gofs(e)] = cmulc(s[o + R * TSp], tkeep[k]);
         }
         return;
     }
@@ -710,8 +716,8 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
             const int e = row_lane_point(el, N2);
         const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
         const cplx t = a.tpass[rowbase + e];
-        a.ux[base + rowbase + e] = cmulc(s[o], t);
-        if (a.dual) a.uy[base + rowbase + e] = cmulc(s[o + R * TSp], t);
+        fx[gofs(e)] = cmulc(s[o], t);
+        if (a.dual) fy[gofs(e)] = cmulc(s[o + R * TSp], t);
     }
 }
 
@@ -978,15 +984,16 @@ __device__ __forceinline__ void emu_lockstep() {}
 #endif
 
 
-// WORK: the plan keeps a working copy of the field with its own row pitch (SsfmArgs::wx; 2^20-sample frames).
-template <bool WORK> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf)
+// WP2 > 0: the plan keeps a working copy of the field with its own row pitch (SsfmArgs::wx); such plans are single-field
+// frames of 256 x 2^WP2 samples, and the kernel takes that geometry as constants (it has no register to spare).
+template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf)
 {
+    constexpr bool WORK = WP2 > 0;
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, t = tid & 15, j = tid >> 4;
-    // (WORK plans are single-field frames of 256 x 4096 samples: geometry by construction, not from the arguments)
-    const int N2 = WORK ? 4096 : 1 << a.p2;
-    const int LOGN = WORK ? 20 : a.p1 + a.p2;
+    const int N2 = WORK ? (1 << WP2) : 1 << a.p2;
+    const int LOGN = WORK ? 8 + WP2 : a.p1 + a.p2;
     cplx *s = (cplx *)lds;                 // [256][16] exchange buffer
     cplx *tw = s + 4096;                   // W_256^k, k < 128
     double *red = (double *)(tw + 128);
@@ -1355,9 +1362,11 @@ struct plx_ssfm {
 };
 
 static const double kInv2Pi = 0.15915494309189533577;
-static const int kDefaultWorkPad = -1;        // working copy of 2^20-sample frames: off.  Measured (profiles/r03_wpad_ab.txt): pads of 0 / 8 / 72 / 264 /
-                                              // 2056 samples leave k_colx16 at 360-373 us per 16 frames against 361-365 without the copy -- rows 64 KiB
-                                              // apart are NOT what slows the 2^20 sweep; PLX_SSFM_WPAD=<pad> keeps the path testable
+static const int kDefaultWorkPad = -1;        // working copy (2^16- and 2^20-sample single-field frames): off.  Measured (profiles/r03_wpad_ab.txt):
+                                              // at 2^20 pads of 0 ... 2056 samples leave k_colx16 at 360-373 us per 16 frames against 361-365 without
+                                              // the copy; at 2^16 a pad evens out the four slow tiles of a frame (bx = 3 mod 8: 2 us late at every
+                                              // barrier, whatever XCD runs them) but k_colx16 gains < 1 % and k_row loses 1.4 %.
+                                              // PLX_SSFM_WPAD=<pad> keeps the path testable
 static const double kDefaultGroupMiB = 0.0;   // field MiB per cache-resident frame group (0: off); PLX_SSFM_GROUP_MIB overrides
 
 static int ilog2(int64_t v)
@@ -1590,7 +1599,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     P->col_threads = P->lds_col > 80 * 1024 ? 1024 : 512;   // measured: 512-thread column workgroups (2 per CU, 16 waves) beat
                                                             // 256 by 3-12 %; tall tiles of large frames: one workgroup per CU, 16 waves
     if (tune.col_threads == 128 || tune.col_threads == 256 || tune.col_threads == 512 || tune.col_threads == 1024) P->col_threads = tune.col_threads;
-    if (allow_lds(k_colx16<false>, P->lds_col) != hipSuccess || allow_lds(k_colx16<true>, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
+    if (allow_lds(k_colx16<0>, P->lds_col) != hipSuccess || allow_lds(k_colx16<8>, P->lds_col) != hipSuccess || allow_lds(k_colx16<12>, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
         allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
         (!P->tw_compact && allow_lds(k_row, P->lds_row > P->rs_lds ? P->lds_row : P->rs_lds) != hipSuccess) ||
         (P->tw_compact && allow_lds(k_row4k, P->rs_lds) != hipSuccess)) {
@@ -1611,7 +1620,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
                 ncu = v;
         }
         const int tiles_pf = nfc * (N2 / a.W);
-        const int cap = ncu * std::min(blocks_per_cu(k_colx16<false>, 256, P->lds_col), blocks_per_cu(k_colx16<true>, 256, P->lds_col));
+        const int cap = ncu * std::min(blocks_per_cu(k_colx16<0>, 256, P->lds_col), std::min(blocks_per_cu(k_colx16<8>, 256, P->lds_col), blocks_per_cu(k_colx16<12>, 256, P->lds_col)));
         if (tiles_pf <= cap) {
             P->fused = 1;
             P->tiles_pf = tiles_pf;
@@ -1629,10 +1638,10 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             a.grab = (int *)(P->d_mbox + (size_t)mstride * (P->fused_grid / tiles_pf));
         }
     }
-    // Optional working copy with a padded row pitch for the fused sweep over 4096-point rows (2^20-sample frames).  The
-    // hypothesis it was built to test -- rows 64 KiB apart put a column tile's rows on one L2 channel -- did not hold
-    // (profiles/r03_notes.md): off unless PLX_SSFM_WPAD >= 0.
-    if (P->fused && P->tw_compact) {
+    // Optional working copy with a padded row pitch for the fused sweep (single-field frames of 256 x 256 or 256 x 4096
+    // samples).  The hypotheses it was built to test -- rows 64 KiB apart camp on one L2 channel; the four slow tiles of a
+    // 2^16 frame set the pace of its barrier -- did not pay (profiles/r03_notes.md): off unless PLX_SSFM_WPAD >= 0.
+    if (P->fused && nfc == 1 && !a.pmd && (P->tw_compact || P->p2 == 8)) {
         const int pad = tune.wpad >= -1 ? tune.wpad : kDefaultWorkPad;
         if (pad >= 0) {
             P->wpitch = N2 + pad;
@@ -1833,8 +1842,9 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
 #endif
                 a.round = steps + sidx;
                 PLX_MARK(0, steps + sidx);
-                if (a.wx) PLX_LAUNCH(k_colx16<true>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
-                else PLX_LAUNCH(k_colx16<false>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
+                if (a.wx && a.p2 == 12) PLX_LAUNCH(k_colx16<12>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
+                else if (a.wx) PLX_LAUNCH(k_colx16<8>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
+                else PLX_LAUNCH(k_colx16<0>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
 #endif

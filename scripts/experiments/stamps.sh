@@ -28,7 +28,7 @@ from polmux_amd import pipeline
 F = int(os.environ["F"])
 hp = pipeline.HotPath(pipeline.HotPathConfig(flag="g-s-", manakov=os.environ["MK"], nsymb=int(os.environ["NSYMB"])), max_frames=F)
 lib = _abi.get().lib
-out = (C.c_longlong * (32 + 2048))()
+out = (C.c_longlong * (32 + 3072))()
 hp.profile(True)
 for r in range(4):
     ux, uy = hp.make_batch(F)
@@ -56,7 +56,10 @@ print("  polls per tile %.2f" % (out[10] / tiles))
 import numpy as np
 w = np.array(out[32:32 + 512], dtype=np.float64) * 0.01 / (tiles / 512.0)
 print("  barrier wait per tile by workgroup: min %.2f  median %.2f  max %.2f us" % (w.min(), np.median(w), w.max()))
-print("  by XCD (workgroup id mod 8):", " ".join("%.2f" % w[x::8].mean() for x in range(8)))
+print("  by workgroup id mod 8:", " ".join("%.2f" % w[x::8].mean() for x in range(8)))
+xcc = np.array(out[32 + 2048:32 + 2048 + 512], dtype=np.int64)
+print("  by HW_REG_XCC_ID:     ", " ".join("%.2f" % (w[xcc == x].mean() if (xcc == x).any() else float("nan")) for x in range(8)), " (workgroups per XCC:", " ".join(str(int((xcc == x).sum())) for x in range(8)), ")")
+print("  XCC of workgroups 0..15:", xcc[:16].tolist())
 print("  by tile of the frame (id mod 32):", " ".join("%.1f" % w[x::32].mean() for x in range(32)))
 print("  first / second workgroup of a CU (id < 256 / >= 256): %.2f / %.2f" % (w[:256].mean(), w[256:].mean()))
 e = np.array(out[32 + 1024:32 + 1024 + 512], dtype=np.float64) * 0.01

@@ -393,7 +393,9 @@ def test_sentinel_landing_of_the_staged_tile_equals_the_ordinary_wait(lib, monke
     F = 5
     dbm = np.array([-3.0, 0.0, 2.0, 4.0, 6.0])
     res = {}
-    for name, env in (("eager", {}), ("safe", {"PLX_SSFM_SAFE_LANDING": "1"})):
+    # ("wpad": the same sweeps on the plan's own working copy of the field, rows 4 KiB + 128 B apart -- PLX_SSFM_WPAD, off by
+    #  default: the arithmetic does not depend on where the field lives)
+    for name, env in (("eager", {}), ("safe", {"PLX_SSFM_SAFE_LANDING": "1"}), ("wpad", {"PLX_SSFM_WPAD": "8"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         cfg = pipeline.HotPathConfig(nsymb=1024, nt=64, variants=2)
@@ -419,7 +421,7 @@ def test_sentinel_landing_of_the_staged_tile_equals_the_ordinary_wait(lib, monke
         hp.close()
     ref = res["eager"][0]
     assert max(ref[2]) > min(ref[2])           # frames leave the loop at different steps
-    for name in ("eager", "safe"):
+    for name in ("eager", "safe", "wpad"):
         for o in res[name]:
             assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]), name
             assert o[2].tolist() == ref[2].tolist() and np.array_equal(o[3], ref[3])
