@@ -68,6 +68,13 @@ struct SsfmArgs {
     const cplx *tw1, *tw2;         // half tables W_N1^k, W_N2^k
     const double *gam;             // [nfc] effective gamma (x8/9 when Manakov, :499-501)
     const double *brf;             // [sets][nplates][9]: R11 R12 R21 R22 (re,im) db0
+    // PMD plans whose db1 is LINEAR in the signed frequency index m (fiber.m:358: db1 = dgdrms*omega): the trunk phase
+    // deltabeta(m) = A m + B (fiber.m:925) factors over the four-step split m = k1 + N1 m2 into a row and a column phasor,
+    // e1[frame][trunk][N1] = exp(-i 2 pi (A k1 + B)) and e2[frame][trunk][N2] = exp(-i 2 pi A N1 m2), formed once per frame
+    // and step by k_pmd_tab; the row pass then needs one complex product per bin and trunk instead of an exponential.
+    cplx *e1tab, *e2tab;
+    double d1slope;                // D: db1 in turns per unit of m
+    int tmax;                      // trunks the tables hold per frame
     double *psum;                  // [F][N] row-sum of channel powers (scalar XPM, :795)
     FrameCtl *ctl;
     unsigned long long *umax;      // [F][nfc] bit pattern of max |u|^2 (>= 0)
@@ -564,6 +571,60 @@ __device__ __forceinline__ void pmd_trunks(cplx &x, cplx &y, double btf, double 
     y = cmul(h, y);
 }
 
+// The same loop with the trunk phasors read from the tables of k_pmd_tab: e = e1[trunk][row] * e2[trunk][column].
+__device__ __forceinline__ void pmd_trunks_tab(cplx &x, cplx &y, double btf, const cplx *e1, int s1, const cplx *e2, int s2, const double *brf,
+                                               int nplates, int n0, int ntrunk, double dz_total)
+{
+    for (int k = 1; k <= ntrunk; k++) {
+        int plate = n0 + k - 1;
+        plate = plate < 0 ? 0 : (plate >= nplates ? nplates - 1 : plate);
+        const double *m = brf + (size_t)plate * BRF_STRIDE;
+        const double s11 = m[0];
+        const cplx s12 = make_double2(m[1], m[2]);
+        const cplx e = cmul(e1[(size_t)(k - 1) * s1], e2[(size_t)(k - 1) * s2]);     // (cos b, -sin b)
+        const cplx sx = cadd(cscale(x, s11), cmul(s12, y));
+        const cplx sy = csub(cmulc(x, s12), cscale(y, s11));
+        x = make_double2(e.x * x.x - e.y * sx.y, e.x * x.y + e.y * sx.x);
+        y = make_double2(e.x * y.x - e.y * sy.y, e.x * y.y + e.y * sy.x);
+    }
+    const cplx h = cexp_neg_turns(btf * dz_total);
+    x = cmul(h, x);
+    y = cmul(h, y);
+}
+
+// Row and column phasors of every trunk of the step each listed frame is about to make (see SsfmArgs::e1tab).  One workgroup
+// per frame; runs between the step controller (k_ctrl / the fused sweep, which leave ntrunk, dzb_first, dzb_last in the
+// frame's record) and the row pass.
+__global__ __launch_bounds__(256) void k_pmd_tab(SsfmArgs a)
+{
+    if (all_done_or_aborted(a)) return;
+    int f;
+    if (!slot_frame(a, blockIdx.x, f)) return;
+    const FrameCtl *ctl = a.ctl + f;
+    if (ctl->done) return;
+    const int N1 = 1 << a.p1, N2 = 1 << a.p2;
+    const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem;
+    if (ntrunk > a.tmax) return;                  // (the row pass then takes the general loop for this frame)
+    const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * BRF_STRIDE : 0);
+    const double lcorr = a.lcorr, rl = 1.0 / lcorr;
+    cplx *e1 = a.e1tab + (size_t)f * a.tmax * N1, *e2 = a.e2tab + (size_t)f * a.tmax * N2;
+    for (int k = 1; k <= ntrunk; k++) {
+        int plate = n0 + k - 1;
+        plate = plate < 0 ? 0 : (plate >= a.nplates ? a.nplates - 1 : plate);
+        const double db0 = brf[(size_t)plate * BRF_STRIDE + 3];
+        const double dzk = (k == 1) ? ctl->dzb_first : (k == ntrunk ? ctl->dzb_last : lcorr);
+        // A = 0.5 D dzk / lcorr, B = 0.5 db0 dzk / lcorr (the quotient formed as in pmd_trunks)
+        const double na = 0.5 * a.d1slope * dzk, qa = na * rl, A = fma(fma(-lcorr, qa, na), rl, qa);
+        const double nb = 0.5 * db0 * dzk, qb = nb * rl, B = fma(fma(-lcorr, qb, nb), rl, qb);
+        for (int j = threadIdx.x; j < N1; j += blockDim.x)
+            e1[(size_t)(k - 1) * N1 + j] = cexp_neg_turns(fma(A, (double)plx_bitrev((unsigned)j, a.p1), B));
+        for (int i = threadIdx.x; i < N2; i += blockDim.x) {
+            const int k2 = (int)plx_bitrev((unsigned)i, a.p2), m2 = k2 >= (N2 >> 1) ? k2 - N2 : k2;
+            e2[(size_t)(k - 1) * N2 + i] = cexp_neg_turns(A * (double)((long long)N1 * m2));
+        }
+    }
+}
+
 // --------------------------------------------------------------- pass 2: rows ---
 // Second half of the forward transform, the linear operator of the step
 // (lin_step :771-773 / matrix_step :907-933) and the first half of the inverse
@@ -691,6 +752,19 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * BRF_STRIDE : 0);
         const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem; // plate of piece k: n0+k (1-based) :908
         const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last, lcorr = a.lcorr;
+        if (a.e1tab && ntrunk <= a.tmax) {       // trunk phasors from the tables of k_pmd_tab (db1 linear in the frequency index)
+            const int N1 = 1 << a.p1;
+            const cplx *e1 = a.e1tab + (size_t)f * a.tmax * N1 + j0, *e2 = a.e2tab + (size_t)f * a.tmax * N2;
+            for (int el = tid; el < nel; el += nthr) {
+                const int e = row_lane_point(el, N2);
+                const int r = e >> a.p2, i = e & (N2 - 1);
+                const int o = r * TSp + row_phys(i);
+                cplx x = s[o], y = s[o + R * TSp];
+                pmd_trunks_tab(x, y, bt[e], e1 + r, N1, e2 + i, N2, brf, a.nplates, n0, ntrunk, cur);
+                s[o] = x;
+                s[o + R * TSp] = y;
+            }
+        } else
         for (int el = tid; el < nel; el += nthr) {
             const int e = row_lane_point(el, N2);
             const int o = (e >> a.p2) * TSp + row_phys(e & (N2 - 1));
@@ -1335,6 +1409,7 @@ struct plx_ssfm {
     std::vector<FrameCtl> h_ctl;
     int brf_sets = 0;
     size_t lds_col = 0, lds_row = 0;
+    cplx *d_e1 = nullptr, *d_e2 = nullptr;   // per-frame, per-trunk row / column phasors of PMD plans with a linear db1 (k_pmd_tab)
     cplx *d_work = nullptr;                  // working copy of the field with a padded row pitch (fused sweep, 4096-point rows), x then y
     int wpitch = 0;
     unsigned long long *d_slots = nullptr;   // slot barrier of the fused column sweep: [launch parity][frame][tile]
@@ -1381,7 +1456,7 @@ static void free_plan(plx_ssfm *P)
     if (!P) return;
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
-    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active); hipFree(P->d_work);
+    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active); hipFree(P->d_work); hipFree(P->d_e1); hipFree(P->d_e2);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     if (P->ev) hipEventDestroy(P->ev);
     for (hipEvent_t e : P->evpool) hipEventDestroy(e);
@@ -1422,7 +1497,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2;
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0;
     double barrier_timeout_ms = 500.0, group_mib = -1.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -1435,6 +1510,7 @@ struct Tune {
         col_threads = geti("PLX_SSFM_COL_THREADS", -1);
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
+        no_pmd_tab = geti("PLX_SSFM_NO_PMD_TAB", 0);   // PMD plans: one exponential per bin and trunk instead of the phasor tables (A/B, tests)
         wpad = geti("PLX_SSFM_WPAD", -2);         // complex samples added to the working copy's row pitch; -1: no working copy
         if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
         if (const char *e = getenv("PLX_SSFM_GROUP_MIB")) group_mib = atof(e);
@@ -1636,6 +1712,28 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             a.mbox = P->d_mbox;
             a.mbox_stride = mstride;
             a.grab = (int *)(P->d_mbox + (size_t)mstride * (P->fused_grid / tiles_pf));
+        }
+    }
+    // PMD plans: is db1 linear in the signed frequency index (fiber.m:358)?  Then the trunk phases factor into row x column
+    // phasors (SsfmArgs::e1tab) and the row pass does one complex product per bin and trunk instead of an exponential.
+    if (a.pmd && have_db1 && !tune.no_pmd_tab) {
+        const double D = desc->db1[1] * kInv2Pi;       // turns per unit of m (k = 1 <-> m = 1)
+        bool lin = D != 0.0 && N >= 4;
+        for (int c = 0; c < nfc && lin; c++)
+            for (int64_t k = 0; k < N && lin; k++) {
+                const double m = (double)(k < N / 2 ? k : k - N);
+                if (fabs(desc->db1[(size_t)c * N + k] * kInv2Pi - D * m) > 4e-15 * fabs(D) * (double)N) lin = false;
+            }
+        if (lin) {
+            const int tmax = (int)ceil(desc->dzmaxt / a.lcorr) + 2;
+            const size_t n1 = (size_t)F * tmax * N1, n2 = (size_t)F * tmax * N2;
+            if (tmax <= 64 && (n1 + n2) * sizeof(cplx) <= ((size_t)4 << 30)) {       // (bounded: 27 trunks at 100 plates and dzmax = L / 4)
+                if (hipMalloc((void **)&P->d_e1, n1 * sizeof(cplx)) != hipSuccess || hipMalloc((void **)&P->d_e2, n2 * sizeof(cplx)) != hipSuccess) {
+                    free_plan(P);
+                    PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed (trunk phasor tables)");
+                }
+                a.e1tab = P->d_e1; a.e2tab = P->d_e2; a.d1slope = D; a.tmax = tmax;
+            }
         }
     }
     // Optional working copy with a padded row pitch for the fused sweep (single-field frames of 256 x 256 or 256 x 4096
@@ -1848,6 +1946,10 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
 #endif
+                if (a.e1tab) {             // PMD: the step's trunk phasors, once per frame (between the controller and the row pass)
+                    PLX_MARK(3, steps + sidx);
+                    PLX_LAUNCH(k_pmd_tab, dim3(FC / nfc), blk, 0, st, a);
+                }
                 PLX_MARK(1, steps + sidx);
                 launch_row(P, a, FC, st);
                 P->row_launches++;
@@ -1863,6 +1965,7 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
                 if (gx > 256) gx = 256;
                 PLX_LAUNCH(k_rowsum, dim3(gx, (unsigned)nframes), blk, 0, st, a);
             }
+            if (a.e1tab) PLX_LAUNCH(k_pmd_tab, dim3(FC / nfc), blk, 0, st, a);
             PLX_MARK(0, steps + sidx);
             PLX_LAUNCH(k_col_fwd, gcol, bcol, P->lds_col, st, a);
             PLX_MARK(1, steps + sidx);

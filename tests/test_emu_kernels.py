@@ -50,8 +50,13 @@ def _tables(n, nt, fls, nplates, nfc=1):
     return betat, db1
 
 
-def test_emu_matrix_ssfm_batch_with_pmd(emu, oracle):
-    """two frames with their own PMD realisation and launch power advance in lock-step launches"""
+@pytest.mark.parametrize("tables", [True, False])
+def test_emu_matrix_ssfm_batch_with_pmd(emu, oracle, monkeypatch, tables):
+    """two frames with their own PMD realisation and launch power advance in lock-step launches -- with the trunk phasors from
+    the row / column tables of k_pmd_tab (db1 linear in the frequency index: the default) and with one exponential per bin and
+    trunk (PLX_SSFM_NO_PMD_TAB=1, also what a plan with a non-linear db1 takes)"""
+    if not tables:
+        monkeypatch.setenv("PLX_SSFM_NO_PMD_TAB", "1")
     n, nt, nplates, L = 512, 8, 6, 2e4
     fls = [1, 1, 1, 0]
     betat, db1 = _tables(n, nt, fls, nplates)
