@@ -79,6 +79,7 @@ def parse():
     ap.add_argument("--nf", type=float, default=None, help="noise figure [dB] of the in-line amplifiers (default: noiseless)")
     ap.add_argument("--no-overlap", action="store_true", help="run the receiver on the fibre stream (no stream overlap)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-rx-thread", action="store_true", help="enqueue the receiver from the fibre's host thread (A/B)")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame latency measurement after the timed region")
     ap.add_argument("--no-cohmix-line", action="store_true", help="skip the short side measurement with the reference's own front end")
     ap.add_argument("--no-gateway", action="store_true", help="skip the per-call timing of the MEX-shaped gateway tier")
@@ -445,7 +446,38 @@ def main():
         ux, uy = get_batch(i)
         hp.run(ux, uy, noise_sigma=a.noise, noise_seed=1000 * rank + i)
     sync_all()
+    hp.kernel_times()                  # (drop the warm-up's kernel intervals)
     t0 = time.perf_counter()
+    # The receiver of a batch is ENQUEUED by a second host thread (its kernels go to the receiver's stream either way): the
+    # fibre call blocks its host thread until the step loop has ended, and the ~3 ms it takes to enqueue the receiver's dozen
+    # launches would otherwise sit between two fibres with the fibre's stream idle.  (Inline when the receiver shares the
+    # fibre's stream or buffers are restaged.)
+    import queue
+    import threading
+    rxq, rx_fail = None, []
+    if rx_stream is not None and nbuf >= total and not a.no_rx_thread:
+        rxq = queue.Queue()
+
+        def rx_worker():
+            try:
+                torch.cuda.set_device(local)
+                lib.call("plx_set_device", local)
+                while True:
+                    item = rxq.get()
+                    if item is None:
+                        return
+                    i_, ux_, uy_, ready_, e2_ = item
+                    rx_stream.wait_event(ready_)
+                    with torch.cuda.stream(rx_stream):
+                        err_ = hp.receive(ux_, uy_, noise_sigma=a.noise, noise_seed=1000 * rank + i_)
+                        ev.record(e2_, rx_stream.cuda_stream)
+                        errs.append(err_.sum(0))
+                        if a.mc:
+                            resolved.append(hp.errors_resolved(F).sum())
+            except BaseException as exc:       # (reported by the main thread)
+                rx_fail.append(exc)
+        rx_thread = threading.Thread(target=rx_worker, daemon=True)
+        rx_thread.start()
     for i in range(a.warmup, total):
         ux, uy = get_batch(i)
         e0, e1, e2 = ev.create(), ev.create(), ev.create()
@@ -454,28 +486,37 @@ def main():
             hp.set_random_pmd(range((rank * total + i) * F, (rank * total + i + 1) * F))
         hp.fibre(ux, uy)
         ev.record(e1, stream)
-        rs = rx_stream.cuda_stream if rx_stream is not None else stream
-        err = hp.receive(ux, uy, noise_sigma=a.noise, noise_seed=1000 * rank + i, side_stream=rx_stream)
-        # (receive() makes rx_stream wait for the fibre; the Rx interval is measured on the Rx stream)
-        ev.record(e2, rs)
-        if rx_stream is not None:
-            with torch.cuda.stream(rx_stream):
-                errs.append(err.sum(0))
-                if a.mc:   # a blind receiver behind random birefringence: resolve pol swap + pi/2 ambiguity (ex20:160-173)
-                    resolved.append(hp.errors_resolved(F).sum())
+        if rxq is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+            rxq.put((i, ux, uy, ready, e2))
         else:
-            errs.append(err.sum(0))
-            if a.mc:
-                resolved.append(hp.errors_resolved(F).sum())
-        if rx_stream is not None and nbuf < total:
-            buf_free[i % nbuf] = torch.cuda.Event()
-            buf_free[i % nbuf].record(rx_stream)
+            rs = rx_stream.cuda_stream if rx_stream is not None else stream
+            err = hp.receive(ux, uy, noise_sigma=a.noise, noise_seed=1000 * rank + i, side_stream=rx_stream)
+            # (receive() makes rx_stream wait for the fibre; the Rx interval is measured on the Rx stream)
+            ev.record(e2, rs)
+            if rx_stream is not None:
+                with torch.cuda.stream(rx_stream):
+                    errs.append(err.sum(0))
+                    if a.mc:   # a blind receiver behind random birefringence: resolve pol swap + pi/2 ambiguity (ex20:160-173)
+                        resolved.append(hp.errors_resolved(F).sum())
+            else:
+                errs.append(err.sum(0))
+                if a.mc:
+                    resolved.append(hp.errors_resolved(F).sum())
+            if rx_stream is not None and nbuf < total:
+                buf_free[i % nbuf] = torch.cuda.Event()
+                buf_free[i % nbuf].record(rx_stream)
         fib_ms.append((e0, e1)); rx_ms.append((e1, e2))
         rl, ss = hp.ssfm_stats()
         row_launches += rl; sample_steps += ss
-        km, kn = hp.kernel_times()
-        k_ms += km; k_n += kn
         util += np.array(hp.utilisation(), np.int64)
+    k_ms, k_n = hp.kernel_times()      # (all timed steps; the warm-up's intervals were dropped before the loop)
+    if rxq is not None:
+        rxq.put(None)
+        rx_thread.join()
+        if rx_fail:
+            raise rx_fail[0]
     sync_all()
     dt = time.perf_counter() - t0
     for e in errs:

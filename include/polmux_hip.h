@@ -141,6 +141,10 @@ int plx_ssfm_utilisation(plx_ssfm *plan, int64_t *frame_steps, int64_t *slots_li
  * [1] log2 N1, [2] log2 N2 of the four-step split; [3] grid of the fused sweep; [4] column tiles per frame;
  * [5] threads per column workgroup, [6] per row workgroup; [7] 1 = one polarisation per row workgroup.  8 entries. */
 int plx_ssfm_info(plx_ssfm *plan, int32_t *info);
+/* Per-kernel timing of the step loop: with profiling enabled an event is recorded between consecutive launches of
+ * plx_ssfm_propagate_dev; plx_ssfm_kernel_times returns, per kernel class (0 the column sweep that starts a step, 1 the row
+ * pass, 2 k_col_inv, 3 control), the milliseconds and the number of ACTIVE launches accumulated over all propagate calls
+ * since its previous call, and resets them (the intervals of a call are read while the next call runs, or here). */
 int plx_ssfm_profile(plx_ssfm *plan, int enable);
 int plx_ssfm_kernel_times(plx_ssfm *plan, double *ms, int64_t *launches);
 

@@ -1430,9 +1430,12 @@ struct plx_ssfm {
     int64_t slots_launched = 0, slots_listed = 0, frame_steps = 0;   // utilisation accounting of the last propagate
     // optional per-kernel timing of the step loop (plx_ssfm_profile): one event between consecutive launches
     int profile = 0;
-    std::vector<hipEvent_t> evpool;
-    std::vector<int> ev_class, ev_step;      // kernel class / step index of the launch that follows event i
-    double k_ms[4] = {0, 0, 0, 0};
+    // The intervals are read LATER -- while the next call's first launches run, or when the times are asked for: some 160
+    // hipEventElapsedTime calls per propagate would otherwise sit between two calls with the GPU idle (~2 ms per 110 ms).
+    struct ProfRun { std::vector<hipEvent_t> ev; std::vector<int> cls, step; int maxnc = 0; bool fused = false; };
+    std::vector<hipEvent_t> evfree;          // events not in use
+    std::vector<ProfRun> prof_pending;       // finished step loops whose intervals have not been read yet
+    double k_ms[4] = {0, 0, 0, 0};           // accumulated since the last plx_ssfm_kernel_times
     int64_t k_launches[4] = {0, 0, 0, 0};
 };
 
@@ -1459,7 +1462,8 @@ static void free_plan(plx_ssfm *P)
     hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active); hipFree(P->d_work); hipFree(P->d_e1); hipFree(P->d_e2);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     if (P->ev) hipEventDestroy(P->ev);
-    for (hipEvent_t e : P->evpool) hipEventDestroy(e);
+    for (hipEvent_t e : P->evfree) hipEventDestroy(e);
+    for (auto &r : P->prof_pending) for (hipEvent_t e : r.ev) hipEventDestroy(e);
     for (int k = 0; k < 2; k++) {
         if (P->h_brf[k]) hipHostFree(P->h_brf[k]);
         if (P->brf_ev[k]) hipEventDestroy(P->brf_ev[k]);
@@ -1856,6 +1860,28 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
     PLX_LAUNCH(k_row, dim3((unsigned)(N1 / a.R), FC), dim3((unsigned)P->row_threads), P->lds_row, st, a);
 }
 
+// Read the event intervals of the step loops that have finished (see plx_ssfm::ProfRun) into k_ms / k_launches.
+static int resolve_profiles(plx_ssfm *P)
+{
+    for (auto &r : P->prof_pending) {
+        // ACTIVE launches only: the chunked loop also issues launches after every frame has finished (they return at
+        // once).  Step s of the slowest frame is its (s+1)-th; the fused column sweep needs one more round to finish
+        // the last step and write the field out.
+        for (size_t i = 0; i + 1 < r.ev.size(); i++) {
+            const int cls = r.cls[i], step = r.step[i];
+            const bool active = (r.fused && cls == 0) ? step <= r.maxnc : step < r.maxnc;
+            if (!active) continue;
+            float ms = 0;
+            PLX_HIP(hipEventElapsedTime(&ms, r.ev[i], r.ev[i + 1]));
+            P->k_ms[cls] += ms;
+            P->k_launches[cls]++;
+        }
+        for (hipEvent_t e : r.ev) P->evfree.push_back(e);
+    }
+    P->prof_pending.clear();
+    return PLX_OK;
+}
+
 // One GROUP of frames through the whole step loop (fiber.m:518-552).  g0: first frame of the group within the call.
 static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nframes, hipStream_t st)
 {
@@ -1908,17 +1934,14 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
     bool pending = false, aborted = false;
     // profiling: an event in front of every launch of the loop (and one after the last); intervals are attributed to
     // the kernel class that follows the event.  Classes: 0 k_colx16 / k_col_fwd, 1 k_row, 2 k_col_inv, 3 control.
-    size_t nev = 0;
-    P->ev_class.clear(); P->ev_step.clear();
+    plx_ssfm::ProfRun run;
     auto mark = [&](int cls, int step) -> int {
         if (!P->profile) return PLX_OK;
-        if (nev == P->evpool.size()) {
-            hipEvent_t e;
-            PLX_HIP(hipEventCreate(&e));
-            P->evpool.push_back(e);
-        }
-        PLX_HIP(hipEventRecord(P->evpool[nev++], st));
-        P->ev_class.push_back(cls); P->ev_step.push_back(step);
+        hipEvent_t e;
+        if (!P->evfree.empty()) { e = P->evfree.back(); P->evfree.pop_back(); }
+        else PLX_HIP(hipEventCreate(&e));
+        run.ev.push_back(e); run.cls.push_back(cls); run.step.push_back(step);
+        PLX_HIP(hipEventRecord(e, st));
         return PLX_OK;
     };
 #define PLX_MARK(cls, step) do { int rc_ = mark((cls), (step)); if (rc_) return rc_; } while (0)
@@ -1975,6 +1998,10 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
             P->row_launches++;
         }
         PLX_MARK(3, steps + chunk);     // closes the last interval of the chunk (the read-back below lands in class 3)
+        if (steps == 0 && !P->prof_pending.empty()) {      // (the GPU has this call's first chunk to work on meanwhile)
+            const int rc_ = resolve_profiles(P);
+            if (rc_) return rc_;
+        }
         steps += chunk;
         if (pending) {
             PLX_HIP(hipEventSynchronize(P->ev));
@@ -2006,19 +2033,9 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
         if (P->h_ctl[f].ncycle > maxnc) maxnc = P->h_ctl[f].ncycle;
     }
     P->last_group_steps = maxnc + (fused ? 1 : 0);
-    if (P->profile) {
-        // ACTIVE launches only: the chunked loop also issues launches after every frame has finished (they return at
-        // once).  Step s of the slowest frame is its (s+1)-th; the fused column sweep needs one more round to finish
-        // the last step and write the field out.
-        for (size_t i = 0; i + 1 < nev; i++) {
-            const int cls = P->ev_class[i], step = P->ev_step[i];
-            const bool active = (fused && cls == 0) ? step <= maxnc : step < maxnc;
-            if (!active) continue;
-            float ms = 0;
-            PLX_HIP(hipEventElapsedTime(&ms, P->evpool[i], P->evpool[i + 1]));
-            P->k_ms[cls] += ms;
-            P->k_launches[cls]++;
-        }
+    if (!run.ev.empty()) {
+        run.maxnc = maxnc; run.fused = fused;
+        P->prof_pending.push_back(std::move(run));
     }
 #undef PLX_MARK
     return PLX_OK;
@@ -2032,7 +2049,6 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     if (P->a.brf_per_frame && P->brf_sets < nframes)
         PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: fewer birefringence sets than frames");
     P->slots_launched = 0; P->slots_listed = 0; P->row_launches = 0; P->sample_steps = 0; P->frame_steps = 0;
-    for (int k = 0; k < 4; k++) { P->k_ms[k] = 0; P->k_launches[k] = 0; }
     // Frames are independent (fiber.m:518: each has its own step sequence), so a large batch is taken through the span in
     // GROUPS whose fields fit the 256 MiB Infinity Cache: a group's ~50 steps x 2 sweeps then re-read what the previous
     // sweep left on the die instead of streaming the whole batch from HBM twice per step (plan: group_frames).
@@ -2073,7 +2089,9 @@ extern "C" int plx_ssfm_profile(plx_ssfm *P, int enable)
 extern "C" int plx_ssfm_kernel_times(plx_ssfm *P, double *ms, int64_t *launches)
 {
     if (!P || !ms || !launches) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_kernel_times: null argument");
-    for (int k = 0; k < 4; k++) { ms[k] = P->k_ms[k]; launches[k] = P->k_launches[k]; }
+    const int rc = resolve_profiles(P);
+    if (rc) return rc;
+    for (int k = 0; k < 4; k++) { ms[k] = P->k_ms[k]; launches[k] = P->k_launches[k]; P->k_ms[k] = 0; P->k_launches[k] = 0; }
     return PLX_OK;
 }
 

@@ -89,7 +89,6 @@ class HotPath:
         self.lib.call("plx_ssfm_create", C.byref(self.ssfm), C.byref(d))
         self.nplates = nplates
         self._profiling = False
-        self._kms, self._kn = np.zeros(4), np.zeros(4, np.int64)
         if self.pmd:   # Monte-Carlo style: an independent random birefringence draw per frame (fiber.m:274-276)
             self.set_random_pmd(range(self.F))
         # --- Tx (host, once): Run_my_PDM_QPSK.m:101-117 ---
@@ -215,7 +214,6 @@ class HotPath:
         (ampliflat's options.noise, ampliflat.m:123-129: the parity route)."""
         F = ux.shape[0]
         self._rows = self._steps = 0
-        self._kms, self._kn = np.zeros(4), np.zeros(4, np.int64)
         cfg = self.cfg
         namp = 0
         for span in range(cfg.nspans):
@@ -224,11 +222,6 @@ class HotPath:
             self.lib.call("plx_ssfm_stats", self.ssfm, C.byref(rows), C.byref(steps))
             self._rows += rows.value
             self._steps += steps.value
-            if self._profiling:
-                ms, nl = np.zeros(4), np.zeros(4, np.int64)
-                self.lib.call("plx_ssfm_kernel_times", self.ssfm, ms.ctypes.data, nl.ctypes.data)
-                self._kms += ms
-                self._kn += nl
             if span + 1 < cfg.nspans or cfg.rx_amp:   # in-line amplifier (ampliflat.m), stays on the device
                 gain = math.exp(self.alphalin * cfg.length)
                 sig = None
@@ -359,8 +352,12 @@ class HotPath:
         self.lib.call("plx_ssfm_profile", self.ssfm, int(bool(on)))
 
     def kernel_times(self):
-        """(ms[4], active launches[4]) of the last fibre() call: column sweep that starts a step, k_row, k_col_inv, control"""
-        return self._kms.copy(), self._kn.copy()
+        """(ms[4], active launches[4]) accumulated over the fibre() calls since the previous call of this method: column sweep
+        that starts a step, k_row, k_col_inv, control (plx_ssfm_kernel_times: the event intervals are read lazily)"""
+        ms, nl = np.zeros(4), np.zeros(4, np.int64)
+        if self._profiling:
+            self.lib.call("plx_ssfm_kernel_times", self.ssfm, ms.ctypes.data, nl.ctypes.data)
+        return ms, nl
 
     def last_ncycle(self, F):
         """ncycle (fiber.m:431) of each frame of the last propagate call"""
