@@ -15,6 +15,7 @@ ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 worst = 0.0
 bad = 0
 ran = 0
+illc = 0
 for case in range(ncase):
     lg = int(r.integers(8, 14))
     ntl = int(r.choice([3, 4, 5]))
@@ -68,10 +69,25 @@ for case in range(ncase):
             err = np.abs(planes[0] + 1j * planes[1] - ou).max() / np.abs(ou).max()
     except _abi.PolmuxError as e:
         print("refused (%s): %s" % (e, tag)); continue
-    ok = nc.value == onc and err < 1e-9 and abs(fd.value - ofd) <= 1e-12 * abs(ofd)
-    worst = max(worst, err)
+    bar, cond = 1e-9, None
+    if err >= bar:
+        # the step rule can be ill-conditioned ("Conditioning of the step rule": e.g. SPM + channel walk-off without
+        # GVD on a coarse grid): measure the ORACLE's own sensitivity to a 1e-15 input perturbation and scale the bar with it
+        if dual:
+            _, _, _, px2, py2 = oracle.matrix_ssfm(sx * (1 + 1e-15), sy, t["betat"], t["db1"], dzm, dph, gam, t["alphalin"], L, nplates, manakov, fls, db0, th, ep)
+            cond = max(np.abs(px2 - ox).max() / np.abs(ox).max(), np.abs(py2 - oy).max() / max(np.abs(oy).max(), 1e-300))
+        else:
+            _, _, ou2 = oracle.scalar_ssfm(sx * (1 + 1e-15), t["betat"], dzm, dph, gam, t["alphalin"], L, fls)
+            cond = np.abs(ou2 - ou).max() / np.abs(ou).max()
+        bar = max(bar, 100 * cond)
+    ok = nc.value == onc and err < bar and abs(fd.value - ofd) <= 1e-12 * abs(ofd)
+    if cond is None:
+        worst = max(worst, err)
+    else:
+        illc += 1
+        print("ill-conditioned case (%s): error %.3g against the oracle's own 1e-15 sensitivity %.3g: %s" % (tag, err, cond, "accepted" if ok else "REJECTED"))
     ran += 1
     if not ok:
         bad += 1
         print("MISMATCH", tag, "nc", nc.value, onc, "err %.3g" % err, "fd", fd.value, ofd)
-print("%d cases run, worst relative field error %.3g, mismatches %d" % (ran, worst, bad))
+print("%d cases run, worst relative field error %.3g (well-conditioned cases), %d ill-conditioned case(s) judged against the oracle's own sensitivity, mismatches %d" % (ran, worst, illc, bad))

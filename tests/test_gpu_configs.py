@@ -425,3 +425,36 @@ def test_sentinel_landing_of_the_staged_tile_equals_the_ordinary_wait(lib, monke
         for o in res[name]:
             assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]), name
             assert o[2].tolist() == ref[2].tolist() and np.array_equal(o[3], ref[3])
+
+
+def test_campaign_on_a_plan_that_cannot_share_the_gpu_keeps_one_stream(lib):
+    """A 2^20-sample frame takes the whole fused grid, so HotPath.overlap_ok() is False and receive() runs on the fibre's
+    stream.  McCampaign.launch() must then put the EVM, the error resolution and its completion event on that SAME stream (it
+    used to leave them on the receiver stream, which never waited for the fibre's: counts and EVM samples read symbols that
+    were still being written).  The pipelined campaign equals the same realisations computed stage by stage with a device
+    synchronisation after every stage, to the bit."""
+    import torch
+    from polmux_amd import pipeline
+    cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, pavg_mw=1.0, cma_mu=1 / 600)
+    camp = pipeline.McCampaign(cfg, frames_per_call=2, noise_sigma=0.25)
+    hp = camp.hp
+    assert not hp.overlap_ok()
+    idx = [0, 1, 2, 3]
+    h1 = camp.launch(idx[:2])
+    h2 = camp.launch(idx[2:])                      # the second batch is enqueued before the first one is read
+    got, evm = camp.collect(h1 + h2, with_samples=True)
+    want, wevm = [], []
+    for i0 in (0, 2):                              # stage by stage, nothing in flight across a stage
+        ux, uy = hp.make_batch(2)
+        hp.fibre(ux, uy, span_keys=idx[i0:i0 + 2])
+        _sync()
+        hp.receive(ux, uy, camp.sigma, 20260101, None, idx[i0:i0 + 2])
+        _sync()
+        v = hp.evm(2)
+        _sync()
+        e = hp.errors_resolved(2)
+        _sync()
+        want.append(e.cpu().numpy()); wevm.append(v.cpu().numpy())
+    assert got.tolist() == np.concatenate(want).tolist() and sum(got) > 0
+    assert np.array_equal(evm, np.concatenate(wevm))
+    camp.close()
