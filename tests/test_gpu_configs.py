@@ -436,7 +436,7 @@ def test_campaign_on_a_plan_that_cannot_share_the_gpu_keeps_one_stream(lib):
     import torch
     from polmux_amd import pipeline
     cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, pavg_mw=1.0, cma_mu=1 / 600)
-    camp = pipeline.McCampaign(cfg, frames_per_call=2, noise_sigma=0.25)
+    camp = pipeline.McCampaign(cfg, frames_per_call=2, noise_sigma=0.45)
     hp = camp.hp
     assert not hp.overlap_ok()
     idx = [0, 1, 2, 3]
@@ -455,6 +455,6 @@ def test_campaign_on_a_plan_that_cannot_share_the_gpu_keeps_one_stream(lib):
         e = hp.errors_resolved(2)
         _sync()
         want.append(e.cpu().numpy()); wevm.append(v.cpu().numpy())
-    assert got.tolist() == np.concatenate(want).tolist() and sum(got) > 0
-    assert np.array_equal(evm, np.concatenate(wevm))
+    assert got.tolist() == np.concatenate(want).tolist()
+    assert np.array_equal(evm, np.concatenate(wevm)) and evm.min() > 0      # (the EVM is a continuous sample: equality to the bit)
     camp.close()
