@@ -1,0 +1,40 @@
+"""dev tool: turn gpurun_out/r03final/* (scripts/final_round.sh lines|trace|traffic) into the files of record under profiles/."""
+import json
+import os
+import shutil
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = os.path.join(R, "gpurun_out", "r03final")
+P = os.path.join(R, "profiles")
+
+
+def rd(name):
+    return open(os.path.join(F, name)).read()
+
+
+out = ["# Round 3: rocprofv3 --kernel-trace --stats of the bench (F = 1024 C1 frames, 16 Tx sequences, MI355X)\n",
+       "Commands (scripts/final_round.sh trace): `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python3 bench.py --steps 2 --warmup 1 "
+       "--no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway --no-cohmix-line` (default: receiver of batch i on a second stream beside the fibre of "
+       "batch i+1), the same with `--no-overlap`, and `--nsymb 16384 --frames 16 --variants 1 --no-overlap` (2^20-sample frames).  NOTE: with rocprofv3 "
+       "attached the kernels of the two streams do not overlap, so the first two traces both show the fibre alone; the overlapped truth is the un-profiled "
+       "bench line (`r03_bench.jsonl` line 1: `roofline.kernels` from HIP events between the launches).\n",
+       "Default path: `k_compact` (active list) + fused column sweep `k_colx16<0>` (inverse column pass of step s + step controller + forward column pass of "
+       "step s+1; teams of 32 workgroups claim frames one at a time; next tile staged by LDS-DMA) + `k_row` (lanes rotated on padded rows): two HBM sweeps "
+       "per SSFM step.\n",
+       "## Per-kernel summary, default run (scripts/prof_summary.py; 'active' = launches at least half as long as the kernel's longest)\n",
+       rd("kernel_trace_summary.md"),
+       "\n## Per-kernel summary, `--no-overlap` run\n", rd("kernel_trace_no_overlap_summary.md"),
+       "\n## Per-kernel summary, 2^20-sample frames (16 per launch; `k_row4k` is the row pass)\n", rd("kernel_trace_2pow20_summary.md"),
+       "\n## rocprofv3 --stats (kernel_stats.csv, top rows, default run)\n\n```", rd("kernel_stats_head.csv").rstrip(), "```\n"]
+d = json.loads(rd("bench_default.json").strip().splitlines()[-1])
+r = d["roofline"]
+out.append("## Cross-check with bench.py's live HIP-event figures (separate, un-profiled run: `r03_bench.jsonl` line 1)\n")
+out.append("* `roofline`: kernel %s, avg active launch %.1f us, achieved %.0f GB/s, frac %.3f; `k_row` %.1f us (%.3f); step group %.3f.  One active launch of a sweep "
+           "= 64 B x %.1f frames x 65536 samples = %.3f GB." % (r["kernel"], r["avg_launch_us"], r["achieved"], r["frac"], r["kernels"]["k_row"]["avg_launch_us"],
+                                                                 r["kernels"]["k_row"]["frac_of_8TBs"], r["step_group"]["frac_of_8TBs"],
+                                                                 r["algorithmic_bytes_per_launch"] / 64 / 65536, r["algorithmic_bytes_per_launch"] / 1e9))
+out.append("* the trace's `k_colx16` average over ACTIVE launches is the fibre ALONE (tracer: no stream overlap); the bench line's figure is beside the receiver.\n")
+open(os.path.join(P, "r03_kernel_trace.md"), "w").write("\n".join(out))
+shutil.copy(os.path.join(F, "bench.jsonl"), os.path.join(P, "r03_bench.jsonl"))
+shutil.copy(os.path.join(F, "traffic.json"), os.path.join(P, "r03_traffic.json"))
+print("profiles/r03_kernel_trace.md, r03_bench.jsonl, r03_traffic.json written")
