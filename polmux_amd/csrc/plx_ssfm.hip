@@ -61,10 +61,6 @@ struct SsfmArgs {
     // the sweeps in between work here in place, the launch that finishes a frame stores it back into the caller's arrays.
     cplx *wx, *wy;
     int wpitch;                    // complex samples between consecutive rows of the working copy
-    // cx / cy: where the column sweep WRITES and the row pass READS.  The same as wx / wy (sweeps in place), or a second
-    // working copy (PING-PONG: no sweep reads and writes the same lines -- the part streams a copy ~7 % faster than an in-place
-    // sweep, profiles/r03_sweep_modes.txt); the column sweep reads wx / wy, the row pass writes them.
-    cplx *cx, *cy;
     const double *betat_p, *db1_p; // [nfc][N], bit-reversed/transposed order
     const cplx *tpass;             // [N] inter-pass twiddles W_N^(n2*k1), same order
     const cplx *hmul;              // [N] general spectral multiplier replacing exp(-i betat dz) (filter passes), same order
@@ -662,9 +658,8 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     // the field: the caller's arrays (rows N2 apart: the R rows of this workgroup are contiguous), or the plan's working copy
     // with its own row pitch (SsfmArgs::wx).  gofs(e): where element e = (row, point) of this workgroup's rows lives.
     const bool wk = a.wx != nullptr;
-    cplx *const fx = wk ? a.wx : a.ux;                                  // where the rows are WRITTEN
+    cplx *const fx = wk ? a.wx : a.ux;
     cplx *const fy = wk ? a.wy : (a.dual ? a.uy : a.ux);
-    const cplx *const rx = wk ? a.cx : fx, *const ry = wk ? a.cy : fy;      // where they are READ (the column sweep's output)
     const size_t base = wk ? ((size_t)fc << a.p1) * a.wpitch + (size_t)j0 * a.wpitch : (size_t)fc * N + (size_t)j0 * N2;
     const int rowadd = wk ? a.wpitch - N2 : 0;
     auto gofs = [&](int e) -> size_t { return base + e + (size_t)(e >> a.p2) * rowadd; };
@@ -688,8 +683,8 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
         for (int k = 0; k < ROW_CH; k++) {
             const int e = row_lane_point(min(e0 + k * nthr, nel - 1), N2);   // (the lane's point: rotated within blocks of 16, see plx_fft.h)
             tv[k] = a.tpass[rowbase + e];
-            xv[k] = rx[gofs(e)];
-            yv[k] = ry[gofs(e)];
+            xv[k] = fx[gofs(e)];
+            yv[k] = fy[gofs(e)];
         }
 #pragma unroll
         for (int k = 0; k < ROW_CH; k++) { pin(tv[k]); pin(xv[k]); pin(yv[k]); }
@@ -829,9 +824,8 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     const size_t N = (size_t)1 << (a.p1 + a.p2);
     const size_t rowbase = (size_t)blockIdx.x << 12;
     // (grid.z: the polarisation; a.wx: the plan's working copy with its own row pitch, see SsfmArgs)
-    const size_t wofs = ((size_t)fc << a.p1) * a.wpitch + (size_t)blockIdx.x * a.wpitch;
-    cplx *const u = a.wx ? (blockIdx.z ? a.wy : a.wx) + wofs : (blockIdx.z ? a.uy : a.ux) + (size_t)fc * N + rowbase;   // written
-    const cplx *const ur = a.wx ? (blockIdx.z ? a.cy : a.cx) + wofs : u;                                                  // read (the column sweep's output)
+    cplx *const u = a.wx ? (blockIdx.z ? a.wy : a.wx) + ((size_t)fc << a.p1) * a.wpitch + (size_t)blockIdx.x * a.wpitch
+                         : (blockIdx.z ? a.uy : a.ux) + (size_t)fc * N + rowbase;
     const cplx *const tp = a.tpass + rowbase;
 
     const Tw4096 w1{tw};
@@ -841,7 +835,7 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     {
         cplx ta = tp[tid];
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = ur[tid + 256 * k];
+        for (int k = 0; k < 16; k++) x[k] = u[tid + 256 * k];
         // (the row is asked for first: the tables, a few KiB out of the L2, arrive behind it under the same wait)
         {
             const cplx t0 = a.tw2[tid], t1 = a.tw2[tid + 256], t2 = a.tw2[512 + (tid & 3)], t3 = tp[256 * (tid & 15)];
@@ -1378,7 +1372,7 @@ template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a
             if (WORK) {
                 int tq = t;
                 pin(tq);
-                cplx *const wd = (tq < 8 ? a.cx : a.cy) + (size_t)fc * wfs + (size_t)bx * 8 + colt;
+                cplx *const wd = (tq < 8 ? a.wx : a.wy) + (size_t)fc * wfs + (size_t)bx * 8 + colt;
 #pragma unroll
                 for (int k = 0; k < 16; k++) wd[(size_t)(16 * j + k) * wp] = x[k];
             } else {
@@ -1418,7 +1412,6 @@ struct plx_ssfm {
     cplx *d_e1 = nullptr, *d_e2 = nullptr;   // per-frame, per-trunk row / column phasors of PMD plans with a linear db1 (k_pmd_tab)
     cplx *d_work = nullptr;                  // working copy of the field with a padded row pitch (fused sweep, 4096-point rows), x then y
     int wpitch = 0;
-    cplx *d_work2 = nullptr;                 // second working copy (ping-pong sweeps)
     unsigned long long *d_slots = nullptr;   // slot barrier of the fused column sweep: [launch parity][frame][tile]
     unsigned long long *d_mbox = nullptr;    // [teams][frames + 4] mailboxes of the fused column sweep's teams, then the two claim counters
     size_t mbox_bytes = 0;
@@ -1466,7 +1459,7 @@ static void free_plan(plx_ssfm *P)
     if (!P) return;
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
-    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active); hipFree(P->d_work); hipFree(P->d_work2); hipFree(P->d_e1); hipFree(P->d_e2);
+    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active); hipFree(P->d_work); hipFree(P->d_e1); hipFree(P->d_e2);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     if (P->ev) hipEventDestroy(P->ev);
     for (hipEvent_t e : P->evfree) hipEventDestroy(e);
@@ -1508,7 +1501,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0, pingpong = 0;
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0;
     double barrier_timeout_ms = 500.0, group_mib = -1.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -1522,7 +1515,6 @@ struct Tune {
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
         no_pmd_tab = geti("PLX_SSFM_NO_PMD_TAB", 0);   // PMD plans: one exponential per bin and trunk instead of the phasor tables (A/B, tests)
-        pingpong = geti("PLX_SSFM_PINGPONG", 0);   // (with a working copy) the column sweep and the row pass write where the other reads
         wpad = geti("PLX_SSFM_WPAD", -2);         // complex samples added to the working copy's row pitch; -1: no working copy
         if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
         if (const char *e = getenv("PLX_SSFM_GROUP_MIB")) group_mib = atof(e);
@@ -1756,8 +1748,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         if (pad >= 0) {
             P->wpitch = N2 + pad;
             const size_t per_pol = (size_t)F * nfc * N1 * P->wpitch;
-            if (hipMalloc((void **)&P->d_work, 2 * per_pol * sizeof(cplx)) != hipSuccess ||
-                (tune.pingpong && hipMalloc((void **)&P->d_work2, 2 * per_pol * sizeof(cplx)) != hipSuccess)) {
+            if (hipMalloc((void **)&P->d_work, 2 * per_pol * sizeof(cplx)) != hipSuccess) {
                 free_plan(P);
                 PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed (working copy of the field)");
             }
@@ -1908,8 +1899,6 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
         a.wx = P->d_work + (size_t)g0 * nfc * N1 * P->wpitch;
         a.wy = a.wx + per_pol;
         a.wpitch = P->wpitch;
-        a.cx = a.wx; a.cy = a.wy;
-        if (P->d_work2) { a.cx = P->d_work2 + (size_t)g0 * nfc * N1 * P->wpitch; a.cy = a.cx + per_pol; }
     }
     a.nframes = nframes;
     a.active = P->d_active;
