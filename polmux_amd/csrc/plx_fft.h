@@ -297,8 +297,18 @@ struct Tw256of4096 {
     }
 };
 
+// The barrier between two passes of a row transform.  __syncthreads() is a workgroup-scope fence + barrier, and the fence waits
+// for EVERY outstanding memory operation of the wave (s_waitcnt vmcnt(0)) -- also for global loads that were issued early on
+// purpose.  LB: wait for the LDS operations only (the passes exchange data through LDS and nothing else).
+template <bool LB> __device__ __forceinline__ void row_barrier()
+{
+#ifndef PLX_EMU
+    if (LB) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); return; }
+#endif
+    __syncthreads();
+}
 // T = 1<<logT padded rows of M = 1<<logM (M >= 16) points each, row t at s + t*row_pitch(M).
-__device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
+template <bool LB = false> __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
 {
     const int M = 1 << logM, halfM = M >> 1, T = 1 << logT, TSp = row_pitch(M);
     int lm = logM;
@@ -311,7 +321,7 @@ __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const c
             p[0] = cadd(a, c);
             p[hp] = cmul(csub(a, c), tw[j]);
         }
-        __syncthreads();
+        row_barrier<LB>();
         lm--;
     }
     for (; lm >= 6; lm -= 2) { // radix-4 stages with q >= 16
@@ -333,7 +343,7 @@ __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const c
             y3 = cmul(y3, tw3(tw, 3 * k, halfM));
             p[0] = y0; p[qs] = y2; p[2 * qs] = y1; p[3 * qs] = y3;
         }
-        __syncthreads();
+        row_barrier<LB>();
     }
     { // 16-point tail in registers
         const int total = T << (logM - 4);
@@ -347,11 +357,11 @@ __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const c
 #pragma unroll
             for (int k = 0; k < 16; k++) p[k] = x[k];
         }
-        __syncthreads();
+        row_barrier<LB>();
     }
 }
 
-__device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
+template <bool LB = false> __device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
 {
     const int M = 1 << logM, halfM = M >> 1, T = 1 << logT, TSp = row_pitch(M);
     {
@@ -366,7 +376,7 @@ __device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const c
 #pragma unroll
             for (int k = 0; k < 16; k++) p[k] = x[k];
         }
-        __syncthreads();
+        row_barrier<LB>();
     }
     const int lmax = (logM & 1) ? logM - 1 : logM;
     for (int lm = 6; lm <= lmax; lm += 2) {
@@ -387,7 +397,7 @@ __device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const c
             cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
             p[0] = cadd(s0, s2); p[qs] = cadd(s1, s3); p[2 * qs] = csub(s0, s2); p[3 * qs] = csub(s1, s3);
         }
-        __syncthreads();
+        row_barrier<LB>();
     }
     if (logM & 1) {
         const int total = T * halfM, hp = row_phys(halfM);
@@ -398,7 +408,7 @@ __device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const c
             p[0] = cadd(a, c);
             p[hp] = csub(a, c);
         }
-        __syncthreads();
+        row_barrier<LB>();
     }
 }
 
