@@ -297,18 +297,8 @@ struct Tw256of4096 {
     }
 };
 
-// The barrier between two passes of a row transform.  __syncthreads() is a workgroup-scope fence + barrier, and the fence waits
-// for EVERY outstanding memory operation of the wave (s_waitcnt vmcnt(0)) -- also for global loads that were issued early on
-// purpose.  LB: wait for the LDS operations only (the passes exchange data through LDS and nothing else).
-template <bool LB> __device__ __forceinline__ void row_barrier()
-{
-#ifndef PLX_EMU
-    if (LB) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); return; }
-#endif
-    __syncthreads();
-}
 // T = 1<<logT padded rows of M = 1<<logM (M >= 16) points each, row t at s + t*row_pitch(M).
-template <bool LB = false> __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
+__device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
 {
     const int M = 1 << logM, halfM = M >> 1, T = 1 << logT, TSp = row_pitch(M);
     int lm = logM;
@@ -321,7 +311,7 @@ template <bool LB = false> __device__ __forceinline__ void row_fft_dif(cplx *s, 
             p[0] = cadd(a, c);
             p[hp] = cmul(csub(a, c), tw[j]);
         }
-        row_barrier<LB>();
+        __syncthreads();
         lm--;
     }
     for (; lm >= 6; lm -= 2) { // radix-4 stages with q >= 16
@@ -343,7 +333,7 @@ template <bool LB = false> __device__ __forceinline__ void row_fft_dif(cplx *s, 
             y3 = cmul(y3, tw3(tw, 3 * k, halfM));
             p[0] = y0; p[qs] = y2; p[2 * qs] = y1; p[3 * qs] = y3;
         }
-        row_barrier<LB>();
+        __syncthreads();
     }
     { // 16-point tail in registers
         const int total = T << (logM - 4);
@@ -357,11 +347,11 @@ template <bool LB = false> __device__ __forceinline__ void row_fft_dif(cplx *s, 
 #pragma unroll
             for (int k = 0; k < 16; k++) p[k] = x[k];
         }
-        row_barrier<LB>();
+        __syncthreads();
     }
 }
 
-template <bool LB = false> __device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
+__device__ __forceinline__ void row_fft_dit(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
 {
     const int M = 1 << logM, halfM = M >> 1, T = 1 << logT, TSp = row_pitch(M);
     {
@@ -376,7 +366,7 @@ template <bool LB = false> __device__ __forceinline__ void row_fft_dit(cplx *s, 
 #pragma unroll
             for (int k = 0; k < 16; k++) p[k] = x[k];
         }
-        row_barrier<LB>();
+        __syncthreads();
     }
     const int lmax = (logM & 1) ? logM - 1 : logM;
     for (int lm = 6; lm <= lmax; lm += 2) {
@@ -397,7 +387,7 @@ template <bool LB = false> __device__ __forceinline__ void row_fft_dit(cplx *s, 
             cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
             p[0] = cadd(s0, s2); p[qs] = cadd(s1, s3); p[2 * qs] = csub(s0, s2); p[3 * qs] = csub(s1, s3);
         }
-        row_barrier<LB>();
+        __syncthreads();
     }
     if (logM & 1) {
         const int total = T * halfM, hp = row_phys(halfM);
@@ -408,7 +398,7 @@ template <bool LB = false> __device__ __forceinline__ void row_fft_dit(cplx *s, 
             p[0] = cadd(a, c);
             p[hp] = csub(a, c);
         }
-        row_barrier<LB>();
+        __syncthreads();
     }
 }
 

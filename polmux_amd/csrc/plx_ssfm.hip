@@ -795,104 +795,6 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     }
 }
 
-// ------------------------------------------------- pass 2, persistent form for 256-point rows ---
-// The row pass of the headline shape (dual polarisation, no PMD, 256-point rows, the step's exp(-i beta dz)): k_row holds a
-// 17 KiB tile per workgroup, eight workgroups per CU, and a tile's loads are in flight only while its workgroup does nothing
-// else -- load, eleven barrier-separated passes, store: the LDS capacity caps the bytes in flight at ~40 % of the tiles a CU
-// holds (profiles/r03_notes.md, row-pass ablation: the load -> LDS -> store skeleton alone streams at the part's in-place rate,
-// the transforms and the multiplier add 19 % that nothing hides).  Here a workgroup is PERSISTENT: it owns the row pair
-// (blockIdx.x mod 128) of every (gridDim.x / 128)-th listed frame, keeps what depends on the row pair only -- the inter-pass
-// twiddles and beta of its points -- in registers for the whole launch, and requests the NEXT frame's tile into registers
-// before it starts the passes on the current one: every resident workgroup has a tile in flight all the time.
-// The arithmetic (and its order) is k_row's: results are bit-identical.
-#define ROWP_TILES 128          // row pairs of a 256 x 256 frame
-#define ROWP_LDS_EXTRA (ROW_CH * ROW_THREADS * (sizeof(cplx) + sizeof(double)))   // a lane's inter-pass twiddles and beta
-__global__ __launch_bounds__(ROW_THREADS, 3) void k_row256p(SsfmArgs a)
-{
-    PLX_DYN_LDS(lds);
-    if (all_done_or_aborted(a)) return;
-    constexpr int N2 = 256, P2 = 8, R = 2, TSp = N2 + N2 / 16, nthr = ROW_THREADS;
-    const int tid = threadIdx.x;
-    const int rp = blockIdx.x & (ROWP_TILES - 1), stride = gridDim.x / ROWP_TILES;
-    int slot = blockIdx.x / ROWP_TILES;
-    cplx *s = (cplx *)lds;                       // [2 * R][TSp]
-    cplx *tw = s + (size_t)2 * R * TSp;
-    if (tid < N2 / 2) tw[tid] = a.tw2[tid];
-    const size_t N = (size_t)1 << 16;
-    const size_t rowbase = (size_t)rp * R * N2;
-    // the lane's points: offset in the row pair (EO), slot in LDS (LO) -- re-formed where they are used, not kept
-#define EO(k) row_lane_point(tidp + (k) * nthr, N2)
-#define LO(k) ((EO(k) >> P2) * TSp + row_phys(EO(k) & (N2 - 1)))
-    // (kept in LDS, [k][lane]: through the register transforms of the passes they would cost 24 registers, and a third wave per SIMD)
-    cplx *const tkl = tw + N2 / 2;               // [ROW_CH][nthr]
-    double *const btl = (double *)(tkl + ROW_CH * nthr);
-#pragma unroll
-    for (int k = 0; k < ROW_CH; k++) {
-        const int e = row_lane_point(tid + k * nthr, N2);
-        tkl[k * nthr + tid] = a.tpass[rowbase + e];
-        btl[k * nthr + tid] = a.betat_p[rowbase + e];
-    }
-#define tkeep(k) tkl[(k) * nthr + tidp]
-#define btk(k) btl[(k) * nthr + tidp]
-    int f;
-    if (!slot_frame(a, slot, f)) return;
-    const int tidp0 = tid;
-    cplx xv[ROW_CH], yv[ROW_CH];
-    {
-        const size_t base = (size_t)f * N + rowbase;
-#pragma unroll
-        for (int k = 0; k < ROW_CH; k++) { const int tidp = tidp0; xv[k] = a.ux[base + EO(k)]; yv[k] = a.uy[base + EO(k)]; }
-    }
-    int done = a.ctl[f].done;
-    double cur = a.ctl[f].cur;
-    for (;;) {
-        int tidp = tid;
-        pin(tidp);
-        const size_t base = (size_t)f * N + rowbase;
-        // the tile of this iteration goes to LDS ...
-#pragma unroll
-        for (int k = 0; k < ROW_CH; k++) {
-            s[LO(k)] = cmul(xv[k], tkeep(k));
-            s[LO(k) + R * TSp] = cmul(yv[k], tkeep(k));
-        }
-        // ... and the next one is requested: it travels while this one is transformed
-        slot += stride;
-        int fn = -1;
-        if (!slot_frame(a, slot, fn)) fn = -1;
-        const int done_c = done;
-        const double cur_c = cur;
-        if (fn >= 0) {
-            const size_t nb = (size_t)fn * N + rowbase;
-#pragma unroll
-            for (int k = 0; k < ROW_CH; k++) { xv[k] = a.ux[nb + EO(k)]; yv[k] = a.uy[nb + EO(k)]; }
-            done = a.ctl[fn].done;
-            cur = a.ctl[fn].cur;
-        }
-        row_barrier<true>();
-        if (!done_c) {                               // (uniform over the workgroup)
-            int lgm = P2;
-            pin_uniform(lgm);                        // (the passes stay loops, as in k_row: unrolled they cost 60 registers)
-            row_fft_dif<true>(s, lgm, 2, tw, tid, nthr);
-#pragma unroll
-            for (int k = 0; k < ROW_CH; k++) {
-                const cplx h = cexp_neg_turns(btk(k) * cur_c);
-                s[LO(k)] = cmul(h, s[LO(k)]);
-                s[LO(k) + R * TSp] = cmul(h, s[LO(k) + R * TSp]);
-            }
-            row_barrier<true>();
-            row_fft_dit<true>(s, lgm, 2, tw, tid, nthr);
-#pragma unroll
-            for (int k = 0; k < ROW_CH; k++) {
-                a.ux[base + EO(k)] = cmulc(s[LO(k)], tkeep(k));
-                a.uy[base + EO(k)] = cmulc(s[LO(k) + R * TSp], tkeep(k));
-            }
-        }
-        // (a lane reads back and rewrites its OWN four slots: no barrier between this tile's last read and the next one's first write)
-        if (fn < 0) return;
-        f = fn;
-    }
-}
-
 // ------------------------------------------------- pass 2 for 4096-point rows (2^20-sample frames) ---
 // One workgroup = one row of ONE polarisation (no PMD: the polarisations only share the multiplier), every radix level
 // in registers: 4096 = 16 x 16 x 16, thread j holds points j + 256 k, three register levels per direction (lvl2_dif<256>
@@ -1516,7 +1418,6 @@ struct plx_ssfm {
     int fused = 0, fused_grid = 0, tiles_pf = 0;
     int col_threads = 512;         // workgroup size of k_col_fwd / k_col_inv
     int row_threads = ROW_THREADS; // workgroup size of k_row
-    int rowp_stride = 0;           // > 0: k_row256p serves the step's row pass, this many frames abreast (128 workgroups per frame)
     int row_split = 0, rs_threads = 0; // long rows without PMD: one polarisation per workgroup (scalar row pass twice)
     size_t rs_lds = 0;
     int tw_compact = 0;            // 4096-point rows: compact twiddle table in d_tw2, register-blocked row pass k_row4k
@@ -1600,7 +1501,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0, rowp = 0;
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0;
     double barrier_timeout_ms = 500.0, group_mib = -1.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -1613,7 +1514,6 @@ struct Tune {
         col_threads = geti("PLX_SSFM_COL_THREADS", -1);
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
-        rowp = geti("PLX_SSFM_ROWP", 0);               // persistent row pass for 256-point rows (k_row256p)
         no_pmd_tab = geti("PLX_SSFM_NO_PMD_TAB", 0);   // PMD plans: one exponential per bin and trunk instead of the phasor tables (A/B, tests)
         wpad = geti("PLX_SSFM_WPAD", -2);         // complex samples added to the working copy's row pitch; -1: no working copy
         if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
@@ -1786,13 +1686,6 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         free_plan(P);
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
     }
-    if (tune.rowp && a.dual && !a.pmd && nfc == 1 && a.p1 == 8 && a.p2 == 8 && a.R == 2 && P->row_threads == ROW_THREADS && !P->row_split) {
-        int ncu = 256, occ = 0, dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
-        if (allow_lds(k_row256p, P->lds_row + ROWP_LDS_EXTRA) == hipSuccess && (occ = blocks_per_cu(k_row256p, ROW_THREADS, P->lds_row + ROWP_LDS_EXTRA)) > 0)
-            P->rowp_stride = occ * ncu / ROWP_TILES;
-        if (tune.rowp > 1) P->rowp_stride = tune.rowp;   // (experiments: frames abreast)
-    }
     // Fused column sweep (k_colx16): the inverse column pass of step s, the step controller and the forward column
     // pass of step s+1 in ONE launch on a register/LDS-resident tile (2 sweeps over HBM per step instead of 3), for
     // dual-polarisation plans with 256 x (8+8) column tiles.  The tiles of a frame meet at a barrier inside the
@@ -1962,10 +1855,6 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
             if (pol) b.ux = a.uy;
             PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
         }
-        return;
-    }
-    if (P->rowp_stride > 0 && !a.force && !a.hmul && !a.umat && !a.wx && FC >= 2u * (unsigned)P->rowp_stride) {
-        PLX_LAUNCH(k_row256p, dim3((unsigned)(ROWP_TILES * P->rowp_stride)), dim3(ROW_THREADS), P->lds_row + ROWP_LDS_EXTRA, st, a);
         return;
     }
     PLX_LAUNCH(k_row, dim3((unsigned)(N1 / a.R), FC), dim3((unsigned)P->row_threads), P->lds_row, st, a);
