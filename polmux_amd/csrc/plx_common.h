@@ -117,6 +117,28 @@ template <int X> __device__ __forceinline__ double lane_xchg(double v)
 }
 #endif
 
+// The two halves of a wave share a value each of them has computed: a = the copy of lanes 0-31, b = the copy of lanes 32-63,
+// both in every lane (lane i and lane i + 32 are partners).  v_permlane32_swap (gfx950) exchanges the upper half of one
+// register with the lower half of another: from two copies of m it leaves exactly a and b.
+#ifdef PLX_EMU
+__device__ __forceinline__ void half_share(double m, double &a, double &b)
+{
+    const int l = (int)(threadIdx.x & 31u);
+    a = __shfl(m, l, 64);
+    b = __shfl(m, l + 32, 64);
+}
+#else
+__device__ __forceinline__ void half_share(double m, double &a, double &b)
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const unsigned lo = (unsigned)__double2loint(m), hi = (unsigned)__double2hiint(m);
+    const u2 r0 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const u2 r1 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    a = __hiloint2double((int)r1[0], (int)r0[0]);
+    b = __hiloint2double((int)r1[1], (int)r0[1]);
+}
+#endif
+
 // ---- agent-scope (whole-GPU) relaxed atomics for words shared between workgroups INSIDE a launch:
 // global_load/store ... sc1, served by the memory side, never by a possibly stale per-CU L1 / per-XCD
 // L2 line (CDNA guide, Guideline 16: "8-B agent atomics both sides").

@@ -795,6 +795,100 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     }
 }
 
+// ------------------------------------------------- pass 2 for 256-point rows, register form ---
+// The headline shape (dual polarisation, no PMD, 256-point rows, the step's exp(-i beta dz)) with every radix level in
+// registers, as k_row4k does for 4096-point rows: ONE WAVE = one tile of 2 rows x 2 polarisations, 16 lanes per row, lane j
+// of a row holds its points j + 16 k.  Forward: lvl2_dif256 -> one exchange through the padded LDS row -> r16_dif; the
+// multiplier on the 16 bins the lane then holds (bit-reversed order, where the tables are); the inverse mirrors it.  Two LDS
+// exchanges per transform pair end (4 x 16 ds_write_b128 + 4 x 16 ds_read_b128 per lane and tile) where k_row's eleven passes make 64 + 96 per
+// lane on half as many points, no workgroup barrier at all (a one-wave workgroup only waits for its own LDS operations), and
+// the butterflies are k_row's, stage by stage.  Inter-pass twiddles as in k_row4k: tpass[j + 16 k] = tpass[j] * tpass[16 k],
+// a lane reads one entry and the row's sixteen lanes share sixteen (bk).
+#define ROWR_THREADS 64
+#define ROWR_LDS ((4 * 272 + 128 + 32) * sizeof(cplx))
+#ifdef PLX_EMU
+#define ROWR_SYNC() __syncthreads()
+#else
+#define ROWR_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+__global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r(SsfmArgs a)
+{
+    PLX_DYN_LDS(lds);
+    if (all_done_or_aborted(a)) return;
+    const int tid = threadIdx.x;
+    int f;
+    if (!slot_frame(a, blockIdx.y, f)) return;
+    const FrameCtl *ctl = a.ctl + f;
+    if (ctl->done) return;
+    cplx *const s = (cplx *)lds + (tid >> 4) * 272;      // this lane group's padded row: physical(p) = p + (p >> 4)
+    cplx *const tw = (cplx *)lds + 4 * 272;              // W_256^k, k < 128
+    cplx *const bk = tw + 128 + 16 * ((tid >> 4) & 1);   // tpass[row][16 k], k < 16
+    const int j = tid & 15, r = (tid >> 4) & 1;
+    const size_t N = (size_t)1 << 16;
+    const size_t rowbase = ((size_t)blockIdx.x * 2 + r) << 8;
+    cplx *const u = (tid >= 32 ? a.uy : a.ux) + (size_t)f * N + rowbase;
+    const cplx *const tp = a.tpass + rowbase;
+    cplx x[16];
+    {
+        const cplx ta = tp[j];
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = u[j + 16 * k];
+        {
+            const cplx t0 = a.tw2[tid], t1 = a.tw2[tid + 64], t3 = tp[16 * j];
+            tw[tid] = t0; tw[tid + 64] = t1;
+            if (tid < 32) bk[j] = t3;
+        }
+        ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = cmul(x[k], cmul(ta, bk[k]));
+    }
+    sched_fence();
+    lvl2_dif256(x, j, tw);
+    sched_fence();
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[row_phys(j + 16 * k)] = x[k];
+    ROWR_SYNC();
+    // the multiplier is the same for the two polarisations of a bin, which sit in lanes i and i + 32: the lower half of the
+    // wave forms it for the lane's bins 0-7, the upper half for bins 8-15, and they swap (half_share)
+    double btv[8];
+    {
+        const double *bt = a.betat_p + rowbase + 16 * j + (tid >= 32 ? 8 : 0);
+#pragma unroll
+        for (int k = 0; k < 8; k++) btv[k] = bt[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = s[17 * j + k];               // row_phys(16 j + k)
+    r16_dif(x);
+    sched_fence();
+    {
+        const double cur = ctl->cur;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const cplx h = cexp_neg_turns(btv[k] * cur);
+            cplx ha, hb;
+            half_share(h.x, ha.x, hb.x);
+            half_share(h.y, ha.y, hb.y);
+            x[k] = cmul(ha, x[k]);
+            x[k + 8] = cmul(hb, x[k + 8]);
+            sched_fence();
+        }
+    }
+    sched_fence();
+    r16_dit(x);
+    sched_fence();
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[17 * j + k] = x[k];
+    ROWR_SYNC();
+    const cplx tb = tp[j];
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = s[row_phys(j + 16 * k)];
+    sched_fence();
+    lvl2_dit256(x, j, tw);
+    sched_fence();
+#pragma unroll
+    for (int k = 0; k < 16; k++) u[j + 16 * k] = cmulc(x[k], cmul(tb, bk[k]));
+}
+
 // ------------------------------------------------- pass 2 for 4096-point rows (2^20-sample frames) ---
 // One workgroup = one row of ONE polarisation (no PMD: the polarisations only share the multiplier), every radix level
 // in registers: 4096 = 16 x 16 x 16, thread j holds points j + 256 k, three register levels per direction (lvl2_dif<256>
@@ -1418,6 +1512,7 @@ struct plx_ssfm {
     int fused = 0, fused_grid = 0, tiles_pf = 0;
     int col_threads = 512;         // workgroup size of k_col_fwd / k_col_inv
     int row_threads = ROW_THREADS; // workgroup size of k_row
+    int rowr = 0;                  // k_row256r serves the step's row pass
     int row_split = 0, rs_threads = 0; // long rows without PMD: one polarisation per workgroup (scalar row pass twice)
     size_t rs_lds = 0;
     int tw_compact = 0;            // 4096-point rows: compact twiddle table in d_tw2, register-blocked row pass k_row4k
@@ -1501,7 +1596,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0;
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0, rowr = 0;
     double barrier_timeout_ms = 500.0, group_mib = -1.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -1514,6 +1609,7 @@ struct Tune {
         col_threads = geti("PLX_SSFM_COL_THREADS", -1);
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
+        rowr = geti("PLX_SSFM_ROWR", 1);               // 0: the LDS-resident k_row also where the register form k_row256r applies (A/B, tests)
         no_pmd_tab = geti("PLX_SSFM_NO_PMD_TAB", 0);   // PMD plans: one exponential per bin and trunk instead of the phasor tables (A/B, tests)
         wpad = geti("PLX_SSFM_WPAD", -2);         // complex samples added to the working copy's row pitch; -1: no working copy
         if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
@@ -1686,6 +1782,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         free_plan(P);
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
     }
+    if (tune.rowr && a.dual && !a.pmd && nfc == 1 && a.p1 == 8 && a.p2 == 8 && !P->row_split && allow_lds(k_row256r, ROWR_LDS) == hipSuccess) P->rowr = 1;
     // Fused column sweep (k_colx16): the inverse column pass of step s, the step controller and the forward column
     // pass of step s+1 in ONE launch on a register/LDS-resident tile (2 sweeps over HBM per step instead of 3), for
     // dual-polarisation plans with 256 x (8+8) column tiles.  The tiles of a frame meet at a barrier inside the
@@ -1855,6 +1952,10 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
             if (pol) b.ux = a.uy;
             PLX_LAUNCH(k_row, gs, bs, P->rs_lds, st, b);
         }
+        return;
+    }
+    if (P->rowr && !a.force && !a.hmul && !a.umat && !a.wx) {
+        PLX_LAUNCH(k_row256r, dim3(128u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
         return;
     }
     PLX_LAUNCH(k_row, dim3((unsigned)(N1 / a.R), FC), dim3((unsigned)P->row_threads), P->lds_row, st, a);

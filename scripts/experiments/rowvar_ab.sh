@@ -1,10 +1,10 @@
 #!/bin/bash
-# dev experiment: persistent row pass (k_row256p, PLX_SSFM_ROWP=1) against k_row; LIBV: which build of the library
+# dev experiment: persistent row pass (k_row256p, PLX_SSFM_ROWR=1) against k_row; LIBV: which build of the library
 mkdir -p gpurun_out/r03ev
 for rep in 1 2; do
 for cfg in ${ROWP_CFGS:-"base:0" "base:1" "rowp2:1"}; do
 set -- ${cfg%%:*} ${cfg##*:}
-ABN=$1 PLX_SSFM_ROWP=$2 timeout -k 10 200 python3 - <<'PY'
+ABN=$1 PLX_SSFM_ROWR=$2 timeout -k 10 200 python3 - <<'PY'
 import os, sys, time
 sys.path.insert(0, os.getcwd())
 import torch, numpy as np
@@ -24,7 +24,7 @@ for r in range(3):
     torch.cuda.synchronize(); t.append((time.perf_counter() - t0) * 1e3)
     if r == 0: chk = float(torch.view_as_real(ux).double().abs().sum().item()), float(torch.view_as_real(uy)[5].double().abs().sum().item())
 ms, k = hp.kernel_times()
-print("%-5s ROWP=%s fibre %.2f ms  col %.1f us  row %.1f us (x%d)  checksum %.17g %.17g" % (n, os.environ["PLX_SSFM_ROWP"], min(t), ms[0] / max(k[0], 1) * 1e3, ms[1] / max(k[1], 1) * 1e3, k[1], chk[0], chk[1]), flush=True)
+print("%-5s ROWR=%s fibre %.2f ms  col %.1f us  row %.1f us (x%d)  checksum %.17g %.17g" % (n, os.environ["PLX_SSFM_ROWR"], min(t), ms[0] / max(k[0], 1) * 1e3, ms[1] / max(k[1], 1) * 1e3, k[1], chk[0], chk[1]), flush=True)
 hp.close()
 PY
 done

@@ -341,6 +341,38 @@ def test_emu_sweep_variants(emu, oracle, monkeypatch):
             assert np.abs(gy[f] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
 
 
+def test_emu_register_form_row_pass(emu, oracle, monkeypatch):
+    """256 x 256 frames without PMD take the register form of the row pass (k_row256r: one wave per 2 rows x 2 polarisations,
+    the multiplier shared between the wave's halves); PLX_SSFM_ROWR=0 keeps the LDS-resident k_row.  Both against the oracle,
+    and against each other (they differ by the rounding of the inter-pass twiddles only)."""
+    n, nt, L = 65536, 16, 1.1e3
+    fls = [1, 0, 1, 0]
+    betat, db1 = _tables(n, nt, fls, 1)
+    fields = [_qpsk_field(n, nt, p)[:2] for p in (4.0, 9.0)]
+    ref = [oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0]) for f in fields]
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PLX_SSFM_ROWR", mode)
+        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=2)
+        plan = C.c_void_p()
+        emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+        monkeypatch.delenv("PLX_SSFM_ROWR")
+        ux = _il(np.stack([f[0] for f in fields])); uy = _il(np.stack([f[1] for f in fields]))
+        emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 2, None)
+        ncyc = np.zeros(2, np.int32)
+        emu.call("plx_ssfm_results", plan, 2, None, _vp(ncyc))
+        emu.call("plx_ssfm_destroy", plan)
+        gx = ux.view(np.complex128).reshape(2, n); gy = uy.view(np.complex128).reshape(2, n)
+        for f in range(2):
+            rc, ofd, onc, ox, oy = ref[f]
+            assert ncyc[f] == onc and onc >= 3
+            assert np.abs(gx[f] - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
+            assert np.abs(gy[f] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
+        got[mode] = (gx.copy(), gy.copy())
+    assert np.abs(got["1"][0] - got["0"][0]).max() < 1e-12 * np.abs(got["0"][0]).max()
+    assert not np.array_equal(got["1"][0], got["0"][0])      # (the switch really selects another kernel)
+
+
 def test_emu_fused_sweep_exact_nonlinear_step(emu, oracle, monkeypatch):
     """The fused sweep's rare path on a one-CU device (one team walks both frames): the '--s-' exact single step
     (fiber.m:172-174: nonlinear phases of radians, so the Kerr step takes the full-range sincos through the exchange buffer)
