@@ -139,6 +139,30 @@ __device__ __forceinline__ void half_share(double m, double &a, double &b)
 }
 #endif
 
+// Lanes i and i + 32 trade halves of a register pair: on return v0 holds (own v0 | partner's v0 ... ) as v_permlane32_swap
+// defines it -- lanes 0-31 keep v0 and receive the upper half's v0 in v1, lanes 32-63 keep v1 and receive the lower half's v1
+// in v0.  Applied twice it is the identity.  (k_row256r with PMD: lane i holds ux, lane i + 32 uy of the same sixteen bins;
+// after the trade every lane holds both polarisations of eight of them.)
+#ifdef PLX_EMU
+__device__ __forceinline__ void half_trade(double &v0, double &v1)
+{
+    const int l = (int)(threadIdx.x & 31u);
+    const bool lower = (threadIdx.x & 32u) == 0;
+    const double a = __shfl(v1, l, 64), b = __shfl(v0, l + 32, 64);
+    const double n0 = lower ? v0 : a, n1 = lower ? b : v1;
+    v0 = n0; v1 = n1;
+}
+#else
+__device__ __forceinline__ void half_trade(double &v0, double &v1)
+{
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const u2 rl = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v0), (unsigned)__double2loint(v1), false, false);
+    const u2 rh = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v0), (unsigned)__double2hiint(v1), false, false);
+    v0 = __hiloint2double((int)rh[0], (int)rl[0]);
+    v1 = __hiloint2double((int)rh[1], (int)rl[1]);
+}
+#endif
+
 // ---- agent-scope (whole-GPU) relaxed atomics for words shared between workgroups INSIDE a launch:
 // global_load/store ... sc1, served by the memory side, never by a possibly stale per-CU L1 / per-XCD
 // L2 line (CDNA guide, Guideline 16: "8-B agent atomics both sides").

@@ -811,7 +811,10 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 #else
 #define ROWR_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #endif
-__global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r(SsfmArgs a)
+// PMD: the waveplate trunks of matrix_step (fiber.m:907-933) need both polarisations of a bin in one lane: the halves of the
+// wave trade (half_trade) so that every lane holds ux and uy of eight bins, run pmd_trunks / pmd_trunks_tab on them -- the
+// arithmetic of k_row's PMD branch, bin by bin -- and trade back.
+template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
@@ -860,7 +863,50 @@ __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r(SsfmArgs a)
     for (int k = 0; k < 16; k++) x[k] = s[17 * j + k];               // row_phys(16 j + k)
     r16_dif(x);
     sched_fence();
-    {
+    if (PMD) {
+        const double cur = ctl->cur;
+        const int ib = 16 * j + (tid >= 32 ? 8 : 0);            // the first of this lane's eight bins within the row
+        const size_t rowf = (size_t)blockIdx.x * 2 + r;
+        const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * BRF_STRIDE : 0);
+        const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { half_trade(x[k].x, x[k + 8].x); half_trade(x[k].y, x[k + 8].y); }   // x[k] = ux, x[k + 8] = uy of bin ib + k
+        if (a.e1tab && ntrunk <= a.tmax) {
+            const cplx *e1 = a.e1tab + (size_t)f * a.tmax * 256 + rowf, *e2 = a.e2tab + (size_t)f * a.tmax * 256 + ib;
+            // (pmd_trunks_tab with the trunk loop outside the bins: a trunk's plate and row phasor are fetched once)
+            for (int t = 0; t < ntrunk; t++) {
+                int plate = n0 + t;
+                plate = plate < 0 ? 0 : (plate >= a.nplates ? a.nplates - 1 : plate);
+                const double *m = brf + (size_t)plate * BRF_STRIDE;
+                const double s11 = m[0];
+                const cplx s12 = make_double2(m[1], m[2]);
+                const cplx e1v = e1[(size_t)t * 256];
+                const cplx *e2t = e2 + (size_t)t * 256;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const cplx e = cmul(e1v, e2t[k]);
+                    const cplx u = x[k], v = x[k + 8];
+                    const cplx sx = cadd(cscale(u, s11), cmul(s12, v));
+                    const cplx sy = csub(cmulc(u, s12), cscale(v, s11));
+                    x[k] = make_double2(e.x * u.x - e.y * sx.y, e.x * u.y + e.y * sx.x);
+                    x[k + 8] = make_double2(e.x * v.x - e.y * sy.y, e.x * v.y + e.y * sy.x);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const cplx h = cexp_neg_turns(btv[k] * cur);
+                x[k] = cmul(h, x[k]);
+                x[k + 8] = cmul(h, x[k + 8]);
+                sched_fence();
+            }
+        } else {
+            const double *d1 = a.db1_p + rowbase + ib;
+            const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last;
+            for (int k = 0; k < 8; k++) pmd_trunks(x[k], x[k + 8], btv[k], d1[k], brf, a.nplates, n0, ntrunk, dzb_first, dzb_last, a.lcorr, cur);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { half_trade(x[k].x, x[k + 8].x); half_trade(x[k].y, x[k + 8].y); }
+    } else {
         const double cur = ctl->cur;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -901,6 +947,21 @@ __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r(SsfmArgs a)
 // tpass[tid + 256 k] = tpass[tid] * tpass[256 k]: a thread reads ONE entry and the workgroup shares sixteen (bk, in LDS)
 // instead of 16 entries per thread at either end of the kernel -- 128 KiB less through the L2 per 64-KiB row, for two more
 // complex products per point.
+// The two MIDDLE exchanges (level 2 <-> level 3) stay inside a block of 256 points = 16 consecutive threads = one wave: they
+// wait for the wave's own LDS operations only (ROWR_SYNC), the workgroup meets at the two outer exchanges.  Level 2's twiddles
+// W_256^e come from a copy of their own, t8[e + (e >> 2)] (e < 128): its lanes ask for e = 4 j2, 8 j2, 12 j2 (+ 16 r1 ...),
+// which in the compact W_4096 table are strides of 16, 32 and 48 entries -- every lane of a 16-lane group on the same banks
+// (41 % of the kernel's LDS cycles were bank conflicts, profiles/r03_pmc_2pow20.txt); the values are the same table entries.
+struct Tw256pad {
+    const cplx *t;
+    __device__ __forceinline__ cplx operator()(int e) const
+    {
+        const int i = e & 127;
+        const cplx w = t[i + (i >> 2)];
+        const bool neg = e >= 128;
+        return make_double2(neg ? -w.x : w.x, neg ? -w.y : w.y);
+    }
+};
 __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
@@ -915,6 +976,7 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     cplx *s = (cplx *)lds;                       // [4352] padded row: physical(p) = p + (p >> 4)
     cplx *tw = s + 4352;                         // W_4096^{4k}, k < 512, then W_4096^0..3
     cplx *bk = tw + 516;                         // tpass[256 k], k < 16
+    cplx *t8 = bk + 16;                          // W_256^e at e + (e >> 2), e < 128
     const size_t N = (size_t)1 << (a.p1 + a.p2);
     const size_t rowbase = (size_t)blockIdx.x << 12;
     // (grid.z: the polarisation; a.wx: the plan's working copy with its own row pitch, see SsfmArgs)
@@ -923,7 +985,7 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     const cplx *const tp = a.tpass + rowbase;
 
     const Tw4096 w1{tw};
-    const Tw256of4096 w2{tw};
+    const Tw256pad w2{t8};
     const int b = tid >> 4, j2 = tid & 15;       // level 2: block b of 256 points, point j2 + 16 k of it
     cplx x[16];
     {
@@ -932,10 +994,11 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
         for (int k = 0; k < 16; k++) x[k] = u[tid + 256 * k];
         // (the row is asked for first: the tables, a few KiB out of the L2, arrive behind it under the same wait)
         {
-            const cplx t0 = a.tw2[tid], t1 = a.tw2[tid + 256], t2 = a.tw2[512 + (tid & 3)], t3 = tp[256 * (tid & 15)];
+            const cplx t0 = a.tw2[tid], t1 = a.tw2[tid + 256], t2 = a.tw2[512 + (tid & 3)], t3 = tp[256 * (tid & 15)], t4 = a.tw2[4 * (tid & 127)];
             tw[tid] = t0; tw[tid + 256] = t1;
             if (tid < 4) tw[512 + tid] = t2;
             if (tid < 16) bk[tid] = t3;
+            if (tid < 128) t8[tid + (tid >> 2)] = t4;
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) pin(x[k]);
@@ -953,7 +1016,7 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     lvl2_dif<16>(x, j2, w2);                     // (written back where this thread read it: no barrier in between)
 #pragma unroll
     for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
-    __syncthreads();
+    ROWR_SYNC();                                 // (the block's sixteen threads are lanes of one wave)
     // the step's multiplier at the 16 bins this thread holds (lin_step :771-773 / matrix_step with matR = I): the phases are
     // asked for HERE, one exchange and one register level ahead of their use (16 more registers fit beside r16_dif)
     double btv[16];
@@ -981,7 +1044,7 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     r16_dit(x);
 #pragma unroll
     for (int k = 0; k < 16; k++) s[17 * tid + k] = x[k];
-    __syncthreads();
+    ROWR_SYNC();
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
     lvl2_dit<16>(x, j2, w2);
@@ -1691,7 +1754,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     if (a.dual && (N2 >= 2048 && !tune.no_row_split)) {   // measured: 2^20 frames 74 -> 66 ms; at N2 = 1024 it loses (47 -> 52)
         P->row_split = 1;
         P->rs_threads = N2 / 8 < ROW_THREADS ? ROW_THREADS : (N2 / 8 > 1024 ? 1024 : N2 / 8);
-        P->rs_lds = ((size_t)(N2 + N2 / 16) + (P->tw_compact ? N2 / 8 + 4 + 16 : N2 / 2)) * sizeof(cplx);   // (+16: k_row4k's bk)
+        P->rs_lds = ((size_t)(N2 + N2 / 16) + (P->tw_compact ? N2 / 8 + 4 + 16 + 160 : N2 / 2)) * sizeof(cplx);   // (+16: k_row4k's bk, +160: its padded W_256 table)
     }
     if (P->tw_compact && (!P->row_split || a.pmd)) {
         free_plan(P);
@@ -1782,7 +1845,8 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         free_plan(P);
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
     }
-    if (tune.rowr && a.dual && !a.pmd && nfc == 1 && a.p1 == 8 && a.p2 == 8 && !P->row_split && allow_lds(k_row256r, ROWR_LDS) == hipSuccess) P->rowr = 1;
+    if (tune.rowr && a.dual && nfc == 1 && a.p1 == 8 && a.p2 == 8 && !P->row_split &&
+        (a.pmd ? allow_lds(k_row256r<true>, ROWR_LDS) : allow_lds(k_row256r<false>, ROWR_LDS)) == hipSuccess) P->rowr = 1;
     // Fused column sweep (k_colx16): the inverse column pass of step s, the step controller and the forward column
     // pass of step s+1 in ONE launch on a register/LDS-resident tile (2 sweeps over HBM per step instead of 3), for
     // dual-polarisation plans with 256 x (8+8) column tiles.  The tiles of a frame meet at a barrier inside the
@@ -1955,7 +2019,8 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         return;
     }
     if (P->rowr && !a.force && !a.hmul && !a.umat && !a.wx) {
-        PLX_LAUNCH(k_row256r, dim3(128u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
+        if (a.pmd) PLX_LAUNCH(k_row256r<true>, dim3(128u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
+        else PLX_LAUNCH(k_row256r<false>, dim3(128u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
         return;
     }
     PLX_LAUNCH(k_row, dim3((unsigned)(N1 / a.R), FC), dim3((unsigned)P->row_threads), P->lds_row, st, a);

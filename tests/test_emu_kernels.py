@@ -373,6 +373,43 @@ def test_emu_register_form_row_pass(emu, oracle, monkeypatch):
     assert not np.array_equal(got["1"][0], got["0"][0])      # (the switch really selects another kernel)
 
 
+@pytest.mark.parametrize("tables", [True])      # (False = one exponential per bin and trunk: on the GPU, test_register_form_row_pass_with_pmd_vs_oracle_three_ways)
+def test_emu_register_form_row_pass_with_pmd(emu, oracle, monkeypatch, tables):
+    """k_row256r<PMD>: the wave's halves trade so that a lane holds both polarisations of eight bins, then the waveplate trunks
+    of matrix_step (fiber.m:907-933) with the phasor tables of k_pmd_tab or one exponential per bin and trunk
+    (PLX_SSFM_NO_PMD_TAB=1).  256 x 256 frame with its own waveplates, against the oracle and against k_row's PMD branch."""
+    if not tables:
+        monkeypatch.setenv("PLX_SSFM_NO_PMD_TAB", "1")
+    n, nt, nplates, L = 65536, 16, 5, 1.3e3
+    fls = [1, 1, 1, 0]
+    betat, db1 = _tables(n, nt, fls, nplates)
+    r = np.random.default_rng(11)
+    brf = (r.random(nplates) * 2 * np.pi - np.pi, r.random(nplates) * np.pi - np.pi / 2, 0.5 * np.arcsin(r.random(nplates) * 2 - 1))
+    fx, fy = _qpsk_field(n, nt, 7.0)[:2]
+    rc, ofd, onc, ox, oy = oracle.matrix_ssfm(fx, fy, betat, db1, 5e2, 5e-3, [1.3e-6], 4.6e-5, L, nplates, 0, fls, *brf)
+    assert rc == 0 and onc >= 3
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PLX_SSFM_ROWR", mode)
+        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 5e2, 5e-3, betat, db1, nplates=nplates, frames=1)
+        plan = C.c_void_p()
+        emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+        monkeypatch.delenv("PLX_SSFM_ROWR")
+        emu.call("plx_ssfm_set_birefringence", plan, _vp(brf[0]), _vp(brf[1]), _vp(brf[2]), 1)
+        ux = _il(fx[None]); uy = _il(fy[None])
+        emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 1, None)
+        ncyc = np.zeros(1, np.int32)
+        emu.call("plx_ssfm_results", plan, 1, None, _vp(ncyc))
+        emu.call("plx_ssfm_destroy", plan)
+        gx = ux.view(np.complex128).reshape(n); gy = uy.view(np.complex128).reshape(n)
+        assert ncyc[0] == onc
+        assert np.abs(gx - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
+        assert np.abs(gy - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
+        got[mode] = (gx.copy(), gy.copy())
+    assert np.abs(got["1"][1] - got["0"][1]).max() < 1e-12 * np.abs(got["0"][1]).max()
+    assert not np.array_equal(got["1"][0], got["0"][0])      # (the switch really selects another kernel)
+
+
 def test_emu_fused_sweep_exact_nonlinear_step(emu, oracle, monkeypatch):
     """The fused sweep's rare path on a one-CU device (one team walks both frames): the '--s-' exact single step
     (fiber.m:172-174: nonlinear phases of radians, so the Kerr step takes the full-range sincos through the exchange buffer)

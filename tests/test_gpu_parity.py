@@ -139,6 +139,43 @@ def test_scalar_ssfm_gateway_vs_oracle(lib, oracle, flag, nfc):
         np.testing.assert_allclose(ur + 1j * ui, ref, rtol=1e-11, atol=1e-13)
 
 
+def test_register_form_row_pass_with_pmd_vs_oracle_three_ways(lib, oracle, monkeypatch):
+    """A 256 x 256 'gps-' frame (10 waveplates) takes the register form of the row pass with the waveplate trunks on traded
+    wave halves (k_row256r<PMD>): with the trunk phasor tables (default), with one exponential per bin and trunk
+    (PLX_SSFM_NO_PMD_TAB=1: what a non-linear db1 takes), and on the LDS-resident k_row (PLX_SSFM_ROWR=0) -- each against the
+    oracle (fiber.m:907-933), step counts equal, and the three fields within rounding of each other."""
+    import torch
+    c = _fibre_case(1024, 64, "gps-", 6.0, nplates=10, dgd=0.25)
+    db0, th, ep = _brf(10, 21)
+    rc, ofd, onc, ox, oy = oracle.matrix_ssfm(c["ux"], c["uy"], c["t"]["betat"], c["t"]["db1"], c["dzm"], c["dph"], c["t"]["gam"],
+                                              c["t"]["alphalin"], c["length"], c["nplates"], False, c["fls"], db0, th, ep)
+    assert rc == 0 and onc > 10
+    st = torch.cuda.current_stream().cuda_stream
+    got = {}
+    for name, env in (("tab", {}), ("exp", {"PLX_SSFM_NO_PMD_TAB": "1"}), ("ldsrow", {"PLX_SSFM_ROWR": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        plan = C.c_void_p()
+        lib.call("plx_ssfm_create", C.byref(plan), C.byref(_desc(c)))
+        for k in env:
+            monkeypatch.delenv(k)
+        lib.call("plx_ssfm_set_birefringence", plan, _vp(db0), _vp(th), _vp(ep), 1)
+        ux, uy = _dev(c["ux"][:, 0][None]), _dev(c["uy"][:, 0][None])
+        lib.call("plx_ssfm_propagate_dev", plan, ux.data_ptr(), uy.data_ptr(), 1, st)
+        _sync()
+        ncyc = np.zeros(1, np.int32)
+        lib.call("plx_ssfm_results", plan, 1, None, _vp(ncyc))
+        lib.call("plx_ssfm_destroy", plan)
+        gx, gy = ux.cpu().numpy()[0], uy.cpu().numpy()[0]
+        assert ncyc[0] == onc, name
+        assert np.abs(gx - ox[:, 0]).max() <= FIELD_RTOL * np.abs(ox).max(), name
+        assert np.abs(gy - oy[:, 0]).max() <= FIELD_RTOL * np.abs(oy).max(), name
+        got[name] = (gx, gy)
+    for name in ("exp", "ldsrow"):
+        assert np.abs(got[name][0] - got["tab"][0]).max() < 1e-11 * np.abs(ox).max()
+    assert not np.array_equal(got["ldsrow"][0], got["tab"][0])      # (the switch really selects another kernel)
+
+
 def test_batch_frames_keep_their_own_step_sequence(lib, oracle):
     """Frames of a batch (own launch power, own PMD draw) each follow the reference's step sequence."""
     import torch
