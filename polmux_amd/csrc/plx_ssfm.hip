@@ -819,8 +819,10 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x;
+    const int slot = blockIdx.y / a.nfc, c = blockIdx.y - slot * a.nfc;       // (channels of a frame: 'sepfields' WDM)
     int f;
-    if (!slot_frame(a, blockIdx.y, f)) return;
+    if (!slot_frame(a, slot, f)) return;
+    const int fc = f * a.nfc + c;
     const FrameCtl *ctl = a.ctl + f;
     if (ctl->done) return;
     cplx *const s = (cplx *)lds + (tid >> 4) * 272;      // this lane group's padded row: physical(p) = p + (p >> 4)
@@ -829,7 +831,7 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
     const int j = tid & 15, r = (tid >> 4) & 1;
     const size_t N = (size_t)1 << 16;
     const size_t rowbase = ((size_t)blockIdx.x * 2 + r) << 8;
-    cplx *const u = (tid >= 32 ? a.uy : a.ux) + (size_t)f * N + rowbase;
+    cplx *const u = (tid >= 32 ? a.uy : a.ux) + (size_t)fc * N + rowbase;
     const cplx *const tp = a.tpass + rowbase;
     cplx x[16];
     {
@@ -855,7 +857,7 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
     // wave forms it for the lane's bins 0-7, the upper half for bins 8-15, and they swap (half_share)
     double btv[8];
     {
-        const double *bt = a.betat_p + rowbase + 16 * j + (tid >= 32 ? 8 : 0);
+        const double *bt = a.betat_p + (size_t)c * N + rowbase + 16 * j + (tid >= 32 ? 8 : 0);
 #pragma unroll
         for (int k = 0; k < 8; k++) btv[k] = bt[k];
     }
@@ -900,7 +902,7 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
                 sched_fence();
             }
         } else {
-            const double *d1 = a.db1_p + rowbase + ib;
+            const double *d1 = a.db1_p + (size_t)c * N + rowbase + ib;
             const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last;
             for (int k = 0; k < 8; k++) pmd_trunks(x[k], x[k + 8], btv[k], d1[k], brf, a.nplates, n0, ntrunk, dzb_first, dzb_last, a.lcorr, cur);
         }
@@ -1845,7 +1847,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         free_plan(P);
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
     }
-    if (tune.rowr && a.dual && nfc == 1 && a.p1 == 8 && a.p2 == 8 && !P->row_split &&
+    if (tune.rowr && a.dual && a.p1 == 8 && a.p2 == 8 && !P->row_split &&
         (a.pmd ? allow_lds(k_row256r<true>, ROWR_LDS) : allow_lds(k_row256r<false>, ROWR_LDS)) == hipSuccess) P->rowr = 1;
     // Fused column sweep (k_colx16): the inverse column pass of step s, the step controller and the forward column
     // pass of step s+1 in ONE launch on a register/LDS-resident tile (2 sweeps over HBM per step instead of 3), for
