@@ -649,7 +649,8 @@ def main():
         # ---- roofline: the dominant kernel, priced with the bytes it REALLY moves per launch (one sweep over the batch:
         # 32 B read + 32 B written per dual-pol sample; tables are shared by all frames and stay in L2) over its
         # average ACTIVE launch duration, measured live with HIP events between the launches on the fibre stream ----
-        names = ["k_colx16" if fused else "k_col_fwd", "k_row", "k_col_inv", "control"]
+        row_kernel = hp.row_kernel()
+        names = ["k_colx16" if fused else "k_col_fwd", row_kernel, "k_col_inv", "control"]
         kern = {}
         for k in range(3):
             if k_n[k]:
@@ -691,7 +692,7 @@ def main():
                        "with_reference_front_end": cohmix_line},
             # a PMD plan's row pass does one exponential + 20 multiply-adds per waveplate trunk and frequency: FP64-VALU-bound
             # (exception 1), still priced in bytes against the HBM peak
-            "roofline": {"bound": "fp64-valu" if (dom == "k_row" and hp.pmd) else "hbm", "kernel": dom,
+            "roofline": {"bound": "fp64-valu" if (dom == row_kernel and hp.pmd) else "hbm", "kernel": dom,
                          "achieved": kern.get(dom, {}).get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern.get(dom, {}).get("frac_of_8TBs"),
                          "algorithmic_bytes_per_launch": SWEEP_BYTES * active_frames * n,

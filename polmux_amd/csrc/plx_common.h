@@ -139,6 +139,25 @@ __device__ __forceinline__ void half_share(double m, double &a, double &b)
 }
 #endif
 
+// (complex forms: on the GPU two scalar swaps; the emulator moves the pair in one rendezvous of its 64 host threads)
+#ifdef PLX_EMU
+__device__ __forceinline__ void half_share(cplx m, cplx &a, cplx &b)
+{
+    const int l = (int)(threadIdx.x & 31u);
+    const double v[4] = {m.x, m.y, m.x, m.y};
+    const int src[4] = {l, l, l + 32, l + 32};
+    double o[4];
+    emu_shfl4(v, src, o, 4);
+    a = make_double2(o[0], o[1]); b = make_double2(o[2], o[3]);
+}
+#else
+__device__ __forceinline__ void half_share(cplx m, cplx &a, cplx &b)
+{
+    half_share(m.x, a.x, b.x);
+    half_share(m.y, a.y, b.y);
+}
+#endif
+
 // Lanes i and i + 32 trade halves of a register pair: on return v0 holds (own v0 | partner's v0 ... ) as v_permlane32_swap
 // defines it -- lanes 0-31 keep v0 and receive the upper half's v0 in v1, lanes 32-63 keep v1 and receive the lower half's v1
 // in v0.  Applied twice it is the identity.  (k_row256r with PMD: lane i holds ux, lane i + 32 uy of the same sixteen bins;
@@ -160,6 +179,26 @@ __device__ __forceinline__ void half_trade(double &v0, double &v1)
     const u2 rh = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v0), (unsigned)__double2hiint(v1), false, false);
     v0 = __hiloint2double((int)rh[0], (int)rl[0]);
     v1 = __hiloint2double((int)rh[1], (int)rl[1]);
+}
+#endif
+
+#ifdef PLX_EMU
+__device__ __forceinline__ void half_trade(cplx &c0, cplx &c1)
+{
+    const int l = (int)(threadIdx.x & 31u);
+    const bool lower = (threadIdx.x & 32u) == 0;
+    const double v[4] = {c1.x, c1.y, c0.x, c0.y};
+    const int src[4] = {l, l, l + 32, l + 32};
+    double o[4];
+    emu_shfl4(v, src, o, 4);
+    const cplx n0 = lower ? c0 : make_double2(o[0], o[1]), n1 = lower ? make_double2(o[2], o[3]) : c1;
+    c0 = n0; c1 = n1;
+}
+#else
+__device__ __forceinline__ void half_trade(cplx &c0, cplx &c1)
+{
+    half_trade(c0.x, c1.x);
+    half_trade(c0.y, c1.y);
 }
 #endif
 

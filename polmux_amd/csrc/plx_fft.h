@@ -232,7 +232,9 @@ __device__ __forceinline__ void lvl2_dif256(cplx *y, int j, const cplx *tw)
 // transform, W a functor e -> W_M^e (e < 3M/4).  Stages m = M (q = M/4) and m = M/4 (q = S) only combine points that
 // share j, so a transform of 16^L points is L such levels with one exchange between consecutive ones (4096-point
 // rows: k_row4k).
-template <int S, class W> __device__ __forceinline__ void lvl2_dif(cplx *y, int j, W w)
+// (u1, u2, u3 = w(4 j), w(8 j), w(12 j): the second stage's twiddles depend on the lane only; a caller whose lanes would
+//  fetch them from the same LDS banks -- sixteen lanes of a transform at strides of 4, 8 and 12 entries -- keeps them in registers)
+template <int S, class W> __device__ __forceinline__ void lvl2_dif(cplx *y, int j, W w, cplx u1, cplx u2, cplx u3)
 {
 #pragma unroll
     for (int r1 = 0; r1 < 4; r1++) { // m = M
@@ -243,8 +245,6 @@ template <int S, class W> __device__ __forceinline__ void lvl2_dif(cplx *y, int 
         y1 = cmul(y1, w(e)); y2 = cmul(y2, w(2 * e)); y3 = cmul(y3, w(3 * e));
         y[r1] = cadd(t0, t2); y[r1 + 4] = y2; y[r1 + 8] = y1; y[r1 + 12] = y3;
     }
-    const int e = 4 * j;
-    const cplx u1 = w(e), u2 = w(2 * e), u3 = w(3 * e);
 #pragma unroll
     for (int r2 = 0; r2 < 4; r2++) { // m = M/4
         const cplx a0 = y[4 * r2], a1 = y[4 * r2 + 1], a2 = y[4 * r2 + 2], a3 = y[4 * r2 + 3];
@@ -254,10 +254,13 @@ template <int S, class W> __device__ __forceinline__ void lvl2_dif(cplx *y, int 
         y[4 * r2] = cadd(t0, t2); y[4 * r2 + 1] = y2; y[4 * r2 + 2] = y1; y[4 * r2 + 3] = y3;
     }
 }
-template <int S, class W> __device__ __forceinline__ void lvl2_dit(cplx *y, int j, W w)
+template <int S, class W> __device__ __forceinline__ void lvl2_dif(cplx *y, int j, W w)
 {
     const int e = 4 * j;
-    const cplx u1 = w(e), u2 = w(2 * e), u3 = w(3 * e);
+    lvl2_dif<S, W>(y, j, w, w(e), w(2 * e), w(3 * e));
+}
+template <int S, class W> __device__ __forceinline__ void lvl2_dit(cplx *y, int j, W w, cplx u1, cplx u2, cplx u3)
+{
 #pragma unroll
     for (int r2 = 0; r2 < 4; r2++) { // m = M/4
         cplx c0 = y[4 * r2], c2 = y[4 * r2 + 1], c1 = y[4 * r2 + 2], c3 = y[4 * r2 + 3];
@@ -274,6 +277,16 @@ template <int S, class W> __device__ __forceinline__ void lvl2_dit(cplx *y, int 
         y[r1] = cadd(s0, s2); y[r1 + 4] = cadd(s1, s3); y[r1 + 8] = csub(s0, s2); y[r1 + 12] = csub(s1, s3);
     }
 }
+template <int S, class W> __device__ __forceinline__ void lvl2_dit(cplx *y, int j, W w)
+{
+    const int e = 4 * j;
+    lvl2_dit<S, W>(y, j, w, w(e), w(2 * e), w(3 * e));
+}
+// W_256^e (e < 192) from the half table W_256^k, k < 128
+struct Tw256half {
+    const cplx *t;
+    __device__ __forceinline__ cplx operator()(int e) const { return tw3(t, e, 128); }
+};
 // twiddle functors over the COMPACT table of W_4096 (W^{4k}, k < 512, then W^0..3: 8 KiB instead of the 32 KiB half
 // table, so that two row workgroups share a CU): W_4096^e, and W_256^e = W_4096^{16 e}
 struct Tw4096 {

@@ -805,7 +805,7 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 // the butterflies are k_row's, stage by stage.  Inter-pass twiddles as in k_row4k: tpass[j + 16 k] = tpass[j] * tpass[16 k],
 // a lane reads one entry and the row's sixteen lanes share sixteen (bk).
 #define ROWR_THREADS 64
-#define ROWR_LDS ((4 * 272 + 128 + 32) * sizeof(cplx))
+#define ROWR_LDS ((4 * 272 + 128 + 48) * sizeof(cplx))
 #ifdef PLX_EMU
 #define ROWR_SYNC() __syncthreads()
 #else
@@ -827,17 +827,22 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
     if (ctl->done) return;
     cplx *const s = (cplx *)lds + (tid >> 4) * 272;      // this lane group's padded row: physical(p) = p + (p >> 4)
     cplx *const tw = (cplx *)lds + 4 * 272;              // W_256^k, k < 128
-    cplx *const bk = tw + 128 + 16 * ((tid >> 4) & 1);   // tpass[row][16 k], k < 16
+    cplx *const bk = tw + 128 + 17 * ((tid >> 4) & 1);   // tpass[row][16 k], k < 16 (the two rows' entries on different banks)
+    const Tw256half w8{tw};
     const int j = tid & 15, r = (tid >> 4) & 1;
     const size_t N = (size_t)1 << 16;
     const size_t rowbase = ((size_t)blockIdx.x * 2 + r) << 8;
     cplx *const u = (tid >= 32 ? a.uy : a.ux) + (size_t)fc * N + rowbase;
     const cplx *const tp = a.tpass + rowbase;
     cplx x[16];
+    // the second register stage's twiddles W_256^{4j}, W^{8j}, W^{12j}: from the table in memory into registers, once -- out of
+    // LDS the sixteen lanes of a transform would fetch them from the same banks (strides of 4, 8 and 12 entries)
+    cplx v1, v2, v3;
     {
         const cplx ta = tp[j];
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = u[j + 16 * k];
+        v1 = a.tw2[4 * j]; v2 = a.tw2[8 * j]; v3 = tw3(a.tw2, 12 * j, 128);
         {
             const cplx t0 = a.tw2[tid], t1 = a.tw2[tid + 64], t3 = tp[16 * j];
             tw[tid] = t0; tw[tid + 64] = t1;
@@ -848,7 +853,7 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
         for (int k = 0; k < 16; k++) x[k] = cmul(x[k], cmul(ta, bk[k]));
     }
     sched_fence();
-    lvl2_dif256(x, j, tw);
+    lvl2_dif<16>(x, j, w8, v1, v2, v3);
     sched_fence();
 #pragma unroll
     for (int k = 0; k < 16; k++) s[row_phys(j + 16 * k)] = x[k];
@@ -872,7 +877,7 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
         const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * BRF_STRIDE : 0);
         const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { half_trade(x[k].x, x[k + 8].x); half_trade(x[k].y, x[k + 8].y); }   // x[k] = ux, x[k + 8] = uy of bin ib + k
+        for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);   // x[k] = ux, x[k + 8] = uy of bin ib + k
         if (a.e1tab && ntrunk <= a.tmax) {
             const cplx *e1 = a.e1tab + (size_t)f * a.tmax * 256 + rowf, *e2 = a.e2tab + (size_t)f * a.tmax * 256 + ib;
             // (pmd_trunks_tab with the trunk loop outside the bins: a trunk's plate and row phasor are fetched once)
@@ -907,15 +912,14 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
             for (int k = 0; k < 8; k++) pmd_trunks(x[k], x[k + 8], btv[k], d1[k], brf, a.nplates, n0, ntrunk, dzb_first, dzb_last, a.lcorr, cur);
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) { half_trade(x[k].x, x[k + 8].x); half_trade(x[k].y, x[k + 8].y); }
+        for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
     } else {
         const double cur = ctl->cur;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const cplx h = cexp_neg_turns(btv[k] * cur);
             cplx ha, hb;
-            half_share(h.x, ha.x, hb.x);
-            half_share(h.y, ha.y, hb.y);
+            half_share(h, ha, hb);
             x[k] = cmul(ha, x[k]);
             x[k + 8] = cmul(hb, x[k + 8]);
             sched_fence();
@@ -931,7 +935,7 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[row_phys(j + 16 * k)];
     sched_fence();
-    lvl2_dit256(x, j, tw);
+    lvl2_dit<16>(x, j, w8, v1, v2, v3);
     sched_fence();
 #pragma unroll
     for (int k = 0; k < 16; k++) u[j + 16 * k] = cmulc(x[k], cmul(tb, bk[k]));
@@ -2243,7 +2247,7 @@ extern "C" int plx_ssfm_info(plx_ssfm *P, int32_t *info)
 {
     if (!P || !info) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_info: null argument");
     info[0] = P->fused; info[1] = P->p1; info[2] = P->p2; info[3] = P->fused_grid; info[4] = P->tiles_pf;
-    info[5] = P->col_threads; info[6] = P->row_threads; info[7] = P->row_split;
+    info[5] = P->col_threads; info[6] = P->rowr ? ROWR_THREADS : (P->tw_compact ? 256 : (P->row_split ? P->rs_threads : P->row_threads)); info[7] = P->row_split;
     return PLX_OK;
 }
 

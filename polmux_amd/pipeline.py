@@ -377,6 +377,12 @@ class HotPath:
         self.lib.call("plx_ssfm_info", self.ssfm, info)
         return bool(info[0])
 
+    def row_kernel(self):
+        """name of the kernel that serves the step's row pass (for reports)"""
+        info = (C.c_int32 * 8)()
+        self.lib.call("plx_ssfm_info", self.ssfm, info)
+        return "k_row256r" if info[6] == 64 else ("k_row4k" if info[2] == 12 and info[7] else "k_row")
+
     def overlap_ok(self):
         """May a second stream (the receiver of the previous batch) share the GPU with fibre()?  The fused column sweep needs
         the tiles of a frame co-resident; when ONE frame takes more than half of the grid (2^19- and 2^20-sample frames)

@@ -27,19 +27,20 @@ res = {"_how": "scripts/traffic_pmc.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZ
        "samples_per_launch": samples}
 for mode, key, kernels in (("fused", None, ["k_colx16", "k_row"]), ("plain", "plain_three_sweep", ["k_col_fwd", "k_row", "k_col_inv"])):
     fe, wr = read(mode, "FETCH_SIZE"), read(mode, "WRITE_SIZE")
+    kernels = [("k_row256r" if (k == "k_row" and "k_row256r" in fe) else k) for k in kernels]   # (the register form serves 256-point rows)
     per = {k: (2 * fe[k] + wr[k]) * 1024 / samples for k in kernels if k in fe and k in wr}
     blk = {"kernels": kernels, "fetch_kb": [fe.get(k) for k in kernels], "write_kb": [wr.get(k) for k in kernels],
            "bytes_per_sample_by_kernel": per, "bytes_per_sample_step": sum(per.values())}
     if key is None:
         res.update(blk)
-        res["default_path"] = "fused column sweep k_colx16 + k_row (2 sweeps per SSFM step)"
+        res["default_path"] = "fused column sweep k_colx16 + %s (2 sweeps per SSFM step)" % kernels[1]
     else:
         blk["selected_by"] = "PLX_SSFM_NO_FUSE=1"
         res[key] = blk
 if os.path.exists(os.path.join(d, "big_FETCH_SIZE.txt")):      # 2^20-sample frames, 16 per launch (k_row4k reports as k_row4k)
     fe, wr = read("big", "FETCH_SIZE"), read("big", "WRITE_SIZE")
     sb = 16 * (1 << 20)
-    names = {"k_colx16": "k_colx16", "k_row4k": "k_row"}
+    names = {"k_colx16": "k_colx16", "k_row4k": "k_row4k"}
     per = {names[k]: (2 * fe[k] + wr[k]) * 1024 / sb for k in names if k in fe and k in wr}
     res["frames_2pow20"] = {"samples_per_launch": sb, "kernels": ["k_colx16", "k_row4k"], "fetch_kb": [fe.get("k_colx16"), fe.get("k_row4k")],
                             "write_kb": [wr.get("k_colx16"), wr.get("k_row4k")], "bytes_per_sample_by_kernel": per,

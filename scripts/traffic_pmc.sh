@@ -14,7 +14,7 @@ for mode in fused plain; do
     timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/traffic/pmc_$c -- python3 bench.py --frames $F --steps 1 --warmup 0 --variants 1 --mc-rounds 0 --no-cpu-baseline --no-overlap --no-single-frame --no-gateway > /dev/null 2>&1 || exit 1
     f=$(find gpurun_out/traffic/pmc_$c -name "*counter_collection.csv" | head -1)
     python scripts/pmc_summary.py $f > gpurun_out/traffic/${mode}_$c.txt
-    grep -E "k_colx16|k_row|k_col_fwd|k_col_inv" gpurun_out/traffic/${mode}_$c.txt
+    grep -E "k_colx16|k_row|k_col_fwd|k_col_inv" gpurun_out/traffic/${mode}_$c.txt || true
     rm -rf gpurun_out/traffic/pmc_$c
   done
 done

@@ -1,6 +1,7 @@
 // hip_emu.cpp -- TEST INFRASTRUCTURE ONLY (see hip_emu.h).
 #include "hip_emu.h"
 #include <chrono>
+#include <map>
 
 namespace emu {
 thread_local BlockCtx *t_ctx = nullptr;
@@ -56,7 +57,7 @@ struct Pool {
         ctx.grid = grid;
         ctx.block = block;
         ctx.nthreads = n;
-        ctx.xchg.assign(n, 0);
+        ctx.xchg.assign(4 * (size_t)n, 0);   // (slots [0, n): the shuffles; [n, 4n): emu_shfl4's further values)
         ctx.lds.assign(shmem ? shmem : 16, (char)0x7f); // poisoned LDS: uninitialised reads show up
         ctx.bar = std::make_unique<std::barrier<>>((std::ptrdiff_t)n);
         ctx.wave_bar.clear();
@@ -86,10 +87,12 @@ struct Pool {
         for (auto &t : th) t.join();
     }
 };
-std::vector<std::unique_ptr<Pool>> &pools()
+// one set of pools per block size: a block start wakes every thread of its pool, and a pool grown to 1024 threads by one
+// kernel would otherwise be woken 64 lanes at a time by the one-wave workgroups of another
+std::vector<std::unique_ptr<Pool>> &pools(unsigned n)
 {
-    static std::vector<std::unique_ptr<Pool>> p;
-    return p;
+    static std::map<unsigned, std::vector<std::unique_ptr<Pool>>> p;
+    return p[n];
 }
 } // namespace
 
@@ -101,7 +104,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &bo
     static const bool trace = std::getenv("PLX_EMU_TRACE") != nullptr;
     if (trace) std::fprintf(stderr, "emu launch grid=(%u,%u,%u) block=%u lds=%zu conc=%d\n", grid.x, grid.y, grid.z, n, shmem, g_concurrency);
     const unsigned conc = (unsigned)(g_concurrency < 1 ? 1 : g_concurrency);
-    auto &ps = pools();
+    auto &ps = pools(n);
     while (ps.size() < conc) ps.push_back(std::make_unique<Pool>());
     std::vector<dim3> ids;
     for (unsigned bz = 0; bz < grid.z; bz++)

@@ -91,6 +91,20 @@ template <class T> static inline T emu_shfl_src(T v, int src_lane)
     (void)lane;
     return r;
 }
+// up to four doubles exchanged in ONE rendezvous of the wave: out[i] = value i of lane src[i] (the permlane-swap idioms of
+// plx_common.h move a complex pair at a time; four separate shuffles would be eight barrier rounds of 64 host threads)
+static inline void emu_shfl4(const double *v, const int *src, double *out, int n)
+{
+    unsigned lin = emu::t_linear, wave = lin / 64;
+    emu::BlockCtx &cx = *emu::t_ctx;
+    for (int i = 0; i < n; i++) std::memcpy(&cx.xchg[(size_t)i * cx.nthreads + lin], &v[i], 8);
+    cx.wave_bar[wave]->arrive_and_wait();
+    for (int i = 0; i < n; i++) {
+        unsigned s_ = wave * 64 + (unsigned)(src[i] & 63);
+        if (s_ < cx.nthreads) std::memcpy(&out[i], &cx.xchg[(size_t)i * cx.nthreads + s_], 8); else out[i] = v[i];
+    }
+    cx.wave_bar[wave]->arrive_and_wait();
+}
 template <class T> static inline T __shfl_xor(T v, int mask, int = 64) { return emu_shfl_src(v, (int)(emu::t_linear % 64) ^ mask); }
 template <class T> static inline T __shfl_down(T v, int d, int = 64)
 {

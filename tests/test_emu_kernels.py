@@ -345,27 +345,28 @@ def test_emu_register_form_row_pass(emu, oracle, monkeypatch):
     """256 x 256 frames without PMD take the register form of the row pass (k_row256r: one wave per 2 rows x 2 polarisations,
     the multiplier shared between the wave's halves); PLX_SSFM_ROWR=0 keeps the LDS-resident k_row.  Both against the oracle,
     and against each other (they differ by the rounding of the inter-pass twiddles only)."""
-    n, nt, L = 65536, 16, 1.1e3
+    n, nt, L = 65536, 16, 7e2
     fls = [1, 0, 1, 0]
     betat, db1 = _tables(n, nt, fls, 1)
-    fields = [_qpsk_field(n, nt, p)[:2] for p in (4.0, 9.0)]
+    monkeypatch.setenv("PLX_SSFM_NO_FUSE", "1")    # (three-sweep step: the emulated frame barrier of the fused sweep is slow and not under test here)
+    fields = [_qpsk_field(n, nt, p)[:2] for p in (9.0,)]
     ref = [oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0]) for f in fields]
     got = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("PLX_SSFM_ROWR", mode)
-        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=2)
+        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=1)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
         monkeypatch.delenv("PLX_SSFM_ROWR")
         ux = _il(np.stack([f[0] for f in fields])); uy = _il(np.stack([f[1] for f in fields]))
-        emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 2, None)
-        ncyc = np.zeros(2, np.int32)
-        emu.call("plx_ssfm_results", plan, 2, None, _vp(ncyc))
+        emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 1, None)
+        ncyc = np.zeros(1, np.int32)
+        emu.call("plx_ssfm_results", plan, 1, None, _vp(ncyc))
         emu.call("plx_ssfm_destroy", plan)
-        gx = ux.view(np.complex128).reshape(2, n); gy = uy.view(np.complex128).reshape(2, n)
-        for f in range(2):
+        gx = ux.view(np.complex128).reshape(1, n); gy = uy.view(np.complex128).reshape(1, n)
+        for f in range(1):
             rc, ofd, onc, ox, oy = ref[f]
-            assert ncyc[f] == onc and onc >= 3
+            assert ncyc[f] == onc and onc >= 2
             assert np.abs(gx[f] - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
             assert np.abs(gy[f] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
         got[mode] = (gx.copy(), gy.copy())
@@ -380,14 +381,15 @@ def test_emu_register_form_row_pass_with_pmd(emu, oracle, monkeypatch, tables):
     (PLX_SSFM_NO_PMD_TAB=1).  256 x 256 frame with its own waveplates, against the oracle and against k_row's PMD branch."""
     if not tables:
         monkeypatch.setenv("PLX_SSFM_NO_PMD_TAB", "1")
-    n, nt, nplates, L = 65536, 16, 5, 1.3e3
+    monkeypatch.setenv("PLX_SSFM_NO_FUSE", "1")    # (three-sweep step, as in test_emu_register_form_row_pass)
+    n, nt, nplates, L = 65536, 16, 5, 8e2
     fls = [1, 1, 1, 0]
     betat, db1 = _tables(n, nt, fls, nplates)
     r = np.random.default_rng(11)
     brf = (r.random(nplates) * 2 * np.pi - np.pi, r.random(nplates) * np.pi - np.pi / 2, 0.5 * np.arcsin(r.random(nplates) * 2 - 1))
     fx, fy = _qpsk_field(n, nt, 7.0)[:2]
     rc, ofd, onc, ox, oy = oracle.matrix_ssfm(fx, fy, betat, db1, 5e2, 5e-3, [1.3e-6], 4.6e-5, L, nplates, 0, fls, *brf)
-    assert rc == 0 and onc >= 3
+    assert rc == 0 and onc >= 2
     got = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("PLX_SSFM_ROWR", mode)
