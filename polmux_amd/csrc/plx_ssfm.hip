@@ -842,7 +842,7 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
         const cplx ta = tp[j];
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = u[j + 16 * k];
-        v1 = a.tw2[4 * j]; v2 = a.tw2[8 * j]; v3 = tw3(a.tw2, 12 * j, 128);
+        if (!PMD) { v1 = a.tw2[4 * j]; v2 = a.tw2[8 * j]; v3 = tw3(a.tw2, 12 * j, 128); }     // (PMD: the trunk loop needs the registers, LDS serves)
         {
             const cplx t0 = a.tw2[tid], t1 = a.tw2[tid + 64], t3 = tp[16 * j];
             tw[tid] = t0; tw[tid + 64] = t1;
@@ -853,7 +853,7 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
         for (int k = 0; k < 16; k++) x[k] = cmul(x[k], cmul(ta, bk[k]));
     }
     sched_fence();
-    lvl2_dif<16>(x, j, w8, v1, v2, v3);
+    if (PMD) lvl2_dif<16>(x, j, w8); else lvl2_dif<16>(x, j, w8, v1, v2, v3);
     sched_fence();
 #pragma unroll
     for (int k = 0; k < 16; k++) s[row_phys(j + 16 * k)] = x[k];
@@ -935,7 +935,7 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[row_phys(j + 16 * k)];
     sched_fence();
-    lvl2_dit<16>(x, j, w8, v1, v2, v3);
+    if (PMD) lvl2_dit<16>(x, j, w8); else lvl2_dit<16>(x, j, w8, v1, v2, v3);
     sched_fence();
 #pragma unroll
     for (int k = 0; k < 16; k++) u[j + 16 * k] = cmulc(x[k], cmul(tb, bk[k]));
