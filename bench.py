@@ -710,7 +710,7 @@ def main():
                          "limiter": "below the HBM roof: %s holds 16 FP64 complex points per lane (256 VGPRs, 8 waves per CU: a lone wave "
                                     "issues one FP64 operation per ~8 clocks, so a tile's arithmetic is as long as its traffic) and a third "
                                     "of a workgroup's time is the skew of the 32 tiles of a frame meeting at the barrier of nextstep's maximum "
-                                    "(profiles/r02_notes.md); k_row streams at the in-place read-modify-write rate" % names[0]
+                                    "(profiles/r02_notes.md); the row pass (%s) streams at the in-place read-modify-write rate" % (names[0], names[1])
                                     if fused else "three plain sweeps at the in-place streaming rate",
                          "survey_accounting": {"bytes_per_sample_step": SURVEY_BYTES_PER_SAMPLE_STEP,
                                                "frac": SURVEY_BYTES_PER_SAMPLE_STEP * sample_steps / (fib * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -13,6 +13,9 @@
 //   k_row      load rows -> x inter-pass twiddle -> N2-point DIF in LDS ->
 //              x exp(-i beta dz) / PMD waveplates (both polarisations of one
 //              frequency co-resident) -> N2-point DIT -> x conj twiddle -> store
+//   k_row256r  the same for 256-point rows of dual-polarisation plans with every radix level in
+//              registers: one wave = 2 rows x 2 polarisations, two LDS exchanges, no workgroup
+//              barrier, the multiplier shared between the wave's halves (k_row4k: 4096-point rows)
 //   k_col_inv  load column tile -> N1-point DIT -> x exp(-alpha dz/2)/N ->
 //              wave-shuffle max of |ux|^2+|uy|^2 -> one atomicMax per workgroup
 //   k_ctrl     one lane per frame: nextstep + checkstep + last-step rule; the
