@@ -976,7 +976,15 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x;
-    const int slot = blockIdx.y / a.nfc, c = blockIdx.y - slot * a.nfc;
+    // Workgroup -> (row, frame-channel, polarisation).  The users of a row's tables (betat: 32 KiB, tpass: 64 KiB per row, the
+    // same for every frame and both polarisations) are dealt to ONE XCD -- workgroups 8 apart under the round-robin dealing --
+    // and next to each other in time: id = 8 K g + 8 k + c with row = 8 g + c and k = 2 (frame-channel) + polarisation < K,
+    // so the tables come out of that XCD's L2 for all but the first of a row's K workgroups (they were re-read from HBM a
+    // quarter of the time under the (row, frame, polarisation) grid: 75.5 B per sample, profiles/r03_traffic.json).
+    const int K = (int)(gridDim.x >> a.p1), lg = a.p1 < 3 ? a.p1 : 3, G = 1 << lg;     // (G = 8 rows to a group; fewer rows: all of them)
+    const int g8 = (int)blockIdx.x / (G * K), rem = (int)blockIdx.x - g8 * G * K;
+    const int brow = g8 * G + (rem & (G - 1)), bk2 = rem >> lg, by = bk2 >> 1, bpol = bk2 & 1;
+    const int slot = by / a.nfc, c = by - slot * a.nfc;
     int f;
     if (!slot_frame(a, slot, f)) return;
     const int fc = f * a.nfc + c;
@@ -987,10 +995,10 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     cplx *bk = tw + 516;                         // tpass[256 k], k < 16
     cplx *t8 = bk + 16;                          // W_256^e at e + (e >> 2), e < 128
     const size_t N = (size_t)1 << (a.p1 + a.p2);
-    const size_t rowbase = (size_t)blockIdx.x << 12;
-    // (grid.z: the polarisation; a.wx: the plan's working copy with its own row pitch, see SsfmArgs)
-    cplx *const u = a.wx ? (blockIdx.z ? a.wy : a.wx) + ((size_t)fc << a.p1) * a.wpitch + (size_t)blockIdx.x * a.wpitch
-                         : (blockIdx.z ? a.uy : a.ux) + (size_t)fc * N + rowbase;
+    const size_t rowbase = (size_t)brow << 12;
+    // (a.wx: the plan's working copy with its own row pitch, see SsfmArgs)
+    cplx *const u = a.wx ? (bpol ? a.wy : a.wx) + ((size_t)fc << a.p1) * a.wpitch + (size_t)brow * a.wpitch
+                         : (bpol ? a.uy : a.ux) + (size_t)fc * N + rowbase;
     const cplx *const tp = a.tpass + rowbase;
 
     const Tw4096 w1{tw};
@@ -2018,7 +2026,7 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         b.dual = 0; b.R = 1; b.logR = 0;
         const dim3 gs((unsigned)N1, FC), bs((unsigned)P->rs_threads);
         if (P->tw_compact) {                     // (both polarisations in one launch: one tail instead of two)
-            PLX_LAUNCH(k_row4k, dim3(gs.x, gs.y, 2), dim3(256), P->rs_lds, st, b);
+            PLX_LAUNCH(k_row4k, dim3(gs.x * gs.y * 2u), dim3(256), P->rs_lds, st, b);   // (rows x frame-channels x polarisations: decoded in the kernel)
             return;
         }
         for (int pol = 0; pol < 2; pol++) {
