@@ -981,9 +981,18 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     // and next to each other in time: id = 8 K g + 8 k + c with row = 8 g + c and k = 2 (frame-channel) + polarisation < K,
     // so the tables come out of that XCD's L2 for all but the first of a row's K workgroups (they were re-read from HBM a
     // quarter of the time under the (row, frame, polarisation) grid: 75.5 B per sample, profiles/r03_traffic.json).
+    // Measured (profiles/r03_row4k_map_ab.txt): FETCH_SIZE 3.57e5 -> 2.68e5 KB per 16-frame launch, 319 -> 314 us; no change at 64
+    // frames; but 8 frames (config[4]'s ladder) run 3 - 5 % SLOWER that way, so batches under 16 frames keep the plain order
+    // (row fastest, then frame-channel, then polarisation).
     const int K = (int)(gridDim.x >> a.p1), lg = a.p1 < 3 ? a.p1 : 3, G = 1 << lg;     // (G = 8 rows to a group; fewer rows: all of them)
-    const int g8 = (int)blockIdx.x / (G * K), rem = (int)blockIdx.x - g8 * G * K;
-    const int brow = g8 * G + (rem & (G - 1)), bk2 = rem >> lg, by = bk2 >> 1, bpol = bk2 & 1;
+    int brow, by, bpol;
+    if (K >= 32) {
+        const int g8 = (int)blockIdx.x / (G * K), rem = (int)blockIdx.x - g8 * G * K, bk2 = rem >> lg;
+        brow = g8 * G + (rem & (G - 1)); by = bk2 >> 1; bpol = bk2 & 1;
+    } else {
+        const int N1 = 1 << a.p1, q = (int)blockIdx.x >> a.p1, FCn = K >> 1;
+        brow = (int)blockIdx.x & (N1 - 1); bpol = q / FCn; by = q - bpol * FCn;
+    }
     const int slot = by / a.nfc, c = by - slot * a.nfc;
     int f;
     if (!slot_frame(a, slot, f)) return;
