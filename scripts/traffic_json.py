@@ -45,5 +45,6 @@ if os.path.exists(os.path.join(d, "big_FETCH_SIZE.txt")):      # 2^20-sample fra
     res["frames_2pow20"] = {"samples_per_launch": sb, "kernels": ["k_colx16", "k_row4k"], "fetch_kb": [fe.get("k_colx16"), fe.get("k_row4k")],
                             "write_kb": [wr.get("k_colx16"), wr.get("k_row4k")], "bytes_per_sample_by_kernel": per,
                             "bytes_per_sample_step": sum(per.values()),
-                            "note": "k_row4k re-reads betat (8 MiB per frame and polarisation) and the inter-pass twiddles from HBM at this size"}
+                            "note": "k_row4k: with the users of a row's tables (frames x polarisations) dealt to one XCD the tables come out of its L2 "
+                                    "(64.7 B per sample; 75.5 B under the (row, frame, polarisation) grid of round 2: betat and the inter-pass twiddles re-read from HBM)"}
 print(json.dumps(res, indent=1))
