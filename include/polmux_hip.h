@@ -130,7 +130,7 @@ int plx_ssfm_stats(plx_ssfm *plan, int64_t *row_pass_launches, int64_t *sample_s
 /* Optional per-kernel timing of the step loop, for roofline reports: with profiling enabled every propagate call
  * records a HIP event between consecutive launches on its stream; after the call, ms[k] / launches[k] hold the
  * summed duration and count of the ACTIVE launches (those issued before the slowest frame had finished) of kernel
- * class k: 0 = column sweep that starts a step (fused k_colx16, or k_col_fwd), 1 = k_row, 2 = k_col_inv,
+ * class k: 0 = column sweep that starts a step (fused k_colx16, or k_col_fwd), 1 = the row pass (k_row256r, k_row4k or k_row: plx_ssfm_info), 2 = k_col_inv,
  * 3 = step control / row sums / read-backs.  Both arrays have 4 entries.                                         */
 /* Lock-step accounting of the last propagate (frames of a batch need different numbers of steps, fiber.m:518): the
  * frame-steps that had work to do; the frame slots of the device's active list summed over the steps (what the
