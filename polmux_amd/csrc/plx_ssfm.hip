@@ -86,6 +86,7 @@ struct SsfmArgs {
     int *nactive;                  // [0] length of the list, [1] running sum of it over the steps (utilisation accounting)
     long long spin_ticks;          // frame-barrier timeout in ticks of plx_clock() (10 ns)
     unsigned long long *slots;     // [2][nframes][tiles per frame] per-tile max |u|^2 by launch parity (k_colx16), ~0 = not arrived
+    int store_late;                // fused sweep: a tile's stores are issued AFTER the next tile has landed (one-team launches: see k_colx16)
     int safe_land;                 // PLX_SSFM_SAFE_LANDING=1: the staged tile is also waited for with s_waitcnt vmcnt(0) (checks the sentinel landing)
     int round;                     // launch index of the fused sweep within this propagate call
     int *grab;                     // [2] frames claimed beyond the first of every team, by launch parity (k_colx16)
@@ -1552,6 +1553,17 @@ template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a
                 if (nf >= 0) stage(nf, (it & 1) ^ 1);
             }
             r16_dif(x);                    // ... during the last register transform and the stores of this one
+            // One-team launches (a frame = the whole grid: 2^20 samples): every workgroup reaches this point at the same moment,
+            // and 32 MiB of stores issued on the heels of the 32 MiB of staging requests share the memory system with them -- the
+            // tile lands twice as late, and the frame barrier that follows waits for the last landing.  There the stores are
+            // held back until this wave's rows of the next tile are in LDS: requests first, stores while the next tile computes.
+            if (a.store_late) {
+                const int nf = (int)red[10 + (it & 1)];
+                if (nf >= 0) {
+                    FrameCtl *const nrec = lctl + 4 * ((it & 1) ^ 1) + (tid >> 6);
+                    while (lds_peek(&nrec->done) == PLX_REC_SENTINEL) nap();
+                }
+            }
             if (WORK) {
                 int tq = t;
                 pin(tq);
@@ -1685,7 +1697,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0, rowr = 0;
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0, rowr = 0, store_late = -1;
     double barrier_timeout_ms = 500.0, group_mib = -1.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -1698,6 +1710,7 @@ struct Tune {
         col_threads = geti("PLX_SSFM_COL_THREADS", -1);
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
+        store_late = geti("PLX_SSFM_STORE_LATE", -1);  // fused sweep: stores after the next tile's landing; -1: where a frame takes the whole grid
         rowr = geti("PLX_SSFM_ROWR", 1);               // 0: the LDS-resident k_row also where the register form k_row256r applies (A/B, tests)
         no_pmd_tab = geti("PLX_SSFM_NO_PMD_TAB", 0);   // PMD plans: one exponential per bin and trunk instead of the phasor tables (A/B, tests)
         wpad = geti("PLX_SSFM_WPAD", -2);         // complex samples added to the working copy's row pitch; -1: no working copy
@@ -1892,6 +1905,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
             P->fused = 1;
             P->tiles_pf = tiles_pf;
             P->fused_grid = (cap / tiles_pf) * tiles_pf;
+            a.store_late = tune.store_late >= 0 ? (tune.store_late ? 1 : 0) : (P->fused_grid > tiles_pf ? 1 : 0);
             const int mstride = F + 4;       // (iterations of a team in a launch <= frames listed; its first workgroup posts two ahead)
             P->mbox_bytes = sizeof(unsigned long long) * ((size_t)mstride * (P->fused_grid / tiles_pf) + 1);
             if (hipMalloc((void **)&P->d_slots, sizeof(unsigned long long) * 2 * (size_t)F * tiles_pf) != hipSuccess ||
