@@ -1697,7 +1697,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0, rowr = 0, store_late = -1;
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0, rowr = 0, store_late = -1, fused_per_cu = 0;
     double barrier_timeout_ms = 500.0, group_mib = -1.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -1710,6 +1710,7 @@ struct Tune {
         col_threads = geti("PLX_SSFM_COL_THREADS", -1);
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
+        fused_per_cu = geti("PLX_SSFM_FUSED_PER_CU", 0);  // fused sweep: workgroups per CU the grid is sized for (0: what fits; 1: half the chip's slots, for two plans propagating side by side)
         store_late = geti("PLX_SSFM_STORE_LATE", -1);  // fused sweep: stores after the next tile's landing; -1: where a frame takes the whole grid
         rowr = geti("PLX_SSFM_ROWR", 1);               // 0: the LDS-resident k_row also where the register form k_row256r applies (A/B, tests)
         no_pmd_tab = geti("PLX_SSFM_NO_PMD_TAB", 0);   // PMD plans: one exponential per bin and trunk instead of the phasor tables (A/B, tests)
@@ -1900,7 +1901,9 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
                 ncu = v;
         }
         const int tiles_pf = nfc * (N2 / a.W);
-        const int cap = ncu * std::min(blocks_per_cu(k_colx16<0>, 256, P->lds_col), std::min(blocks_per_cu(k_colx16<8>, 256, P->lds_col), blocks_per_cu(k_colx16<12>, 256, P->lds_col)));
+        int per_cu = std::min(blocks_per_cu(k_colx16<0>, 256, P->lds_col), std::min(blocks_per_cu(k_colx16<8>, 256, P->lds_col), blocks_per_cu(k_colx16<12>, 256, P->lds_col)));
+        if (tune.fused_per_cu > 0 && tune.fused_per_cu < per_cu) per_cu = tune.fused_per_cu;
+        const int cap = ncu * per_cu;
         if (tiles_pf <= cap) {
             P->fused = 1;
             P->tiles_pf = tiles_pf;
