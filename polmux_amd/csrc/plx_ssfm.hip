@@ -86,6 +86,7 @@ struct SsfmArgs {
     int *nactive;                  // [0] length of the list, [1] running sum of it over the steps (utilisation accounting)
     long long spin_ticks;          // frame-barrier timeout in ticks of plx_clock() (10 ns)
     unsigned long long *slots;     // [2][nframes][tiles per frame] per-tile max |u|^2 by launch parity (k_colx16), ~0 = not arrived
+    int row_rev;                   // k_row256r takes the listed frames in DESCENDING order (the column sweep takes them ascending: each kernel starts on the frames the other finished with, which are still in the Infinity Cache)
     int store_late;                // fused sweep: a tile's stores are issued AFTER the next tile has landed (one-team launches: see k_colx16)
     int safe_land;                 // PLX_SSFM_SAFE_LANDING=1: the staged tile is also waited for with s_waitcnt vmcnt(0) (checks the sentinel landing)
     int round;                     // launch index of the fused sweep within this propagate call
@@ -126,6 +127,18 @@ __device__ __forceinline__ bool slot_frame(const SsfmArgs &a, int slot, int &f)
     if (!a.active) { f = slot; return slot < a.nframes; }
     if (slot >= a.nactive[0]) return false;
     f = a.active[slot];
+    return true;
+}
+
+// The row pass takes the listed frames in DESCENDING order where the column sweep takes them ascending (SsfmArgs::row_rev): each
+// kernel then starts on the frames the other has just finished with, which are still in the 256 MiB Infinity Cache (128 frames
+// of 2^16 samples, 8 of 2^20).  false: the slot lies beyond the list (the host's grid may be longer than the list).
+__device__ __forceinline__ bool row_slot(const SsfmArgs &a, int &slot)
+{
+    if (!a.row_rev) return true;
+    const int n = a.active ? a.nactive[0] : a.nframes;
+    if (slot >= n) return false;
+    slot = n - 1 - slot;
     return true;
 }
 
@@ -640,7 +653,9 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, nthr = blockDim.x;
-    const int slot = blockIdx.y / a.nfc, c = blockIdx.y - slot * a.nfc;
+    int slot = blockIdx.y / a.nfc;
+    const int c = blockIdx.y - slot * a.nfc;
+    if (!row_slot(a, slot)) return;
     int f;
     if (!slot_frame(a, slot, f)) return;
     const int fc = f * a.nfc + c;
@@ -823,7 +838,9 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x;
-    const int slot = blockIdx.y / a.nfc, c = blockIdx.y - slot * a.nfc;       // (channels of a frame: 'sepfields' WDM)
+    int slot = blockIdx.y / a.nfc;
+    const int c = blockIdx.y - slot * a.nfc;       // (channels of a frame: 'sepfields' WDM)
+    if (!row_slot(a, slot)) return;
     int f;
     if (!slot_frame(a, slot, f)) return;
     const int fc = f * a.nfc + c;
@@ -994,7 +1011,9 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
         const int N1 = 1 << a.p1, q = (int)blockIdx.x >> a.p1, FCn = K >> 1;
         brow = (int)blockIdx.x & (N1 - 1); bpol = q / FCn; by = q - bpol * FCn;
     }
-    const int slot = by / a.nfc, c = by - slot * a.nfc;
+    int slot = by / a.nfc;
+    const int c = by - slot * a.nfc;
+    if (!row_slot(a, slot)) return;
     int f;
     if (!slot_frame(a, slot, f)) return;
     const int fc = f * a.nfc + c;
@@ -1697,7 +1716,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0, rowr = 0, store_late = -1, fused_per_cu = 0;
+    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0, rowr = 0, store_late = -1, fused_per_cu = 0, row_rev = 0;
     double barrier_timeout_ms = 500.0, group_mib = -1.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -1711,7 +1730,8 @@ struct Tune {
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
         fused_per_cu = geti("PLX_SSFM_FUSED_PER_CU", 0);  // fused sweep: workgroups per CU the grid is sized for (0: what fits; 1: half the chip's slots, for two plans propagating side by side)
-        store_late = geti("PLX_SSFM_STORE_LATE", -1);  // fused sweep: stores after the next tile's landing; -1: where a frame takes the whole grid
+        store_late = geti("PLX_SSFM_STORE_LATE", -1);  // fused sweep: stores after the next tile's landing; -1: where a launch has more than one team
+        row_rev = geti("PLX_SSFM_ROW_REV", 1);         // 0: the row pass takes the listed frames in ascending order as well (A/B)
         rowr = geti("PLX_SSFM_ROWR", 1);               // 0: the LDS-resident k_row also where the register form k_row256r applies (A/B, tests)
         no_pmd_tab = geti("PLX_SSFM_NO_PMD_TAB", 0);   // PMD plans: one exponential per bin and trunk instead of the phasor tables (A/B, tests)
         wpad = geti("PLX_SSFM_WPAD", -2);         // complex samples added to the working copy's row pitch; -1: no working copy
@@ -1807,6 +1827,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
     a.invN = 1.0 / (double)N;
     a.spin_ticks = (long long)(tune.barrier_timeout_ms * 1e5);
     a.safe_land = tune.safe_landing;
+    a.row_rev = tune.row_rev;
     // (the mailbox entries of k_colx16 pack frame + 1 and iteration + 1 into 22-bit fields)
     if ((int64_t)desc->max_frames + 4 >= ((int64_t)1 << 22)) { free_plan(P); PLX_FAIL(PLX_ERR_UNSUPPORTED, "plx_ssfm_create: max_frames must be below 2^22 - 4"); }
 
