@@ -397,7 +397,10 @@ def test_sentinel_landing_of_the_staged_tile_equals_the_ordinary_wait(lib, monke
     #  default: the arithmetic does not depend on where the field lives)
     # (the working copy's padded rows are served by the LDS-resident k_row, which rounds the inter-pass twiddles differently
     #  from the register form k_row256r: "wpad" is compared with "ldsrow", the same row pass on the caller's arrays)
-    for name, env in (("eager", {}), ("safe", {"PLX_SSFM_SAFE_LANDING": "1"}), ("ldsrow", {"PLX_SSFM_ROWR": "0"}),
+    # ("early": the fused sweep's stores issued before the next tile has landed, the order of one-team launches; "fwdrows":
+    #  the row pass over the listed frames in ascending order -- both only move work in time)
+    for name, env in (("eager", {}), ("safe", {"PLX_SSFM_SAFE_LANDING": "1"}), ("early", {"PLX_SSFM_STORE_LATE": "0"}),
+                      ("fwdrows", {"PLX_SSFM_ROW_REV": "0"}), ("ldsrow", {"PLX_SSFM_ROWR": "0"}),
                       ("wpad", {"PLX_SSFM_WPAD": "8", "PLX_SSFM_ROWR": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -424,7 +427,7 @@ def test_sentinel_landing_of_the_staged_tile_equals_the_ordinary_wait(lib, monke
         hp.close()
     ref = res["eager"][0]
     assert max(ref[2]) > min(ref[2])           # frames leave the loop at different steps
-    for name, base in (("eager", "eager"), ("safe", "eager"), ("ldsrow", "ldsrow"), ("wpad", "ldsrow")):
+    for name, base in (("eager", "eager"), ("safe", "eager"), ("early", "eager"), ("fwdrows", "eager"), ("ldsrow", "ldsrow"), ("wpad", "ldsrow")):
         ref = res[base][0]
         for o in res[name]:
             assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]), name
