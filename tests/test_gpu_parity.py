@@ -176,6 +176,44 @@ def test_register_form_row_pass_with_pmd_vs_oracle_three_ways(lib, oracle, monke
     assert not np.array_equal(got["ldsrow"][0], got["tab"][0])      # (the switch really selects another kernel)
 
 
+def test_long_rows_sixteen_frames_take_the_xcd_grouped_map_vs_oracle(lib, oracle, monkeypatch):
+    """From 16 frames up k_row4k deals the 2 x F users of a row's tables to one XCD, next to each other in time (its own decode
+    of the workgroup index) and, like every row pass, walks the listed frames backwards.  18 frames on a power ladder on the
+    4 x 4096 split of a 2^14 frame (PLX_SSFM_P1=2: the oracle is affordable at this size): every frame's field, step count and
+    first step against the oracle -- a slip in the decode would transform some row twice and another never."""
+    import torch
+    F = 18
+    c = _fibre_case(256, 64, "g-s-", 2.0)
+    dbm = -3.0 + 10.0 * np.arange(F) / (F - 1)
+    scale = np.sqrt(10 ** (dbm / 10))
+    for k, v in (("PLX_SSFM_P1", "2"), ("PLX_SSFM_LOGW", "6")):
+        monkeypatch.setenv(k, v)
+    d = _desc(c, frames=F)
+    plan = C.c_void_p()
+    lib.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+    for k in ("PLX_SSFM_P1", "PLX_SSFM_LOGW"):
+        monkeypatch.delenv(k)
+    info = (C.c_int32 * 8)()
+    lib.call("plx_ssfm_info", plan, info)
+    assert list(info)[:3] == [0, 2, 12] and info[7] == 1          # three sweeps, 4 x 4096, one polarisation per row workgroup
+    x0 = np.stack([c["ux"][:, 0] * s for s in scale]); y0 = np.stack([c["uy"][:, 0] * s for s in scale])
+    ux, uy = _dev(x0), _dev(y0)
+    lib.call("plx_ssfm_propagate_dev", plan, ux.data_ptr(), uy.data_ptr(), F, torch.cuda.current_stream().cuda_stream)
+    _sync()
+    ncyc = np.zeros(F, np.int32); fd = np.zeros(F)
+    lib.call("plx_ssfm_results", plan, F, _vp(fd), _vp(ncyc))
+    lib.call("plx_ssfm_destroy", plan)
+    gx, gy = ux.cpu().numpy(), uy.cpu().numpy()
+    for f in range(F):
+        rc, ofd, onc, ox, oy = oracle.matrix_ssfm(x0[f][:, None], y0[f][:, None], c["t"]["betat"], c["t"]["db1"], c["dzm"], c["dph"],
+                                                  c["t"]["gam"], c["t"]["alphalin"], c["length"], c["nplates"], False, c["fls"],
+                                                  np.zeros(1), np.zeros(1), np.zeros(1))
+        assert rc == 0 and ncyc[f] == onc and fd[f] == pytest.approx(ofd, rel=1e-12), f
+        assert np.abs(gx[f] - ox[:, 0]).max() <= FIELD_RTOL * np.abs(ox).max(), f
+        assert np.abs(gy[f] - oy[:, 0]).max() <= FIELD_RTOL * np.abs(oy).max(), f
+    assert ncyc.max() > ncyc.min()                 # frames leave the list at different steps: the backward walk meets a shrinking list
+
+
 def test_batch_frames_keep_their_own_step_sequence(lib, oracle):
     """Frames of a batch (own launch power, own PMD draw) each follow the reference's step sequence."""
     import torch
