@@ -596,14 +596,20 @@ def main():
         hp.profile(False)              # (no HIP event between the launches)
         hp.fibre(sx.clone(), sy.clone())
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        hp.fibre(sx, sy)
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        hp.receive(sx, sy, noise_sigma=a.noise, noise_seed=4242)
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        single = {"fibre_ms": (t2 - t1) * 1e3, "rx_ms": (t3 - t2) * 1e3, "gsample_per_s": n / (t3 - t1) / 1e9}
+        best = None
+        for rep_ in range(3):          # (best of three: the first repetition after the campaign still finds the clocks low)
+            wx, wy = sx.clone(), sy.clone()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            hp.fibre(wx, wy)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            hp.receive(wx, wy, noise_sigma=a.noise, noise_seed=4242)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            if best is None or t3 - t1 < best[2]:
+                best = (t2 - t1, t3 - t2, t3 - t1)
+        single = {"fibre_ms": best[0] * 1e3, "rx_ms": best[1] * 1e3, "gsample_per_s": n / best[2] / 1e9, "repetitions": 3}
     # the same workload with the reference's OWN front end (receiver_cohmix + 5-bit ADC + decimate on the device) instead of the
     # harness's 2-sps pick: a short timed region of its own, reported beside the headline (never instead of it)
     cohmix_line = None
