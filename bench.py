@@ -56,7 +56,11 @@ def parse():
     ap.add_argument("--nsymb", type=int, default=1024)
     ap.add_argument("--nt", type=int, default=64)
     ap.add_argument("--pavg", type=float, default=2.0)
-    ap.add_argument("--flag", default="g-s-")
+    ap.add_argument("--flag", default=None, help="fiber() flag (default 'g-s-'; 'gps-' with --nch > 1: BASELINE config[2])")
+    ap.add_argument("--nch", type=int, default=1,
+                    help="channels per frame: N > 1 makes every frame a 'sepfields' WDM field of N columns (ex10_wdm.m:9-11) that share "
+                         "the step length (fiber.m:694-698); BASELINE config[2] is --nch 16 --spans 10 --nf 5 --frames 32")
+    ap.add_argument("--chspacing", type=float, default=0.4, help="channel spacing [nm] of the WDM comb (ex10_wdm.m: 0.4)")
     ap.add_argument("--variants", type=int, default=16, help="distinct Tx sequences cycled over the frames of a batch")
     ap.add_argument("--power-ladder", action="store_true",
                     help="frame f is launched at point f %% 64 of BASELINE config[4]'s ladder (-4...+8 dBm in equal dB steps): "
@@ -207,9 +211,14 @@ def cpu_params(cfg, hp, noise):
              symbolrate=cfg.symbolrate, lam=cfg.lam, disp=cfg.disp, slope=cfg.slope, fft_length=cfg.fft_length, cde_L=cfg.cde_L,
              power_mw=hp.power_mw, cma_mu=cfg.cma_mu, cma_taps=cfg.cma_taps, freqavg=cfg.freqavg, phasavg=cfg.phasavg,
              poworder=cfg.poworder, adcbits=cfg.adcbits, front=None, nspans=cfg.nspans, span_sigma=None)
+    if cfg.nch > 1:
+        p["tx_x"], p["tx_y"] = hp.tx_columns()
+        p["nplates"] = hp.nplates
     if cfg.span_nf_db is not None and cfg.nspans > 1:
         from polmux_amd.ampliflat import ase_sigma
-        p["span_sigma"] = float(ase_sigma(cfg.span_nf_db, math.exp(hp.alphalin * cfg.length), 1)[0])
+        hp.bind_gstate()
+        sg = ase_sigma(cfg.span_nf_db, math.exp(hp.alphalin * cfg.length), cfg.nch)
+        p["span_sigma"] = float(sg[0]) if cfg.nch == 1 else np.ascontiguousarray(sg, dtype=float)
     if hp.front is not None:
         p["front"] = hp.front_tables
         p["front_shifts"] = hp.front_shifts
@@ -221,6 +230,15 @@ def cpu_baseline(cfg, hp, nframes, noise):
     (frames of the batch, same receiver noise level): one core, then one frame stream per host core."""
     from oracle import cpu_chain
     p = cpu_params(cfg, hp, noise)
+    if cfg.nch > 1:
+        # a WDM frame of BASELINE config[2] is ~16 C1 frames x 10 spans of CPU work: the bounded sample is ONE frame through
+        # the first `k` spans (with amplifiers) + all of its receivers; the spans being alike, the frame's time is taken
+        # as t_fibre * nspans / k + t_rx
+        k = max(1, min(cfg.nspans, 1 if cfg.nfft * cfg.nch >= (1 << 20) else 2))
+        tf, tr, nc = cpu_chain.run_wdm_frame(p, k, 999)
+        est = tf * cfg.nspans / k + tr
+        return (cfg.nch * cfg.nfft / est / 1e9, tf + tr, nc, "one %d-channel frame: %d of its %d spans (%.1f s) + its %d receivers (%.1f s); "
+                "value = samples of the frame / (fibre time x %d / %d + receiver time)" % (cfg.nch, k, cfg.nspans, tf, cfg.nch, tr, cfg.nspans, k)), None
     dt, nc = cpu_chain.run_frames(p, nframes, 999)
     one = (nframes * cfg.nfft / dt / 1e9, dt, nc)
     cores = host_cores()
@@ -289,7 +307,7 @@ def gateway_bench(cfg, hp):
     # -- matrix_ssfm: one frame of this run through one span (fiber.m:372-389)
     gam, betat, db1 = hp._keep
     d = _abi.SsfmDesc()
-    d.nfft, d.nfc, d.dual_pol, d.max_frames = cfg.nfft, 1, 1, 1
+    d.nfft, d.nfc, d.dual_pol, d.max_frames = cfg.nfft, cfg.nch, 1, 1
     for i in range(4):
         d.fls[i] = hp.fls[i]
     d.dzmaxt, d.dphimaxt, d.alphalin, d.length = min(cfg.dzmax, cfg.length), cfg.dphimax, hp.alphalin, cfg.length
@@ -297,11 +315,11 @@ def gateway_bench(cfg, hp):
     d.gam, d.betat, d.db1 = gam.ctypes.data, betat.ctypes.data, db1.ctypes.data
     z = np.zeros(1)
     fd, nc = C.c_double(), C.c_int32()
-    tx, ty = hp.tx_host
+    tx, ty = hp.tx_columns() if cfg.nch > 1 else hp.tx_host
 
     def span():
-        uxr, uxi = np.ascontiguousarray(tx.real), np.ascontiguousarray(tx.imag)
-        uyr, uyi = np.ascontiguousarray(ty.real), np.ascontiguousarray(ty.imag)
+        uxr, uxi = np.asfortranarray(tx.real), np.asfortranarray(tx.imag)
+        uyr, uyi = np.asfortranarray(ty.real), np.asfortranarray(ty.imag)
         lib.call("plx_matrix_ssfm", uxr.ctypes.data, uxi.ctypes.data, uyr.ctypes.data, uyi.ctypes.data, C.byref(d), z.ctypes.data,
                  z.ctypes.data, z.ctypes.data, C.byref(fd), C.byref(nc))
     if not hp.pmd:
@@ -330,6 +348,11 @@ def workload_label(a, n):
     """config.workload from the ACTUAL arguments: which BASELINE configuration (if any) this line is."""
     what = ("28 Gbaud PDM-QPSK, 2^%d-sample dual-pol frame, %dx80 km SSMF span fiber('%s'), CDE_OFDE 256/128, CMA 7 taps + "
             "V&V carrier recovery; front end: %s" % (int(np.log2(n)), a.spans, a.flag, a.frontend))
+    if a.nch > 1:
+        what = "%d 'sepfields' channels %.2f nm apart per frame (shared dz, per-channel receivers), " % (a.nch, a.chspacing) + what
+        tag = "ex03/ex10-style WDM PDM-QPSK (BASELINE config[2]: 16 channels, 10x80 km nonlinear SSFM%s)" % (
+            "" if (a.nch == 16 and a.spans == 10) else "; this line: %d channels, %d span(s)" % (a.nch, a.spans))
+        return tag + ": " + what
     if a.mc:
         tag = "ex24_pmd-style random-PMD batch (BASELINE config[3] realisations in the timed region: fresh waveplates per frame and step)"
     elif n == 1 << 20 or a.spans > 1 or a.power_ladder:
@@ -343,16 +366,21 @@ def workload_label(a, n):
     return tag + ": " + what
 
 
-def offline_traffic(fused, F, n):
+def offline_traffic(fused, F, n, nch=1, flag="g-s-"):
     """HBM bytes per launch of the dominant kernel from the PMC counters.  Counters need their own rocprofv3 passes
     (FETCH_SIZE, WRITE_SIZE: MI355X_MICROARCH.md, HBM section), so this is NOT measured in this run: it is read from the
-    summary of scripts/traffic_pmc.sh on this round's build, if one is committed (2^16- and 2^20-sample frames)."""
-    for name in ("r03_traffic.json", "r02_traffic.json"):
+    summary of scripts/traffic_pmc.sh on this round's build, if one is committed (2^16- and 2^20-sample frames, and the
+    16-channel WDM frame of BASELINE config[2])."""
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         tj = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tj):
             continue
         tr = json.load(open(tj))
-        if n == 1 << 20:
+        if nch > 1:
+            tr = tr.get("wdm_%dch" % nch, {}) if (n == 65536 and flag == "gps-") else {}
+        elif flag != "g-s-":
+            return None, None
+        elif n == 1 << 20:
             tr = tr.get("frames_2pow20", {})
         elif n != 65536:
             return None, None
@@ -360,10 +388,12 @@ def offline_traffic(fused, F, n):
             tr = tr.get("plain_three_sweep", {})
         per = tr.get("bytes_per_sample_by_kernel")
         if not per:
+            if nch > 1:
+                continue
             return None, None
         k = "k_colx16" if fused else "k_col_fwd"
-        return per[k] * F * n, {"file": "profiles/" + name, "how": "offline rocprofv3 --pmc passes (not this run)",
-                                "bytes_per_sample_by_kernel": per}
+        return per[k] * F * nch * n, {"file": "profiles/" + name, "how": "offline rocprofv3 --pmc passes (not this run)",
+                                      "bytes_per_sample_by_kernel": per}
     return None, None
 
 
@@ -392,10 +422,13 @@ def main():
     lib.call("plx_set_device", local)
     cdev = "cpu" if (rehearsal or world == 1) else "cuda"        # where the collectives' tensors live
 
-    if a.mc:
+    if a.mc or (a.flag is None and a.nch > 1):
         a.flag = "gps-"
+    if a.flag is None:
+        a.flag = "g-s-"
+    nch = a.nch
     cfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag=a.flag, frontend=a.frontend, nspans=a.spans,
-                                 span_nf_db=a.nf, variants=a.variants)
+                                 span_nf_db=a.nf, variants=a.variants, nch=nch, chspacing=a.chspacing)
     F = a.frames
     hp = pipeline.HotPath(cfg, max_frames=F)
     hp.profile(True)          # a HIP event between consecutive launches of the step loop: per-kernel durations, live
@@ -405,7 +438,7 @@ def main():
     total = a.steps + a.warmup
     # (bounded by free HBM: with more steps than buffers a buffer is refilled from a pristine copy by one
     # device-to-device copy on the fibre stream -- inside the timed region, reported as "restaged_batches")
-    batch_bytes = 2 * F * n * 16
+    batch_bytes = 2 * F * nch * n * 16
     free_b, _tot = torch.cuda.mem_get_info()
     nbuf = max(2, min(total, int(0.6 * free_b // batch_bytes)))
     if os.environ.get("PLX_BENCH_NBUF"):      # dev: force the restaging path
@@ -473,7 +506,7 @@ def main():
                         ev.record(e2_, rx_stream.cuda_stream)
                         errs.append(err_.sum(0))
                         if a.mc:
-                            resolved.append(hp.errors_resolved(F).sum())
+                            resolved.append(hp.errors_resolved(F * nch).sum())
             except BaseException as exc:       # (reported by the main thread)
                 rx_fail.append(exc)
         rx_thread = threading.Thread(target=rx_worker, daemon=True)
@@ -499,11 +532,11 @@ def main():
                 with torch.cuda.stream(rx_stream):
                     errs.append(err.sum(0))
                     if a.mc:   # a blind receiver behind random birefringence: resolve pol swap + pi/2 ambiguity (ex20:160-173)
-                        resolved.append(hp.errors_resolved(F).sum())
+                        resolved.append(hp.errors_resolved(F * nch).sum())
             else:
                 errs.append(err.sum(0))
                 if a.mc:
-                    resolved.append(hp.errors_resolved(F).sum())
+                    resolved.append(hp.errors_resolved(F * nch).sum())
             if rx_stream is not None and nbuf < total:
                 buf_free[i % nbuf] = torch.cuda.Event()
                 buf_free[i % nbuf].record(rx_stream)
@@ -609,12 +642,13 @@ def main():
             t3 = time.perf_counter()
             if best is None or t3 - t1 < best[2]:
                 best = (t2 - t1, t3 - t2, t3 - t1)
-        single = {"fibre_ms": best[0] * 1e3, "rx_ms": best[1] * 1e3, "gsample_per_s": n / best[2] / 1e9, "repetitions": 3}
+        single = {"fibre_ms": best[0] * 1e3, "rx_ms": best[1] * 1e3, "gsample_per_s": nch * n / best[2] / 1e9, "repetitions": 3}
     # the same workload with the reference's OWN front end (receiver_cohmix + 5-bit ADC + decimate on the device) instead of the
     # harness's 2-sps pick: a short timed region of its own, reported beside the headline (never instead of it)
     cohmix_line = None
     if rank == 0 and world == 1 and a.frontend == "pick" and not a.mc and not a.no_cohmix_line and not a.power_ladder and a.spans == 1:
-        ccfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag=a.flag, frontend="cohmix", variants=a.variants)
+        ccfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag=a.flag, frontend="cohmix", variants=a.variants,
+                                      nch=nch, chspacing=a.chspacing)
         chp = pipeline.HotPath(ccfg, max_frames=F)
         csteps = max(2, min(4, a.steps))
         cb = [chp.make_batch(F) for _ in range(2)]
@@ -639,7 +673,7 @@ def main():
             cstep(i)
         torch.cuda.synchronize()
         cdt = time.perf_counter() - t1
-        cohmix_line = {"value": csteps * F * n / cdt / 1e9, "unit": "Gsample/s", "steps": csteps, "ms_per_step": cdt / csteps * 1e3,
+        cohmix_line = {"value": csteps * F * nch * n / cdt / 1e9, "unit": "Gsample/s", "steps": csteps, "ms_per_step": cdt / csteps * 1e3,
                        "front_end": "receiver_cohmix (optical filter, hybrids + balanced photodiodes, electrical filter) + %d-bit ADC + decimate "
                                     "to 2 sps on the device (RxPdmCohQpsk.m:36-72)" % ccfg.adcbits,
                        "note": "same batch size and fibre; two field buffers, restaged from a pristine copy inside the timed region"}
@@ -649,7 +683,7 @@ def main():
     if rank == 0 and world == 1 and not a.no_gateway:
         gateway = gateway_bench(cfg, hp)
     if rank == 0:
-        samples = float(world) * a.steps * F * n
+        samples = float(world) * a.steps * F * nch * n
         value = samples / dt / 1e9
         fused = hp.fused()
         # ---- roofline: the dominant kernel, priced with the bytes it REALLY moves per launch (one sweep over the batch:
@@ -663,23 +697,23 @@ def main():
                 avg_ms = k_ms[k] / k_n[k]
                 # with a power ladder the launches shrink as frames finish: bytes per launch = bytes of the frames still active
                 act = float(np.mean([(ncyc > s).sum() for s in range(int(ncyc.max()))])) if len(ncyc) else float(F)
-                gbs = SWEEP_BYTES * act * n / (avg_ms * 1e-3) / 1e9
+                gbs = SWEEP_BYTES * act * nch * n / (avg_ms * 1e-3) / 1e9
                 kern[names[k]] = {"avg_launch_us": avg_ms * 1e3, "active_launches": int(k_n[k]), "achieved_GBs": gbs,
                                   "frac_of_8TBs": gbs / HBM_PEAK_GBS}
         dom = max(kern, key=lambda k_: kern[k_]["avg_launch_us"] * kern[k_]["active_launches"]) if kern else names[0]
         sweeps = 2 if fused else 3
         group_bytes = SWEEP_BYTES * sweeps
         group_gbs = group_bytes * sample_steps / (fib * 1e-3) / 1e9
-        traffic, traffic_src = offline_traffic(fused, F, n) if a.flag == "g-s-" else (None, None)
+        traffic, traffic_src = offline_traffic(fused, F, n, nch, a.flag)
         active_frames = float(np.mean([(ncyc > s).sum() for s in range(int(ncyc.max()))])) if len(ncyc) else float(F)
         out = {
             "metric": "dual-pol Gsample/s through SSFM+Rx-DSP", "value": value, "unit": "Gsample/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_label(a, n),
-                       "frames_per_gpu_per_step": F, "nsymb": a.nsymb, "nt": a.nt, "pavg_mw": a.pavg,
+                       "frames_per_gpu_per_step": F, "channels_per_frame": nch, "nsymb": a.nsymb, "nt": a.nt, "pavg_mw": a.pavg,
                        "tx_variants": hp.nvar, "power_ladder": bool(a.power_ladder),
-                       "ssfm_steps_per_frame": sample_steps / (a.steps * F * n),
+                       "ssfm_steps_per_frame": sample_steps / (a.steps * F * nch * n),
                        "ssfm_steps_min_max": [int(ncyc.min()), int(ncyc.max())] if len(ncyc) else None,
                        # lock-step launches over frames with different trip counts (fiber.m:518): frame-steps with work / frame
                        # slots the workgroups iterated over (device active list, rebuilt before every step) / frame slots the
@@ -690,9 +724,10 @@ def main():
                        "rx_noise_sigma": a.noise,
                        "fibre_ms_per_step": fib / a.steps, "rxdsp_ms_per_step": rxm / a.steps,
                        "frames_per_s": float(world) * a.steps * F / dt, "fresh_pmd_per_realisation": bool(a.mc),
+                       "fused_grid_workgroups": hp.info()[3], "column_tiles_per_frame": hp.info()[4],
                        "bit_errors_xy": err_total.cpu().tolist(),
                        "bit_errors_resolved": int(res_total.item()) if a.mc else None,
-                       "bits": int(world) * a.steps * F * 4 * a.nsymb, "restaged_batches": restaged,
+                       "bits": int(world) * a.steps * F * nch * 4 * a.nsymb, "restaged_batches": restaged,
                        "rehearsal_all_ranks_on_one_gpu": bool(rehearsal),
                        "single_frame": single,
                        "with_reference_front_end": cohmix_line},
@@ -701,7 +736,7 @@ def main():
             "roofline": {"bound": "fp64-valu" if (dom == row_kernel and hp.pmd) else "hbm", "kernel": dom,
                          "achieved": kern.get(dom, {}).get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern.get(dom, {}).get("frac_of_8TBs"),
-                         "algorithmic_bytes_per_launch": SWEEP_BYTES * active_frames * n,
+                         "algorithmic_bytes_per_launch": SWEEP_BYTES * active_frames * nch * n,
                          "bytes_per_sample_per_launch": SWEEP_BYTES,
                          "avg_launch_us": kern.get(dom, {}).get("avg_launch_us"),
                          "traffic": traffic, "traffic_source": traffic_src,
@@ -726,9 +761,11 @@ def main():
             "gateway": gateway,
         }
         if not a.no_cpu_baseline and world == 1:      # a reported baseline, timed at N = 1 only
-            (v, cdt, nc), allc = cpu_baseline(cfg, hp, a.cpu_frames, a.noise)
+            one, allc = cpu_baseline(cfg, hp, a.cpu_frames, a.noise)
+            v, cdt, nc = one[:3]
             out["cpu_baseline"] = {"value": v, "unit": "Gsample/s", "cores": 1, "kind": "port",
-                                   "sample": "%d frame(s) of the same batch through oracle/ (fibre %d steps + front end + noise + "
+                                   "sample": one[3] if len(one) > 3 else
+                                             "%d frame(s) of the same batch through oracle/ (fibre %d steps + front end + noise + "
                                              "CDE + CMA + CPE), %.1f s" % (a.cpu_frames, nc, cdt)}
             if allc is not None:
                 va, busiest, wall, cores, per = allc

@@ -59,6 +59,48 @@ def run_frames(p, nframes, seed):
     return time.perf_counter() - t0, nc
 
 
+def run_wdm_frame(p, spans, seed):
+    """One 'sepfields' WDM frame (BASELINE config[2]: tx_x / tx_y [nfft x nch], shared step length fiber.m:694-698) through
+    `spans` of its p["nspans"] spans with the in-line amplifiers, then EVERY channel through the receiver chain.
+    Returns (seconds in the fibre spans, seconds in the receivers, ncycle summed over the spans done)."""
+    from oracle import plxo
+    r = np.random.default_rng(seed)
+    ox, oy = p["tx_x"], p["tx_y"]
+    nch = ox.shape[1]
+    nc = 0
+    t0 = time.perf_counter()
+    for span in range(spans):
+        nplates, db0, th, ep = 1, [0.0], [0.0], [0.0]
+        if p["fls"][1]:                  # fiber.m:274-276
+            nplates = int(p["nplates"])
+            db0 = r.random(nplates) * 2 * np.pi - np.pi
+            th = r.random(nplates) * np.pi - 0.5 * np.pi
+            ep = 0.5 * np.arcsin(r.random(nplates) * 2 - 1)
+        rc, fd, k, ox, oy = plxo.matrix_ssfm(ox, oy, p["betat"], p["db1"], p["dzmax"], p["dphimax"], p["gam"],
+                                             p["alphalin"], p["length"], nplates, 0, p["fls"], db0, th, ep)
+        nc += k
+        g = np.exp(p["alphalin"] * p["length"])                       # in-line amplifier, ampliflat.m:123-143
+        ox, oy = np.sqrt(g) * ox, np.sqrt(g) * oy
+        if p.get("span_sigma") is not None:
+            sg = np.asarray(p["span_sigma"]).reshape(1, -1)
+            ox = ox + sg * (r.standard_normal(ox.shape) + 1j * r.standard_normal(ox.shape))
+            oy = oy + sg * (r.standard_normal(oy.shape) + 1j * r.standard_normal(oy.shape))
+    t1 = time.perf_counter()
+    half = p["nt"] // 2
+    g = np.exp(-0.5 * p["alphalin"] * p["length"])                    # (the loop amplified the last span too: rx_scale undoes its loss itself)
+    for c in range(nch):
+        rx = np.stack([ox[::half, c], oy[::half, c]], 1) * (p["rx_scale"] * g)
+        if p["noise"]:
+            rx = rx + p["noise"] * (r.standard_normal(rx.shape) + 1j * r.standard_normal(rx.shape))
+        ex, ey, _ = plxo.cde_ofde(rx[:, 0], rx[:, 1], 2 * p["symbolrate"] * 1e9, p["lam"] * 1e-9, p["length"] * int(p.get("nspans", 1)), p["disp"] * 1e-6,
+                                  p["slope"] * 1e-6, p["fft_length"], p["cde_L"])
+        op = plxo.dsp_params(power_mw=p["power_mw"], applypol=True, polmethod="cma", cma_mu=p["cma_mu"], cma_taps=p["cma_taps"],
+                             freqavg=p["freqavg"], phasavg=p["phasavg"], poworder=p["poworder"])
+        sym = plxo.dsp_pdm_coh_qpsk(np.stack([ex, ey], 1), op)
+        plxo.samp2pat_coherent(np.angle(sym))
+    return t1 - t0, time.perf_counter() - t1, nc
+
+
 def run_parallel(p, frames_per_core, cores, timeout_s=180.0):
     """One child process per core (`python -m oracle.cpu_chain params.npz n seed`: fresh interpreters that never see the
     parent's GPU state), each running frames_per_core frames.  Returns (wall seconds, busiest child's compute seconds)

@@ -37,7 +37,7 @@ class HotPathConfig:
                  dgd=0.1, nplates=100, manakov="no", nspans=1, fft_length=256, cde_L=128, applypol=True,
                  polmethod="cma", cma_taps=7, cma_mu=1 / 6000, freqavg=500, phasavg=3, poworder=2,
                  frontend="pick", oftype="gauss", obw=1.9, oord=3, eftype="bessel5", ebw=0.65, eord=4, lopower=0.0,
-                 adcbits=5, span_nf_db=None, rx_amp=False, variants=1):
+                 adcbits=5, span_nf_db=None, rx_amp=False, variants=1, nch=1, chspacing=0.4):
         """frontend: 'pick' = 2-sps sampling supplied by the harness; 'cohmix' = the reference's own
         receiver_cohmix + ADC + decimate chain (RxPdmCohQpsk.m, Run_my_PDM_QPSK.m:52-73 defaults) on the device.
         nspans > 1: every span but the last is followed by an in-line flat amplifier restoring its loss
@@ -46,7 +46,11 @@ class HotPathConfig:
         well (gain = span loss, ASE from span_nf_db), the `fiber(...); ampliflat(Gerbio,'gain',ampli)` of
         ex20_coherent_polmux.m:147-148 / ex24_pmd.m:86-87, and the receiver sees the amplified, noise-loaded field.
         variants: number of distinct Tx waveforms (de Bruijn seed pairs s+1, s+2 as Run_my_PDM_QPSK.m:104-105 does per
-        channel); frame f carries variant f % variants, with its own transmitted bits for the error count."""
+        channel); frame f carries variant f % variants, with its own transmitted bits for the error count.
+        nch > 1: a frame is a 'sepfields' WDM field of nch columns (create_field.m:17-18, ex10_wdm.m:9-11; BASELINE
+        config[2]) chspacing nm apart around lam: the channels share the step length (fiber.m:694-698) and each keeps its
+        own walk-off and gamma (fiber.m:326-328); channel c of frame f carries variant (f nch + c) % variants, and every
+        channel has its own receiver (receiver_cohmix.m:104-125 picks the column)."""
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -64,21 +68,23 @@ class HotPath:
         self.lib = _abi.get()
         self.dev = torch.device("cuda", torch.cuda.current_device())
         n = cfg.nfft
+        nch = self.nch = int(cfg.nch)
+        self.CF = self.F * nch                           # channel-frames: what the receiver's plans count
         # --- host side of fiber(): flag, conversions, tables (fiber.m:157-362) ---
-        GSTATE.NSYMB, GSTATE.NT, GSTATE.NCH = cfg.nsymb, cfg.nt, 1
+        GSTATE.NSYMB, GSTATE.NT, GSTATE.NCH = cfg.nsymb, cfg.nt, nch
         GSTATE.SYMBOLRATE = cfg.symbolrate
         GSTATE.FN = synth.fn_grid(cfg.nsymb, cfg.nt)
-        GSTATE.LAMBDA = np.array([cfg.lam])
+        GSTATE.LAMBDA = cfg.lam + cfg.chspacing * (np.arange(nch) - (nch - 1) / 2)      # lasersource.m: equally spaced comb
         x = {"length": cfg.length, "alphadB": cfg.alphadB, "aeff": cfg.aeff, "n2": cfg.n2, "lambda": cfg.lam,
              "disp": cfg.disp, "slope": cfg.slope, "dphimax": cfg.dphimax, "dzmax": min(cfg.dzmax, cfg.length)}
-        self.fls, dphimaxt, dzmaxt = parse_flag(cfg.flag, 1, x)
+        self.fls, dphimaxt, dzmaxt = parse_flag(cfg.flag, nch, x)
         self.pmd = self.fls[1] == 1
         nplates = cfg.nplates if self.pmd else 1
         dgdrms = math.sqrt(3 * math.pi / 8) * cfg.dgd / math.sqrt(nplates) if self.pmd else 0.0   # fiber.m:277
-        t = fiber_tables(x, self.fls, 1, dgdrms)
+        t = fiber_tables(x, self.fls, nch, dgdrms)
         self.alphalin = t["alphalin"]
         d = _abi.SsfmDesc()
-        d.nfft, d.nfc, d.dual_pol, d.max_frames = n, 1, 1, self.F
+        d.nfft, d.nfc, d.dual_pol, d.max_frames = n, nch, 1, self.F
         for i in range(4):
             d.fls[i] = self.fls[i]
         d.dzmaxt, d.dphimaxt, d.alphalin, d.length = dzmaxt, dphimaxt, t["alphalin"], cfg.length
@@ -96,7 +102,7 @@ class HotPath:
         self.tx_host = (ux, uy)
         self.bits = bits
         self.power_mw = power
-        GSTATE.POWER = np.array([power])
+        GSTATE.POWER = np.full(nch, power)
         self.tx = torch.from_numpy(np.stack([ux, uy])).to(self.dev)          # [2, n]
         self.pat = torch.from_numpy(np.ascontiguousarray(bits.T.astype(np.uint8))).to(self.dev)   # [4, nsymb]
         # further Tx waveforms (other de Bruijn seeds): heterogeneous batches whose frames differ in data
@@ -110,7 +116,7 @@ class HotPath:
         if self.nvar > 1:
             self.tx_var = torch.from_numpy(np.stack([np.stack([v[0], v[1]]) for v in self.var_host])).to(self.dev)   # [V, 2, n]
             pv = np.stack([np.ascontiguousarray(v[2].T.astype(np.uint8)) for v in self.var_host])               # [V, 4, nsymb]
-            self.pat_frames = torch.from_numpy(pv[np.arange(self.F) % self.nvar].copy()).to(self.dev)          # [F, 4, nsymb]
+            self.pat_frames = torch.from_numpy(pv[np.arange(self.CF) % self.nvar].copy()).to(self.dev)         # [F nch, 4, nsymb]
         self.rx_gain = None                              # per-frame receiver scale of a launch-power ladder (make_batch)
         # --- Rx plans ---
         self.Lrx = 2 * cfg.nsymb
@@ -126,7 +132,7 @@ class HotPath:
                    phasavg=cfg.phasavg, poworder=cfg.poworder)
         self.dsp_p = dsp_params_struct(dsp, power)
         self.dsp = C.c_void_p()
-        self.lib.call("plx_dsp_create", C.byref(self.dsp), self.Lrx, 2, self.F, C.byref(self.dsp_p))
+        self.lib.call("plx_dsp_create", C.byref(self.dsp), self.Lrx, 2, self.CF, C.byref(self.dsp_p))
         # receive scale: undo the span loss and bring symbols to the 4*sqrt(P) full scale that
         # DspPdmCohQpsk divides by (DspPdmCohQpsk.m:22-23, "2* -> see receiver_cohmix")
         self.rx_scale = 4.0 * math.sqrt(power) / math.sqrt(power / 2.0)
@@ -137,7 +143,7 @@ class HotPath:
             from . import rxfront
             rp = dict(oftype=cfg.oftype, obw=cfg.obw, oord=cfg.oord, eftype=cfg.eftype, ebw=cfg.ebw, eord=cfg.eord,
                       lopower=cfg.lopower)
-            hopt, elo, hel, post_delay, _ = rxfront._front_tables(1, rp, nfc=1)
+            hopt, elo, hel, post_delay, _ = rxfront._front_tables(1, rp, nfc=nch)
             # in-line amplifier restoring the span loss, folded into the optical filter table (no extra sweep)
             if not cfg.rx_amp:
                 hopt = hopt * math.exp(0.5 * self.alphalin * cfg.length)
@@ -145,14 +151,14 @@ class HotPath:
             delay = rxfront.evaldelay(cfg.oftype, cfg.obw * 0.5) + rxfront.evaldelay(cfg.eftype, cfg.ebw) + post_delay
             self.front_shifts = [rxfront._mround(-delay * cfg.nt)] * 2         # 'theory' delay, RxPdmCohQpsk.m:124-137
             self.front_tables = dict(hopt=hopt, elo=elo, hel=hel, fir=rxfront.fir1_lowpass(16, 1.0 / r), decim=r)
-            self.front = rxfront._Front(n, True, self.F, hopt, elo, hel, True, cfg.adcbits, r, self.front_tables["fir"])
+            self.front = rxfront._Front(n, True, self.CF, hopt, elo, hel, True, cfg.adcbits, r, self.front_tables["fir"])
         elif cfg.frontend != "pick":
             raise ValueError("frontend must be 'pick' or 'cohmix'")
         c128 = torch.complex128
-        self.rx = torch.empty((self.F, 2, self.Lrx), dtype=c128, device=self.dev)
+        self.rx = torch.empty((self.CF, 2, self.Lrx), dtype=c128, device=self.dev)
         self.eq = torch.empty_like(self.rx)
-        self.sym = torch.empty((self.F, 2, cfg.nsymb), dtype=c128, device=self.dev)
-        self.err = torch.zeros((self.F, 2), dtype=torch.int64, device=self.dev)
+        self.sym = torch.empty((self.CF, 2, cfg.nsymb), dtype=c128, device=self.dev)
+        self.err = torch.zeros((self.CF, 2), dtype=torch.int64, device=self.dev)
 
     def close(self):
         for name, h in (("plx_ssfm_destroy", self.ssfm), ("plx_cde_destroy", self.cde), ("plx_dsp_destroy", self.dsp)):
@@ -165,23 +171,28 @@ class HotPath:
 
     # ------------------------------------------------------------------ inputs ---
     def make_batch(self, nframes, launch_scale=None):
-        """Synthetic inputs -> (ux, uy), each [F, n] complex128: frame f carries Tx waveform f % variants, with an
-        optional per-frame launch-power scaling (power sweep; the receiver then normalises each frame by its own
-        launch power, as a per-run GSTATE.POWER does in DspPdmCohQpsk.m:22-23)."""
+        """Synthetic inputs -> (ux, uy), each [F, n] complex128 ([F, nch, n] for 'sepfields' WDM frames): channel c of
+        frame f carries Tx waveform (f nch + c) % variants, with an optional per-frame launch-power scaling (power sweep;
+        the receiver then normalises each frame by its own launch power, as a per-run GSTATE.POWER does in
+        DspPdmCohQpsk.m:22-23)."""
         torch = self.torch
+        nch, n = self.nch, self.cfg.nfft
+        ncf = nframes * nch
         if self.nvar > 1:
-            idx = torch.arange(nframes, device=self.dev) % self.nvar
+            idx = torch.arange(ncf, device=self.dev) % self.nvar
             ux = self.tx_var[idx, 0].contiguous()
             uy = self.tx_var[idx, 1].contiguous()
         else:
-            ux = self.tx[0].unsqueeze(0).repeat(nframes, 1).contiguous()
-            uy = self.tx[1].unsqueeze(0).repeat(nframes, 1).contiguous()
+            ux = self.tx[0].unsqueeze(0).repeat(ncf, 1).contiguous()
+            uy = self.tx[1].unsqueeze(0).repeat(ncf, 1).contiguous()
         self.rx_gain = None
         if launch_scale is not None:
-            ls = np.asarray(launch_scale, dtype=float).reshape(-1)
+            ls = np.repeat(np.asarray(launch_scale, dtype=float).reshape(-1), nch)
             k = torch.as_tensor(np.sqrt(ls), device=self.dev).reshape(-1, 1)
             ux, uy = ux * k, uy * k
-            self.rx_gain = torch.as_tensor(1.0 / np.sqrt(ls), device=self.dev).reshape(-1, 1, 1)
+            self.rx_gain = torch.as_tensor(1.0 / np.sqrt(ls), device=self.dev).reshape(-1, 1, 1)   # per channel-frame
+        if nch > 1:
+            ux, uy = ux.view(nframes, nch, n), uy.view(nframes, nch, n)
         return ux, uy
 
     def set_random_pmd(self, seeds):
@@ -208,7 +219,7 @@ class HotPath:
         return self.torch.cuda.current_stream().cuda_stream
 
     def fibre(self, ux, uy, span_keys=None, inject_noise=None):
-        """ux, uy: [F, n] complex128 device tensors ([frame][channel=1][nfft]), propagated in place.
+        """ux, uy: [F, n] (or [F, nch, n]) complex128 device tensors ([frame][channel][nfft]), propagated in place.
         span_keys: per-frame keys of the amplifiers' ASE streams (realisation indices).  inject_noise: optional list,
         one entry per amplifier, of [F, 2, n] complex128 device tensors used INSTEAD of the device generator
         (ampliflat's options.noise, ampliflat.m:123-129: the parity route)."""
@@ -227,12 +238,12 @@ class HotPath:
                 sig = None
                 if cfg.span_nf_db is not None:
                     from .ampliflat import ase_sigma
-                    sig = np.ascontiguousarray(ase_sigma(cfg.span_nf_db, gain, 1), dtype=float)
+                    sig = np.ascontiguousarray(ase_sigma(cfg.span_nf_db, gain, self.nch), dtype=float)
                 kt = None
                 if span_keys is not None:
                     kt = self.torch.as_tensor(np.asarray(list(span_keys), dtype=np.int64), device=self.dev)
                 inj = inject_noise[namp] if inject_noise is not None else None
-                self.lib.call("plx_ampliflat_dev", ux.data_ptr(), uy.data_ptr(), cfg.nfft, 1, F, gain,
+                self.lib.call("plx_ampliflat_dev", ux.data_ptr(), uy.data_ptr(), cfg.nfft, self.nch, F, gain,
                               sig.ctypes.data if sig is not None else None, inj.data_ptr() if inj is not None else None,
                               (20260101 + 7919 * span) & (2 ** 64 - 1),
                               kt.data_ptr() if kt is not None else None, 1, 1, self.stream())
@@ -254,11 +265,13 @@ class HotPath:
             side_stream.wait_event(ready)
             with torch.cuda.stream(side_stream):
                 return self.receive(ux, uy, noise_sigma, noise_seed, None, noise_keys)
-        F = ux.shape[0]
+        F = ux.shape[0] * self.nch             # channel-frames: every channel of a 'sepfields' frame has its own receiver
         cfg = self.cfg
         half = cfg.nt // 2
         st = self.stream()
         rx = self.rx[:F]
+        if self.nch > 1:
+            ux, uy = ux.view(F, cfg.nfft), uy.view(F, cfg.nfft)
         if self.front is not None:             # receiver_cohmix + ADC + decimate; ux, uy are consumed
             if self.rx_gain is not None:       # launch-power ladder: each frame normalised by its own power
                 ux.mul_(self.rx_gain[:F, :, 0])
@@ -372,10 +385,28 @@ class HotPath:
         self.lib.call("plx_ssfm_utilisation", self.ssfm, *[C.byref(x) for x in v])
         return tuple(x.value for x in v)
 
-    def fused(self):
+    def info(self):
+        """plx_ssfm_info of the fibre plan: [fused, log2 N1, log2 N2, fused grid, column tiles per frame, ...]"""
         info = (C.c_int32 * 8)()
         self.lib.call("plx_ssfm_info", self.ssfm, info)
-        return bool(info[0])
+        return list(info)
+
+    def fused(self):
+        return bool(self.info()[0])
+
+    def bind_gstate(self):
+        """GSTATE as this plan's grid and comb need it (another HotPath built meanwhile has set its own)."""
+        cfg = self.cfg
+        GSTATE.NSYMB, GSTATE.NT, GSTATE.NCH = cfg.nsymb, cfg.nt, self.nch
+        GSTATE.SYMBOLRATE = cfg.symbolrate
+        GSTATE.FN = synth.fn_grid(cfg.nsymb, cfg.nt)
+        GSTATE.LAMBDA = cfg.lam + cfg.chspacing * (np.arange(self.nch) - (self.nch - 1) / 2)
+        GSTATE.POWER = np.full(self.nch, self.power_mw)
+
+    def tx_columns(self):
+        """Tx field of ONE frame as MATLAB holds it: (ux, uy), each [nfft x nch] (column c = variant c % variants)"""
+        cols = [self.var_host[c % self.nvar] for c in range(self.nch)]
+        return (np.asfortranarray(np.stack([c[0] for c in cols], 1)), np.asfortranarray(np.stack([c[1] for c in cols], 1)))
 
     def row_kernel(self):
         """name of the kernel that serves the step's row pass (for reports)"""
