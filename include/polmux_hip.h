@@ -45,6 +45,7 @@ extern "C" {
 #define PLX_ERR_ARG (-2)       /* bad argument (message mirrors the reference)      */
 #define PLX_ERR_UNSUPPORTED (-3)
 #define PLX_ERR_REFERENCE (-4) /* the reference itself raises here, e.g. fiber.m:854 */
+#define PLX_ERR_TIMEOUT (-5)   /* a frame barrier of the fused sweep timed out: another kernel holds the GPU (see plx_ssfm_propagate_dev) */
 
 const char *plx_last_error(void);
 /* ABI version of this header: major*1000 + minor */
@@ -60,6 +61,9 @@ int plx_set_device(int device);
  * repeated call allocates nothing.                                                                               */
 int plx_release_all(void);
 int plx_gateway_stats(int64_t *out);
+/* the same with room for later counters: fills min(n, 9) entries; out[8] = gateway propagations that were repeated on the
+ * barrier-free three-sweep step after a frame-barrier time-out (another kernel held part of the GPU)                  */
+int plx_gateway_stats_ex(int64_t *out, int n);
 
 /* ------------------------------------------------------------------ fastexp --- */
 /* fastexp.c:37-47 / fastexp.m:28: y = cos(x) + i*sin(x), x real [m x n].           */
@@ -90,6 +94,11 @@ typedef struct plx_ssfm_desc {
 typedef struct plx_ssfm plx_ssfm;
 
 int plx_ssfm_create(plx_ssfm **plan, const plx_ssfm_desc *desc);
+/* flags: PLX_SSFM_SHARE_DEVICE -- the plan takes the barrier-free three-sweep step (no workgroup of it ever waits for
+ * another one): for processes that share a GPU, and for plans that propagate beside a long-running kernel of another
+ * stream (a one-team plan -- plx_ssfm_info: info[4] == info[3] -- whose receiver runs beside the next batch's fibre). */
+#define PLX_SSFM_SHARE_DEVICE 1u
+int plx_ssfm_create_ex(plx_ssfm **plan, const plx_ssfm_desc *desc, uint32_t flags);
 int plx_ssfm_destroy(plx_ssfm *plan);
 /* brf.db0/theta/epsilon (fiber.m:266-276): host arrays [nplates x nsets]; set s is
  * used by frame f = s (nsets == 1: shared by all frames).                          */
@@ -115,13 +124,25 @@ int plx_ssfm_set_birefringence_dev(plx_ssfm *plan, const double *db0, const doub
  * frame does not fit the chip that way the plan takes the barrier-free three-sweep
  * step.  If another long-running kernel holds the device (two processes on one GPU, a
  * second plan propagating at the same time), a barrier that cannot complete within
- * 0.5 s raises a sticky abort: nothing is stored or advanced after it and the call
- * returns PLX_ERR_HIP ("frame barrier timed out"); PLX_SSFM_NO_FUSE=1 at plan creation
- * selects the barrier-free sweeps for such deployments.  Short kernels of another stream
+ * 0.5 s raises a sticky abort: nothing is stored or advanced after it, the call returns
+ * PLX_ERR_TIMEOUT and the field of THAT call is invalid (it was propagated in place up to
+ * the time-out); the plan switches itself to the barrier-free three-sweep step, so the
+ * caller restores the field and calls again (the gateway calls plx_matrix_ssfm /
+ * plx_scalar_ssfm do exactly that from their staging copy and return success).
+ * plx_ssfm_create_ex(..., PLX_SSFM_SHARE_DEVICE) selects that step from the start for
+ * such deployments.  Short kernels of another stream
  * of the same process are harmless as long as one frame takes at most half of the grid
  * (plx_ssfm_info: 2 * info[4] <= info[3]); larger frames (2^19, 2^20 samples) should have
  * the device to themselves while they propagate.                                     */
 int plx_ssfm_propagate_dev(plx_ssfm *plan, double *d_ux, double *d_uy, int nframes, void *stream);
+/* Diagnostics for parity work on ill-conditioned step sequences (noise-loaded WDM fields: the step rule fiber.m:682-715
+ * amplifies rounding differences).  set_step_sequence: the step length nextstep would return for step k (0-based) is
+ * replaced by dz[k] for k < nsteps, for every frame of later propagate calls (nsteps 0: off); the loop around it
+ * (fiber.m:512-551: zprop, the last-step rule) is unchanged.  log_steps(max_steps > 0): later propagate calls record
+ * every frame's step lengths; step_sequence copies frame f's first max_steps of them out (ncycle of them are valid). */
+int plx_ssfm_set_step_sequence(plx_ssfm *plan, const double *dz, int nsteps);
+int plx_ssfm_log_steps(plx_ssfm *plan, int max_steps);
+int plx_ssfm_step_sequence(plx_ssfm *plan, int frame, double *dz, int max_steps);
 /* per-frame results of the last propagate: firstdz, ncycle (fiber.m:431)           */
 int plx_ssfm_results(plx_ssfm *plan, int nframes, double *firstdz, int32_t *ncycle);
 /* kernel-time accounting of the last propagate: launches of the dominant
@@ -202,6 +223,21 @@ int plx_cmaadaptivefilter_m(const double *xr, const double *xi, int32_t Mdim, do
                             double *h2r, double *h2i, int32_t ntap, double mu, const double *R, double *yr, double *yi);
 int plx_easiadaptivefilter_m(const double *xr, const double *xi, int32_t Mdim, double *h1r, double *h1i,
                              double *h2r, double *h2i, int32_t ntap, double mu, double *yr, double *yi);
+
+/* y = cmapolardemux(x, params) / y = easipolardemux(x, params) as ONE gateway call: the driver loops of
+ * DspPdmCohQpsk.m:142-192 / :195-244 (== dsp4cohdec.m:374-425 / :427-478) -- cyclic extension, centre taps set from M,
+ * up to 50*ceil(1/(L*mu)) - 1 (CMA) or 20*ceil(1/(L*mu)) - 1 (EASI) passes, the 5e-5 convergence test -- run on the
+ * device; the unchanged per-pass MEX costs a PCIe round trip per pass (up to 299 per frame).  x [L x 2] split planes
+ * (xi may be NULL); M: the initial centre-tap matrix the driver forms at :146-160 from params.mat / params.phizero / the
+ * single-polarisation ratio, row-major 2x2 complex as 8 doubles (re,im); R = params.R [2], mu = params.mu, taps =
+ * params.taps.  y [L x 2] split planes; optional: final taps h1, h2 [taps x 2] planes, passes made.  mfile_twin (EASI):
+ * the loop around the .m twin of the filter (easiadaptivefilter.m:51-84) instead of the C (the CMA twins coincide under
+ * the drivers' sps = 1).  Errors as the filter gateways: "Ntaps should be an ODD INTEGER."                              */
+int plx_cmapolardemux(const double *xr, const double *xi, int64_t L, int32_t taps, double mu, const double *R,
+                      const double *M, double *yr, double *yi, double *h1r, double *h1i, double *h2r, double *h2i,
+                      int32_t *passes);
+int plx_easipolardemux(const double *xr, const double *xi, int64_t L, double mu, const double *M, int32_t mfile_twin,
+                       double *yr, double *yi, double *h1r, double *h1i, double *h2r, double *h2i, int32_t *passes);
 
 /* resident, batched pol-demux driver: cmapolardemux / easipolardemux
  * (DspPdmCohQpsk.m:142-244 == dsp4cohdec.m:374-478): cyclic extension, centre-tap

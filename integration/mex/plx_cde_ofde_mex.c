@@ -5,9 +5,10 @@
 static double *plane_or_zeros(const mxArray *a, size_t n) { double *p = mxGetPi(a); return p ? p : (double *)mxCalloc(n, sizeof(double)); }
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
-    plx_mex_once();
     (void)nlhs;
+    if (plx_mex_release_request(nrhs, prhs)) return;
     if (nrhs != 9) mexErrMsgTxt("Nine inputs required.");
+    plx_mex_once();
     size_t nx = mxGetNumberOfElements(prhs[0]);
     plhs[0] = mxCreateDoubleMatrix(nx, 1, mxCOMPLEX);
     plhs[1] = mxCreateDoubleMatrix(nx, 1, mxCOMPLEX);

@@ -14,9 +14,10 @@ static mxArray *complex_copy(const mxArray *a)
 }
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
-    plx_mex_once();
     (void)nlhs;
+    if (plx_mex_release_request(nrhs, prhs)) return;
     if (nrhs != 7) mexErrMsgTxt("Seven inputs required.");
+    plx_mex_once();
     int Mdim = (int)mxGetM(prhs[0]), ntap = (int)mxGetM(prhs[1]);
     double mu = mxGetScalar(prhs[4]);
     int L = Mdim - ntap + 1;

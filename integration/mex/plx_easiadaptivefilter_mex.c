@@ -9,9 +9,10 @@ static double *imag_plane(const mxArray *a, size_t n)
 }
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
-    plx_mex_once();
     (void)nlhs;
+    if (plx_mex_release_request(nrhs, prhs)) return;
     if (nrhs != 6) mexErrMsgTxt("Six inputs required.");
+    plx_mex_once();
     int Mdim = (int)mxGetM(prhs[0]), Npol = (int)mxGetN(prhs[0]);
     double Ntap = mxGetScalar(prhs[3]), mu = mxGetScalar(prhs[4]), sps = mxGetScalar(prhs[5]);
     double *xi = imag_plane(prhs[0], (size_t)Mdim * Npol);

@@ -5,9 +5,10 @@
 #include <string.h>
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
-    plx_mex_once();
     (void)nlhs;
+    if (plx_mex_release_request(nrhs, prhs)) return;
     if (nrhs != 16) mexErrMsgTxt("Sixteen inputs required.");
+    plx_mex_once();
     plx_ssfm_desc d;
     memset(&d, 0, sizeof(d));
     d.nfft = (int64_t)mxGetM(prhs[0]); d.nfc = (int32_t)mxGetN(prhs[0]); d.dual_pol = 1; d.max_frames = 1;

@@ -5,9 +5,10 @@
 #include <string.h>
 void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[])
 {
-    plx_mex_once();
     (void)nlhs;
+    if (plx_mex_release_request(nrhs, prhs)) return;
     if (nrhs != 10) mexErrMsgTxt("Ten inputs required.");
+    plx_mex_once();
     plx_front_desc d;
     memset(&d, 0, sizeof(d));
     d.nfft = (int64_t)mxGetNumberOfElements(prhs[0]);

@@ -70,6 +70,11 @@ int plxo_matrix_ssfm(plxo_c *ux, plxo_c *uy, const double *betat,
                      double Lf, int nplates, int manakov, const int *fls,
                      const double *db0, const double *theta,
                      const double *epsilon, double *firstdz, int *ncycle);
+/* test diagnostics: record the step lengths nextstep returns inside plxo_matrix_ssfm (fiber.m:512, :534) */
+void plxo_set_step_log(double *buf, int cap);
+int plxo_step_log_count(void);
+/* test diagnostics: step k of the next plxo_matrix_ssfm call takes dz[k] instead of nextstep's result (k < n) */
+void plxo_set_step_replay(const double *dz, int n);
 int plxo_scalar_ssfm(plxo_c *u, const double *betat, double dzmaxt,
                      double dphimaxt, const double *gam, double alphalin,
                      long nfft, int nfc, double Lf, const int *fls, int tolflag,

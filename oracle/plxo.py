@@ -147,8 +147,9 @@ def matrix_step(betat, db1, dzb, ux, uy, db0, theta, epsilon, lcorr, ntot, nmem)
 
 
 def matrix_ssfm(ux, uy, betat, db1, dzmaxt, dphimaxt, gam, alphalin, Lf, nplates, manakov, fls,
-                db0, theta, epsilon):
-    """fiber.m:459-554.  Returns (rc, firstdz, ncycle, ux, uy)."""
+                db0, theta, epsilon, return_dz=False, replay_dz=None):
+    """fiber.m:459-554.  Returns (rc, firstdz, ncycle, ux, uy) and, with return_dz, the list of the step lengths nextstep
+    returned (fiber.m:512, :534: ncycle of them).  replay_dz: step k takes replay_dz[k] instead of nextstep's result."""
     ux, uy = _shape2(ux), _shape2(uy)
     nfft, nfc = ux.shape
     b = _d(betat).reshape(nfft, nfc, order="F")
@@ -157,10 +158,23 @@ def matrix_ssfm(ux, uy, betat, db1, dzmaxt, dphimaxt, gam, alphalin, Lf, nplates
     db0, theta, epsilon = _d(np.atleast_1d(db0)), _d(np.atleast_1d(theta)), _d(np.atleast_1d(epsilon))
     first = C.c_double(0)
     ncyc = C.c_int(0)
+    log = np.zeros(1 << 16) if return_dz else None
+    rp = None
+    if replay_dz is not None:
+        rp = _d(np.atleast_1d(replay_dz))
+        lib().plxo_set_step_replay(_p(rp), C.c_int(rp.size))
+    if return_dz:
+        lib().plxo_set_step_log(_p(log), C.c_int(log.size))
     rc = lib().plxo_matrix_ssfm(_p(ux), _p(uy), _p(b), _p(d), C.c_double(dzmaxt), C.c_double(dphimaxt),
                                 _p(g), C.c_double(alphalin), C.c_int(nfc), C.c_long(nfft), C.c_double(Lf),
                                 C.c_int(nplates), C.c_int(int(manakov)), _fls(fls), _p(db0), _p(theta),
                                 _p(epsilon), C.byref(first), C.byref(ncyc))
+    if rp is not None:
+        lib().plxo_set_step_replay(None, C.c_int(0))
+    if return_dz:
+        n = lib().plxo_step_log_count()
+        lib().plxo_set_step_log(None, C.c_int(0))
+        return rc, first.value, ncyc.value, ux, uy, log[:min(n, log.size)].copy()
     return rc, first.value, ncyc.value, ux, uy
 
 

@@ -302,6 +302,20 @@ static void scale_field(plxo_c *u, size_t n, double s)
     for (size_t i = 0; i < n; i++) u[i] = rmul(s, u[i]);
 }
 
+/* test diagnostics: the step lengths nextstep returns inside matrix_ssfm (fiber.m:512, :534), in order */
+static double *g_dzlog;
+static int g_dzcap, g_dzn;
+void plxo_set_step_log(double *buf, int cap) { g_dzlog = buf; g_dzcap = buf ? cap : 0; g_dzn = 0; }
+int plxo_step_log_count(void) { return g_dzn; }
+static void log_dz(double dz) { if (g_dzlog) { if (g_dzn < g_dzcap) g_dzlog[g_dzn] = dz; g_dzn++; } }
+/* ... and the reverse: step k (0-based) of the next plxo_matrix_ssfm call takes replay[k] instead of nextstep's result, k < n
+ * (parity tests hand the DEVICE's step sequence to the restatement: on noise-loaded fields the step rule itself amplifies
+ * rounding differences, so the transforms are compared under one and the same sequence) */
+static const double *g_replay;
+static int g_replay_n, g_replay_k;
+void plxo_set_step_replay(const double *dz, int n) { g_replay = dz; g_replay_n = dz ? n : 0; g_replay_k = 0; }
+static double replay_dz(double dz) { const int k = g_replay_k++; return (g_replay && k < g_replay_n) ? g_replay[k] : dz; }
+
 /* ---------------------------------------------------------- matrix_ssfm --- */
 /* fiber.m:459-554 */
 int plxo_matrix_ssfm(plxo_c *ux, plxo_c *uy, const double *betat,
@@ -320,7 +334,9 @@ int plxo_matrix_ssfm(plxo_c *ux, plxo_c *uy, const double *betat,
     int rc = 0;
     size_t tot = (size_t)nfft * nfc;
 
-    double dz = plxo_nextstep(dzmaxt, dphimaxt, gam, nfc, alphalin, ux, uy, nfft); /* :512 */
+    g_replay_k = 0;
+    double dz = replay_dz(plxo_nextstep(dzmaxt, dphimaxt, gam, nfc, alphalin, ux, uy, nfft)); /* :512 */
+    log_dz(dz);
     double halfalpha = 0.5 * alphalin;
     int ntot = 0;
     *firstdz = dz;
@@ -336,7 +352,8 @@ int plxo_matrix_ssfm(plxo_c *ux, plxo_c *uy, const double *betat,
         double att = exp(-halfalpha * dz);                                     /* :531-532 */
         scale_field(ux, tot, att);
         scale_field(uy, tot, att);
-        dz = plxo_nextstep(dzmaxt, dphimaxt, gam, nfc, alphalin, ux, uy, nfft); /* :534 */
+        dz = replay_dz(plxo_nextstep(dzmaxt, dphimaxt, gam, nfc, alphalin, ux, uy, nfft)); /* :534 */
+        log_dz(dz);
         zprop = zprop + dz;
         ncycle = ncycle + 1;
     }

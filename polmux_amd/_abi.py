@@ -16,6 +16,8 @@ PLX_ERR_HIP = -1
 PLX_ERR_ARG = -2
 PLX_ERR_UNSUPPORTED = -3
 PLX_ERR_REFERENCE = -4
+PLX_ERR_TIMEOUT = -5
+PLX_SSFM_SHARE_DEVICE = 1
 
 
 class PolmuxError(RuntimeError):
@@ -59,10 +61,15 @@ SIGNATURES = {
     "plx_set_device": [C.c_int],
     "plx_release_all": [],
     "plx_gateway_stats": [_vp],
+    "plx_gateway_stats_ex": [_vp, C.c_int],
     "plx_fastexp": [_vp, _vp, _vp, _sz],
     "plx_fastexp_dev": [_vp, _vp, _sz, _vp],
     "plx_ssfm_create": [C.POINTER(_vp), C.POINTER(SsfmDesc)],
+    "plx_ssfm_create_ex": [C.POINTER(_vp), C.POINTER(SsfmDesc), C.c_uint32],
     "plx_ssfm_destroy": [_vp],
+    "plx_ssfm_set_step_sequence": [_vp, _vp, C.c_int],
+    "plx_ssfm_log_steps": [_vp, C.c_int],
+    "plx_ssfm_step_sequence": [_vp, C.c_int, _vp, C.c_int],
     "plx_ssfm_set_birefringence": [_vp, _vp, _vp, _vp, C.c_int],
     "plx_ssfm_set_birefringence_dev": [_vp, _vp, _vp, _vp, C.c_int, _vp],
     "plx_ssfm_propagate_dev": [_vp, _vp, _vp, C.c_int, _vp],
@@ -85,6 +92,8 @@ SIGNATURES = {
     "plx_easiadaptivefilter": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _dbl, _dbl, _dbl, _vp, _vp],
     "plx_cmaadaptivefilter_m": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _dbl, _vp, _vp, _vp],
     "plx_easiadaptivefilter_m": [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32, _dbl, _vp, _vp],
+    "plx_cmapolardemux": [_vp, _vp, _i64, _i32, _dbl, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "plx_easipolardemux": [_vp, _vp, _i64, _dbl, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "plx_poldemux_dev": [C.c_int, _vp, _vp, _i64, C.c_int, _i32, _dbl, _vp, _vp, _vp, _vp, _vp],
     "plx_dsp_create": [C.POINTER(_vp), _i64, _i32, _i32, C.POINTER(DspParams)],
     "plx_dsp_destroy": [_vp],

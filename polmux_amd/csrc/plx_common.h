@@ -98,6 +98,25 @@ __device__ __forceinline__ void pin_uniform(int &v) { asm volatile("" : "+s"(v))
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
 
+// A field store with a cache policy chosen at build time (A/B of the sweeps' stores; PLX_STORE_POLICY 0 plain, 1 nt, 2 sc1)
+#ifndef PLX_STORE_POLICY
+#define PLX_STORE_POLICY 0
+#endif
+__device__ __forceinline__ void st_field(cplx *p, cplx v)
+{
+#if defined(PLX_EMU) || PLX_STORE_POLICY == 0
+    *p = v;
+#else
+    typedef double d2v __attribute__((ext_vector_type(2)));
+    d2v w; w[0] = v.x; w[1] = v.y;
+#if PLX_STORE_POLICY == 1
+    __builtin_nontemporal_store(w, (d2v *)p);
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
+#endif
+#endif
+}
+
 // ---- DPP lane exchange inside a 16-lane row (no LDS crossbar on the critical path) ----
 // xor-1 / xor-2 are quad permutes; 7 and 15 are the row_half_mirror / row_mirror pairings
 // (lane i <-> 7-i, i <-> 15-i), valid butterfly partners once the lower levels are reduced;

@@ -20,7 +20,7 @@ namespace plxgw {
 enum Slot { S_IN = 0, S_OUT = 1, S_AUX = 2, S_AUX2 = 3, S_COUNT = 4 };
 
 struct Stats {
-    int64_t calls, dev_allocs, host_allocs, plan_builds, plan_hits, dev_bytes, host_bytes, releases;
+    int64_t calls, dev_allocs, host_allocs, plan_builds, plan_hits, dev_bytes, host_bytes, releases, fallbacks;
 };
 
 PLX_HIDDEN std::mutex &mutex();
@@ -31,6 +31,7 @@ PLX_HIDDEN void *pinned(Slot s, size_t bytes);
 PLX_HIDDEN uint64_t hash_bytes(const void *p, size_t n, uint64_t seed);
 PLX_HIDDEN void count_call();
 PLX_HIDDEN void count_plan(bool built);
+PLX_HIDDEN void count_fallback();
 
 // cached plans (owned by the cache; never destroy them).  nullptr on failure, *rc holds the code.
 PLX_HIDDEN plx_ssfm *ssfm_plan(const plx_ssfm_desc &d, int *rc);

@@ -13,7 +13,7 @@ namespace plxgw {
 namespace {
 struct Buf { void *p = nullptr; size_t cap = 0; };
 Buf g_dev[S_COUNT], g_pin[S_COUNT];
-Stats g_stats = {0, 0, 0, 0, 0, 0, 0, 0};
+Stats g_stats = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 std::mutex g_mu;
 
 template <class PLAN> struct Entry { uint64_t key; PLAN *plan; };
@@ -43,6 +43,7 @@ template <class PLAN, class DESTROY> void insert(std::list<Entry<PLAN>> &lst, ui
 
 std::mutex &mutex() { return g_mu; }
 void count_call() { g_stats.calls++; }
+void count_fallback() { g_stats.fallbacks++; }
 void count_plan(bool built) { if (built) g_stats.plan_builds++; else g_stats.plan_hits++; }
 
 void *dev(Slot s, size_t bytes)
@@ -192,5 +193,16 @@ extern "C" int plx_gateway_stats(int64_t *out)
     std::lock_guard<std::mutex> lk(g_mu);
     out[0] = g_stats.calls; out[1] = g_stats.dev_allocs; out[2] = g_stats.host_allocs; out[3] = g_stats.plan_builds;
     out[4] = g_stats.plan_hits; out[5] = g_stats.dev_bytes; out[6] = g_stats.host_bytes; out[7] = g_stats.releases;
+    return PLX_OK;
+}
+
+extern "C" int plx_gateway_stats_ex(int64_t *out, int n)
+{
+    using namespace plxgw;
+    if (!out || n < 0) PLX_FAIL(PLX_ERR_ARG, "plx_gateway_stats_ex: bad argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    const int64_t v[9] = {g_stats.calls, g_stats.dev_allocs, g_stats.host_allocs, g_stats.plan_builds, g_stats.plan_hits,
+                          g_stats.dev_bytes, g_stats.host_bytes, g_stats.releases, g_stats.fallbacks};
+    for (int i = 0; i < n && i < 9; i++) out[i] = v[i];
     return PLX_OK;
 }

@@ -1072,6 +1072,66 @@ extern "C" int plx_easiadaptivefilter_m(const double *xr, const double *xi, int3
     return gateway_filter(PLX_DEMUX_EASI_M, xr, xi, Mdim, h1r, h1i, h2r, h2i, (double)ntap, mu, nullptr, 1.0, yr, yi, true);
 }
 
+// The whole DRIVER loop as one gateway call: y = cmapolardemux(x, params) / easipolardemux(x, params)
+// (DspPdmCohQpsk.m:142-192, :195-244 == dsp4cohdec.m:374-478).  The unchanged drivers call the filter MEX once per pass, up
+// to 299 times per frame, each a PCIe round trip (0.22 ms per pass against 0.08 ms on one host core); here the cyclic
+// extension (:161-165), the centre-tap initialisation from M (:160), the pass loop with its budget (:175 / :227) and the
+// 5e-5 test (:187) all run on the device (k_cma16 / k_cma / k_easi / k_easi_m) and x crosses the bus once.
+static int gateway_poldemux(int method, const double *xr, const double *xi, int64_t L, int32_t taps, double mu, const double *R,
+                            const double *M, double *yr, double *yi, double *h1r, double *h1i, double *h2r, double *h2i,
+                            int32_t *passes)
+{
+    if (!xr || !M || !yr || !yi) PLX_FAIL(PLX_ERR_ARG, "pol-demux gateway: null argument");
+    if (L < 1 || L > ((int64_t)1 << 28)) PLX_FAIL(PLX_ERR_ARG, "pol-demux gateway: bad length");
+    if (method != PLX_DEMUX_CMA) taps = 1;                                  // easipolardemux fixes taps = 1 (:197)
+    if (taps < 1 || taps > 64) PLX_FAIL(PLX_ERR_UNSUPPORTED, "pol-demux: at most 64 taps are supported");
+    std::lock_guard<std::mutex> lk(plxgw::mutex());
+    plxgw::count_call();
+    const size_t nx = 4 * (size_t)L, nh = 8 * (size_t)taps;                 // doubles: x / y [2][L] complex, h [4][taps] complex
+    // staging: x | M (up, one copy) and y | h | passes (down, one copy)
+    double *hst = (double *)plxgw::pinned(plxgw::S_IN, (2 * nx + 8 + nh + 2) * sizeof(double));
+    double *dbuf = (double *)plxgw::dev(plxgw::S_IN, (2 * nx + 8 + nh + 2) * sizeof(double));
+    if (!hst || !dbuf) return PLX_ERR_HIP;
+    double *hx = hst, *hM = hst + nx, *hy = hst + nx + 8, *hh = hy + nx, *hp = hh + nh;
+    double *dx = dbuf, *dM = dbuf + nx, *dy = dbuf + nx + 8, *dh = dy + nx, *dp = dh + nh;
+    for (int p = 0; p < 2; p++)
+        for (int64_t i = 0; i < L; i++) {
+            hx[2 * ((size_t)p * L + i)] = xr[(size_t)p * L + i];
+            hx[2 * ((size_t)p * L + i) + 1] = xi ? xi[(size_t)p * L + i] : 0.0;
+        }
+    for (int k = 0; k < 8; k++) hM[k] = M[k];
+    PLX_HIP(hipMemcpyAsync(dx, hx, (nx + 8) * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    PLX_HIP(hipMemsetAsync(dy, 0, (nx + nh + 2) * sizeof(double), nullptr));
+    int rc = plx_poldemux_dev(method, dx, dy, L, 1, taps, mu, R, dM, dh, (int32_t *)dp, nullptr);
+    if (rc) return rc;
+    PLX_HIP(hipMemcpyAsync(hy, dy, (nx + nh + 2) * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    PLX_HIP(hipStreamSynchronize(nullptr));
+    for (size_t i = 0; i < 2 * (size_t)L; i++) { yr[i] = hy[2 * i]; yi[i] = hy[2 * i + 1]; }
+    for (int j = 0; j < 2 * taps; j++) {                                    // [h1(:,1) h1(:,2) | h2(:,1) h2(:,2)]
+        if (h1r) h1r[j] = hh[2 * j];
+        if (h1i) h1i[j] = hh[2 * j + 1];
+        if (h2r) h2r[j] = hh[2 * (2 * taps + j)];
+        if (h2i) h2i[j] = hh[2 * (2 * taps + j) + 1];
+    }
+    if (passes) std::memcpy(passes, hp, sizeof(int32_t));
+    return PLX_OK;
+}
+
+extern "C" int plx_cmapolardemux(const double *xr, const double *xi, int64_t L, int32_t taps, double mu, const double *R,
+                                 const double *M, double *yr, double *yi, double *h1r, double *h1i, double *h2r, double *h2i,
+                                 int32_t *passes)
+{
+    if (!R) PLX_FAIL(PLX_ERR_ARG, "plx_cmapolardemux: R is required");
+    return gateway_poldemux(PLX_DEMUX_CMA, xr, xi, L, taps, mu, R, M, yr, yi, h1r, h1i, h2r, h2i, passes);
+}
+
+extern "C" int plx_easipolardemux(const double *xr, const double *xi, int64_t L, double mu, const double *M, int32_t mfile_twin,
+                                  double *yr, double *yi, double *h1r, double *h1i, double *h2r, double *h2i, int32_t *passes)
+{
+    return gateway_poldemux(mfile_twin ? PLX_DEMUX_EASI_M : PLX_DEMUX_EASI, xr, xi, L, 1, mu, nullptr, M, yr, yi, h1r, h1i, h2r,
+                            h2i, passes);
+}
+
 // ===================================================================== DSP host ===
 struct plx_dsp {
     plx_dsp_params p;

@@ -101,6 +101,13 @@ struct SsfmArgs {
     // length and attenuation come from the launch arguments instead of the per-frame controller
     int force;
     double f_cur, f_leff, f_sc;
+    // diagnostics (plx_ssfm_set_step_sequence / plx_ssfm_log_steps): nextstep's result of step k (0-based) replaced by
+    // dzlist[k] while k < ndz -- parity tests replay the ORACLE's step sequence on noise-loaded fields, where the step
+    // rule amplifies rounding differences ("Conditioning of the step rule") -- and every frame's own sequence
+    // written to dzlog[frame][k], k < logcap
+    const double *dzlist;
+    int ndz, logcap;
+    double *dzlog;
     // resume the constant-phase loop after an adaptive first step (tolflag == 1, fiber.m:588-611)
     int resume, ncycle0;
     double dz0, zdone0;
@@ -267,6 +274,11 @@ template <bool AGENT, class ARGS, class REC> __device__ __forceinline__ bool ctr
         double step = (a.alphalin == 0) ? leffn : -1 / a.alphalin * log(1 - dl);
         dz = step > a.dzmax ? a.dzmax : step;
     }
+    {   // (diagnostics: a replayed step sequence, the frame's own sequence logged; both off in production plans)
+        const int k = c.started ? c.ncycle : 0;        // 0-based index of the step whose length this is
+        if (a.dzlist && k < a.ndz) dz = a.dzlist[k];
+        if (a.dzlog && count && k < a.logcap) a.dzlog[(size_t)f * a.logcap + k] = dz;
+    }
     if (!c.started) {
         c.started = 1;
         if (a.resume) { // fiber.m:604-611: dz proposed by the adaptive first step, already capped at dzmax
@@ -335,12 +347,15 @@ struct CtrlK {
     int *ndone;
     unsigned long long *umax;
     const double *gam;
+    const double *dzlist;
+    double *dzlog;
+    int ndz, logcap;
 };
 static_assert(sizeof(CtrlK) <= 128, "k_colx16 reserves 128 bytes of LDS for the constants");
 // Returns Leff of the next step, or -1 when the frame has reached the fibre end.
-__device__ __noinline__ double ctrl_head_call(const PLX_LDS_QUAL CtrlK *k, PLX_LDS_QUAL FrameCtl *rec, int count, double pmax)
+__device__ __noinline__ double ctrl_head_call(const PLX_LDS_QUAL CtrlK *k, PLX_LDS_QUAL FrameCtl *rec, int count, double pmax, int f)
 {
-    if (!ctrl_head<true>(*k, 0, *rec, true, pmax, count != 0)) return -1.0;
+    if (!ctrl_head<true>(*k, f, *rec, true, pmax, count != 0)) return -1.0;
     return rec->leff;
 }
 __device__ __noinline__ void ctrl_tail_call(const PLX_LDS_QUAL CtrlK *k, PLX_LDS_QUAL FrameCtl *rec)
@@ -1104,7 +1119,7 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     for (int k = 0; k < 16; k++) x[k] = s[row_phys(tid + 256 * k)];
     lvl2_dit<256>(x, tid, w1);
 #pragma unroll
-    for (int k = 0; k < 16; k++) u[jo + 256 * k] = cmulc(x[k], cmul(tb, bk[k]));
+    for (int k = 0; k < 16; k++) st_field(&u[jo + 256 * k], cmulc(x[k], cmul(tb, bk[k])));
 }
 
 // ------------------------------------------------------ pass 3: inverse columns ---
@@ -1243,7 +1258,12 @@ __device__ __forceinline__ void glds_rows(const cplx *src, size_t stride, cplx *
     unsigned lb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)lds_wave_base);
     unsigned long long p = (unsigned long long)src;
     const unsigned long long st = (unsigned long long)stride * sizeof(cplx);
-#define PLX_GLDS_STEP "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tv_lshl_add_u64 %0, %0, 0, %2\n\ts_add_u32 %1, %1, 0x400\n\t"
+#ifdef PLX_GLDS_NT
+#define PLX_GLDS_AUX " nt"
+#else
+#define PLX_GLDS_AUX ""
+#endif
+#define PLX_GLDS_STEP "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" PLX_GLDS_AUX "\n\tv_lshl_add_u64 %0, %0, 0, %2\n\ts_add_u32 %1, %1, 0x400\n\t"
     asm volatile(PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP
                  PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP
                  : "+v"(p), "+s"(lb) : "s"(st) : "memory", "m0", "scc");
@@ -1348,6 +1368,7 @@ template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a
         red[8] = -1.0;
         kk->dphimax = a.dphimax; kk->alphalin = a.alphalin; kk->dzmax = a.dzmax; kk->dz0 = a.dz0; kk->zdone0 = a.zdone0; kk->Lf = a.Lf; kk->lcorr = a.lcorr;
         kk->dual = a.dual ? 1 : 0; kk->resume = a.resume ? 1 : 0; kk->ncycle0 = a.ncycle0; kk->nfc = 0; kk->ndone = a.ndone; kk->umax = nullptr; kk->gam = nullptr;
+        kk->dzlist = a.dzlist; kk->dzlog = a.dzlog; kk->ndz = a.ndz; kk->logcap = a.logcap;
     }
     auto settle = [&](int par) {           // tid 0 only; par: the parity the owed record was staged in
         const int pf = (int)red[8];
@@ -1481,7 +1502,7 @@ template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a
                     st_agent((unsigned *)a.ndone + 1, 1u);
                     red[19] = 1.0;
                 } else {
-                    const double pv = ctrl_head_call((const PLX_LDS_QUAL CtrlK *)kk, (PLX_LDS_QUAL FrameCtl *)wrec, ti == 0, pm);
+                    const double pv = ctrl_head_call((const PLX_LDS_QUAL CtrlK *)kk, (PLX_LDS_QUAL FrameCtl *)wrec, ti == 0, pm, f);
                     if (ti == 0) red[8] = (double)f;
                     red[16] = pv; red[17] = pv < 0 ? 1.0 : 0.0; red[18] = mm; red[19] = 0.0;
                 }
@@ -1498,7 +1519,7 @@ template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a
             const int nf = (int)red[10 + (it & 1)];    // (the team's next frame, or -1: none left)
             if (nf >= 0) stage(nf, (it & 1) ^ 1);  // (every thread is past its reads of s: the barrier above)
 #pragma unroll
-            for (int k = 0; k < 16; k++) fld[cbase + (size_t)(j + 16 * k) * N2] = y[k];
+            for (int k = 0; k < 16; k++) st_field(&fld[cbase + (size_t)(j + 16 * k) * N2], y[k]);
         } else {
             if (a.spm) {                   // Kerr step of step s+1 (:832-852) on registers
                 const double gamleff = gaml[c] * leff;
@@ -1591,7 +1612,7 @@ template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a
                 for (int k = 0; k < 16; k++) wd[(size_t)(16 * j + k) * wp] = x[k];
             } else {
 #pragma unroll
-                for (int k = 0; k < 16; k++) fld[cbase + (size_t)(16 * j + k) * N2] = x[k];
+                for (int k = 0; k < 16; k++) st_field(&fld[cbase + (size_t)(16 * j + k) * N2], x[k]);
             }
             // [phase 7] staging issue + r16_dif + stores issued
         }
@@ -1630,6 +1651,10 @@ struct plx_ssfm {
     unsigned long long *d_mbox = nullptr;    // [teams][frames + 4] mailboxes of the fused column sweep's teams, then the two claim counters
     size_t mbox_bytes = 0;
     int fused = 0, fused_grid = 0, tiles_pf = 0;
+    uint32_t flags = 0;                      // plx_ssfm_create_ex
+    int barrier_timeouts = 0;                // propagate calls of this plan that ended in a frame-barrier time-out (it then takes the three-sweep step for good)
+    double *d_dzlist = nullptr, *d_dzlog = nullptr;   // diagnostics: replayed / logged step sequences
+    int dzlist_cap = 0;
     int col_threads = 512;         // workgroup size of k_col_fwd / k_col_inv
     int row_threads = ROW_THREADS; // workgroup size of k_row
     int rowr = 0;                  // k_row256r serves the step's row pass
@@ -1674,6 +1699,7 @@ static void free_plan(plx_ssfm *P)
     if (!P) return;
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
+    hipFree(P->d_dzlist); hipFree(P->d_dzlog);
     hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active); hipFree(P->d_work); hipFree(P->d_e1); hipFree(P->d_e2);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     if (P->ev) hipEventDestroy(P->ev);
@@ -1716,12 +1742,13 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
 namespace {
 struct Tune {
-    int no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0, rowr = 0, store_late = -1, fused_per_cu = 0, row_rev = 0;
+    int short_rows = 0, no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0, rowr = 0, store_late = -1, fused_per_cu = 0, row_rev = 0;
     double barrier_timeout_ms = 500.0, group_mib = -1.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
     {
         no_fuse = geti("PLX_SSFM_NO_FUSE", 0);
+        short_rows = geti("PLX_SSFM_SHORT_ROWS", 0);   // (A/B) three-sweep plans of 2^20-sample frames on the 512 x 2048 split instead of 256 x 4096
         p1 = geti("PLX_SSFM_P1", -1);
         logW = geti("PLX_SSFM_LOGW", -1);
         rows = geti("PLX_SSFM_ROWS", -1);
@@ -1742,9 +1769,12 @@ struct Tune {
 bool pow2_in(int v, int lo, int hi) { return v >= lo && v <= hi && (v & (v - 1)) == 0; }
 } // namespace
 
-extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
+extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc) { return plx_ssfm_create_ex(out, desc, 0u); }
+
+extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uint32_t flags)
 {
     if (!out || !desc) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: null argument");
+    if (flags & ~(uint32_t)PLX_SSFM_SHARE_DEVICE) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create_ex: unknown flag");
     *out = nullptr;
     const int64_t N = desc->nfft;
     const int p = ilog2(N);
@@ -1756,10 +1786,12 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         PLX_FAIL(PLX_ERR_REFERENCE, "The CNLSE with separate fields is not yet implemented"); // fiber.m:854
     if (desc->dual_pol && desc->fls[3] && desc->nfc == 1) { /* xpm flag is forced to 0 for one field, :224 */ }
     if (desc->nplates < 1) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: nplates must be >= 1");
-    const Tune tune;
+    Tune tune;
+    if (flags & PLX_SSFM_SHARE_DEVICE) tune.no_fuse = 1;      // the barrier-free three-sweep step: no co-residency requirement
 
     plx_ssfm *P = new plx_ssfm();
     P->d = *desc;
+    P->flags = flags;
     P->p = p;
     // Four-step split N = N1 x N2.  The column tile is N1 rows x T complex (T = W columns per
     // polarisation x npol) and is kept at <= 64 KiB so two workgroups share a CU; a wider, shorter
@@ -1773,7 +1805,7 @@ extern "C" int plx_ssfm_create(plx_ssfm **out, const plx_ssfm_desc *desc)
         // 2^20-sample dual-polarisation frames without PMD keep the 256-row tile of the fused column sweep and take
         // 4096-point rows instead (one polarisation per row workgroup, compact twiddle table: two workgroups per CU);
         // everything else stops at 2048-point rows and gets taller column tiles
-        const bool long_rows = desc->dual_pol && !desc->fls[1] && desc->nfc == 1 && !tune.no_fuse && !tune.no_row_split;
+        const bool long_rows = desc->dual_pol && !desc->fls[1] && desc->nfc == 1 && !tune.no_row_split && !(tune.no_fuse && tune.short_rows);
         const int p2max = long_rows ? 12 : 11;
         if (p - p1 > p2max) p1 = p - p2max;                  // large frames: taller tiles instead
         if (p1 > p - 4) p1 = p - 4;                          // keep N2 >= 16
@@ -2164,13 +2196,19 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
     bool pending = false, aborted = false;
     // profiling: an event in front of every launch of the loop (and one after the last); intervals are attributed to
     // the kernel class that follows the event.  Classes: 0 k_colx16 / k_col_fwd, 1 k_row, 2 k_col_inv, 3 control.
-    plx_ssfm::ProfRun run;
+    // (the events of a call that ends early -- a HIP failure, a frame-barrier time-out -- go back to the plan's free list)
+    struct ProfGuard {
+        plx_ssfm *P;
+        plx_ssfm::ProfRun run;
+        ~ProfGuard() { for (hipEvent_t e : run.ev) P->evfree.push_back(e); }
+    } guard{P, {}};
+    plx_ssfm::ProfRun &run = guard.run;
     auto mark = [&](int cls, int step) -> int {
         if (!P->profile) return PLX_OK;
         hipEvent_t e;
         if (!P->evfree.empty()) { e = P->evfree.back(); P->evfree.pop_back(); }
         else PLX_HIP(hipEventCreate(&e));
-        run.ev.push_back(e); run.cls.push_back(cls); run.step.push_back(step);
+        run.ev.push_back(e); run.cls.push_back(cls); run.step.push_back(step);   // (owned by the guard from here on)
         PLX_HIP(hipEventRecord(e, st));
         return PLX_OK;
     };
@@ -2251,10 +2289,17 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
     PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     PLX_HIP(hipStreamSynchronize(st));
     P->slots_listed += P->h_ndone[3];
-    if (aborted || P->h_ndone[1])
-        PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: frame barrier timed out (the workgroups of a frame were not co-resident: "
-                              "another kernel holds the GPU); nothing was stored after the timeout -- create the plan with "
-                              "PLX_SSFM_NO_FUSE=1 to share the device");
+    if (aborted || P->h_ndone[1]) {
+        // The field of this call is lost (it has been propagated in place up to the time-out).  The plan itself stays usable:
+        // from now on it takes the barrier-free three-sweep step, which needs no co-residency.  The gateway tier, whose
+        // pristine input is still in its pinned staging buffer, repeats the call that way at once (gateway_ssfm).
+        P->barrier_timeouts++;
+        P->fused = 0;
+        PLX_FAIL(PLX_ERR_TIMEOUT, "plx_ssfm_propagate_dev: frame barrier timed out (the workgroups of a frame were not co-resident: "
+                                  "another kernel holds the GPU); nothing was stored after the time-out and the field of this call is "
+                                  "INVALID -- the plan now takes the barrier-free three-sweep step: restore the field and call again, "
+                                  "or create such plans with plx_ssfm_create_ex(..., PLX_SSFM_SHARE_DEVICE)");
+    }
     int maxnc = 0;
     for (int f = g0; f < g0 + nframes; f++) {
         P->frame_steps += P->h_ctl[f].ncycle + (fused ? 1 : 0);   // (the fused sweep's last round writes the field out)
@@ -2266,6 +2311,7 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
     if (!run.ev.empty()) {
         run.maxnc = maxnc; run.fused = fused;
         P->prof_pending.push_back(std::move(run));
+        run.ev.clear();                 // (moved out: nothing left for the guard to return)
     }
 #undef PLX_MARK
     return PLX_OK;
@@ -2289,6 +2335,41 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
         if (rc) return rc;
     }
     PLX_HIP(hipGetLastError());
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_set_step_sequence(plx_ssfm *P, const double *dz, int nsteps)
+{
+    if (!P || nsteps < 0 || (nsteps > 0 && !dz)) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_set_step_sequence: bad argument");
+    if (nsteps > P->dzlist_cap) {
+        if (P->d_dzlist) { (void)hipFree(P->d_dzlist); P->d_dzlist = nullptr; P->dzlist_cap = 0; }
+        PLX_HIP(hipMalloc((void **)&P->d_dzlist, sizeof(double) * (size_t)nsteps));
+        P->dzlist_cap = nsteps;
+    }
+    if (nsteps > 0) PLX_HIP(hipMemcpy(P->d_dzlist, dz, sizeof(double) * (size_t)nsteps, hipMemcpyHostToDevice));
+    P->a.dzlist = nsteps > 0 ? P->d_dzlist : nullptr;
+    P->a.ndz = nsteps;
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_log_steps(plx_ssfm *P, int max_steps)
+{
+    if (!P || max_steps < 0) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_log_steps: bad argument");
+    if (P->d_dzlog) { (void)hipFree(P->d_dzlog); P->d_dzlog = nullptr; }
+    P->a.dzlog = nullptr; P->a.logcap = 0;
+    if (max_steps > 0) {
+        PLX_HIP(hipMalloc((void **)&P->d_dzlog, sizeof(double) * (size_t)max_steps * P->d.max_frames));
+        P->a.dzlog = P->d_dzlog; P->a.logcap = max_steps;
+    }
+    return PLX_OK;
+}
+
+extern "C" int plx_ssfm_step_sequence(plx_ssfm *P, int frame, double *dz, int max_steps)
+{
+    if (!P || !dz || frame < 0 || frame >= P->d.max_frames || max_steps < 0) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_step_sequence: bad argument");
+    if (!P->d_dzlog) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_step_sequence: no log (plx_ssfm_log_steps)");
+    const int n = max_steps < P->a.logcap ? max_steps : P->a.logcap;
+    PLX_HIP(hipMemcpy(dz, P->d_dzlog + (size_t)frame * P->a.logcap, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost));
     return PLX_OK;
 }
 
@@ -2426,6 +2507,14 @@ static int gateway_ssfm(double *uxr, double *uxi, double *uyr, double *uyi, cons
     }
     PLX_HIP(hipMemcpyAsync(dx, h, bytes, hipMemcpyHostToDevice, nullptr));
     rc = plx_ssfm_propagate_dev(P, dx, dy, 1, nullptr);
+    if (rc == PLX_ERR_TIMEOUT) {
+        // fiber.m:372-389 always returns a field.  Another kernel holds part of the GPU, so the frame's workgroups could not
+        // meet; the caller's input is still in the pinned staging buffer: upload it again and make the same call on the
+        // barrier-free three-sweep step (the plan has switched itself), counted in plx_gateway_stats_ex.
+        plxgw::count_fallback();
+        PLX_HIP(hipMemcpyAsync(dx, h, bytes, hipMemcpyHostToDevice, nullptr));
+        rc = plx_ssfm_propagate_dev(P, dx, dy, 1, nullptr);
+    }
     if (rc) return rc;
     PLX_HIP(hipMemcpyAsync(h, dx, bytes, hipMemcpyDeviceToHost, nullptr));
     PLX_HIP(hipStreamSynchronize(nullptr));

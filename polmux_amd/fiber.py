@@ -202,6 +202,14 @@ def fiber(x, flag=None, rng=None):
         return (p, d)
 
     plan = _plan_for(hash(key), build)[0]
+    # diagnostics for parity work (include/polmux_hip.h, plx_ssfm_set_step_sequence): x["_replay_dz"] = the step lengths to use
+    # instead of nextstep's (fiber.m:682-715), x["_log_dz"] = True returns the device's own sequence in fiber.last["dz"]
+    replay = x.get("_replay_dz")
+    if replay is not None:
+        rz = np.ascontiguousarray(replay, dtype=float)
+        lib.call("plx_ssfm_set_step_sequence", plan, rz.ctypes.data, rz.size)
+    if x.get("_log_dz"):
+        lib.call("plx_ssfm_log_steps", plan, 1 << 14)
     if fls[1] == 1:
         a, b, c_ = (np.ascontiguousarray(v, dtype=float) for v in (db0, theta, eps))
         lib.call("plx_ssfm_set_birefringence", plan, a.ctypes.data, b.ctypes.data, c_.ctypes.data, 1)
@@ -215,6 +223,13 @@ def fiber(x, flag=None, rng=None):
     first, ncyc = C.c_double(), C.c_int32()
     lib.call("plx_ssfm_results", plan, 1, C.byref(first), C.byref(ncyc))
     info = dict(firstdz=first.value, ncycle=ncyc.value)
+    if replay is not None:
+        lib.call("plx_ssfm_set_step_sequence", plan, None, 0)
+    if x.get("_log_dz"):
+        dzs = np.zeros(min(ncyc.value, 1 << 14))
+        lib.call("plx_ssfm_step_sequence", plan, 0, dzs.ctypes.data, dzs.size)
+        lib.call("plx_ssfm_log_steps", plan, 0)
+        info["dz"] = dzs
     fiber.last = info                                                         # fiber.m:431 prints these
     if brf is not None:
         brf.update(lcorr=x["length"] / nplates, betat=t["betat"], db1=t["db1"], **info)

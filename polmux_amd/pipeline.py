@@ -37,7 +37,7 @@ class HotPathConfig:
                  dgd=0.1, nplates=100, manakov="no", nspans=1, fft_length=256, cde_L=128, applypol=True,
                  polmethod="cma", cma_taps=7, cma_mu=1 / 6000, freqavg=500, phasavg=3, poworder=2,
                  frontend="pick", oftype="gauss", obw=1.9, oord=3, eftype="bessel5", ebw=0.65, eord=4, lopower=0.0,
-                 adcbits=5, span_nf_db=None, rx_amp=False, variants=1, nch=1, chspacing=0.4):
+                 adcbits=5, span_nf_db=None, rx_amp=False, variants=1, nch=1, chspacing=0.4, share_device=False):
         """frontend: 'pick' = 2-sps sampling supplied by the harness; 'cohmix' = the reference's own
         receiver_cohmix + ADC + decimate chain (RxPdmCohQpsk.m, Run_my_PDM_QPSK.m:52-73 defaults) on the device.
         nspans > 1: every span but the last is followed by an in-line flat amplifier restoring its loss
@@ -50,7 +50,10 @@ class HotPathConfig:
         nch > 1: a frame is a 'sepfields' WDM field of nch columns (create_field.m:17-18, ex10_wdm.m:9-11; BASELINE
         config[2]) chspacing nm apart around lam: the channels share the step length (fiber.m:694-698) and each keeps its
         own walk-off and gamma (fiber.m:326-328); channel c of frame f carries variant (f nch + c) % variants, and every
-        channel has its own receiver (receiver_cohmix.m:104-125 picks the column)."""
+        channel has its own receiver (receiver_cohmix.m:104-125 picks the column).
+        share_device: the fibre plan takes the barrier-free three-sweep step (plx_ssfm_create_ex, PLX_SSFM_SHARE_DEVICE): a
+        frame that is the whole grid of the fused sweep (2^20 samples, 16 channels) can then propagate beside the receiver of
+        the previous batch on another stream (the fused sweep would wait for its frame's workgroups to be co-resident)."""
         self.__dict__.update(locals())
         del self.__dict__["self"]
 
@@ -92,7 +95,7 @@ class HotPath:
         self._keep = (np.ascontiguousarray(t["gam"]), t["betat"], t["db1"])
         d.gam, d.betat, d.db1 = (a.ctypes.data for a in self._keep)
         self.ssfm = C.c_void_p()
-        self.lib.call("plx_ssfm_create", C.byref(self.ssfm), C.byref(d))
+        self.lib.call("plx_ssfm_create_ex", C.byref(self.ssfm), C.byref(d), _abi.PLX_SSFM_SHARE_DEVICE if cfg.share_device else 0)
         self.nplates = nplates
         self._profiling = False
         if self.pmd:   # Monte-Carlo style: an independent random birefringence draw per frame (fiber.m:274-276)

@@ -32,7 +32,7 @@ n = os.environ["ABN"]
 if n != "base": _abi.LIB_PATH = os.path.join(os.path.dirname(_abi.LIB_PATH), "libpolmux_hip_%s.so" % n)
 from polmux_amd import pipeline
 F = int(os.environ["F"])
-hp = pipeline.HotPath(pipeline.HotPathConfig(flag=os.environ["FLAG"], nsymb=int(os.environ["NSYMB"])), max_frames=F)
+hp = pipeline.HotPath(pipeline.HotPathConfig(flag=os.environ["FLAG"], nsymb=int(os.environ["NSYMB"]), nch=int(os.environ.get("NCH", "1"))), max_frames=F)
 hp.profile(True)
 ts = []
 for r in range(5):

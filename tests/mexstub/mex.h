@@ -7,10 +7,13 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-typedef struct mxArray_tag { size_t m, n; double *pr, *pi; } mxArray;
+typedef struct mxArray_tag { size_t m, n; double *pr, *pi; char *str; /* non-NULL: a char row vector */ } mxArray;
 typedef enum { mxREAL = 0, mxCOMPLEX = 1 } mxComplexity;
 mxArray *mxCreateDoubleMatrix(size_t m, size_t n, mxComplexity c);
 mxArray *mxCreateDoubleScalar(double v);
+mxArray *mxCreateString(const char *s);
+int mxIsChar(const mxArray *a);
+int mxGetString(const mxArray *a, char *buf, size_t buflen);   /* 0 on success, 1 if truncated / not a char array */
 mxArray *mxDuplicateArray(const mxArray *a);
 void mxDestroyArray(mxArray *a);
 double *mxGetPr(const mxArray *a);

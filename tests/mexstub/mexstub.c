@@ -16,6 +16,20 @@ mxArray *mxCreateDoubleMatrix(size_t m, size_t n, mxComplexity c)
     a->pi = c == mxCOMPLEX ? (double *)calloc(cnt, sizeof(double)) : NULL;
     return a;
 }
+mxArray *mxCreateString(const char *str)
+{
+    mxArray *a = mxCreateDoubleMatrix(1, strlen(str), mxREAL);
+    a->str = (char *)malloc(strlen(str) + 1);
+    strcpy(a->str, str);
+    return a;
+}
+int mxIsChar(const mxArray *a) { return a && a->str != NULL; }
+int mxGetString(const mxArray *a, char *buf, size_t buflen)
+{
+    if (!a || !a->str || buflen == 0) return 1;
+    snprintf(buf, buflen, "%s", a->str);
+    return strlen(a->str) >= buflen;
+}
 mxArray *mxCreateDoubleScalar(double v) { mxArray *a = mxCreateDoubleMatrix(1, 1, mxREAL); a->pr[0] = v; return a; }
 mxArray *mxDuplicateArray(const mxArray *s)
 {
@@ -24,7 +38,7 @@ mxArray *mxDuplicateArray(const mxArray *s)
     if (s->pi) memcpy(a->pi, s->pi, s->m * s->n * sizeof(double));
     return a;
 }
-void mxDestroyArray(mxArray *a) { if (a) { free(a->pr); free(a->pi); free(a); } }
+void mxDestroyArray(mxArray *a) { if (a) { free(a->pr); free(a->pi); free(a->str); free(a); } }
 double *mxGetPr(const mxArray *a) { return a->pr; }
 double *mxGetPi(const mxArray *a) { return a->pi; }
 void mxSetPi(mxArray *a, double *pi) { a->pi = pi; }

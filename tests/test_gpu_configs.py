@@ -467,3 +467,92 @@ def test_campaign_on_a_plan_that_cannot_share_the_gpu_keeps_one_stream(lib):
     assert got.tolist() == np.concatenate(want).tolist()
     assert np.array_equal(evm, np.concatenate(wevm)) and evm.min() > 0      # (the EVM is a continuous sample: equality to the bit)
     camp.close()
+
+
+def test_gateway_falls_back_to_three_sweeps_when_another_kernel_holds_the_gpu(lib, oracle, monkeypatch):
+    """fiber.m:372-389 always returns a field.  A 16-channel frame is ONE team of the fused sweep (512 tiles = the whole grid):
+    its workgroups must all be resident to meet at the frame barrier.  With a bounded spinning kernel of another stream holding
+    the LDS of half the CUs (tests/gpuhelpers/spin.hip: 'another process on the device') they cannot; the barrier times out,
+    nothing is stored after the time-out, and plx_matrix_ssfm repeats the span from its pinned staging copy on the barrier-free
+    three-sweep step: the call SUCCEEDS, the field is the oracle's, plx_gateway_stats_ex counts the fallback, and the cached
+    plan stays on the three-sweep step afterwards."""
+    import os
+    import torch
+    from tests.test_gpu_parity import _desc, _fibre_case, _vp
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spin = C.CDLL(os.path.join(root, "tests", "gpuhelpers", "_build", "libplxspin.so"))
+    spin.plx_test_spin.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    lib.call("plx_release_all")
+    monkeypatch.setenv("PLX_SSFM_BARRIER_TIMEOUT_MS", "150")
+    c = _fibre_case(1024, 64, "g-s-", 1.0, nfc=16, length=1.5e4)
+    d = _desc(c)
+    planes = [np.asfortranarray(v.copy()) for v in (c["ux"].real, c["ux"].imag, c["uy"].real, c["uy"].imag)]
+    z = np.zeros(1)
+    fd, nc = C.c_double(), C.c_int32()
+
+    def stats():
+        v = np.zeros(9, np.int64)
+        lib.call("plx_gateway_stats_ex", v.ctypes.data, 9)
+        return v
+    s0 = stats()
+    side = torch.cuda.Stream()
+    # 128 workgroups x 120 KiB of LDS: no column workgroup (66 KiB) fits beside one, so at most 2 x 128 of the 512 are resident
+    assert spin.plx_test_spin(128, 256, 120 * 1024, 2.0, C.c_void_p(side.cuda_stream)) == 0
+    lib.call("plx_matrix_ssfm", *[_vp(p) for p in planes], C.byref(d), _vp(z), _vp(z), _vp(z), C.byref(fd), C.byref(nc))
+    s1 = stats()
+    torch.cuda.synchronize()
+    assert s1[8] == s0[8] + 1, "the span did not take the fallback (was the frame co-resident after all?)"
+    rc, ofd, onc, ox, oy = oracle.matrix_ssfm(c["ux"], c["uy"], c["t"]["betat"], c["t"]["db1"], c["dzm"], c["dph"], c["t"]["gam"],
+                                              c["t"]["alphalin"], c["length"], 1, False, c["fls"], z, z, z)
+    assert rc == 0 and nc.value == onc and fd.value == pytest.approx(ofd, rel=1e-12)
+    gx, gy = planes[0] + 1j * planes[1], planes[2] + 1j * planes[3]
+    assert np.abs(gx - ox).max() <= FIELD_RTOL * np.abs(ox).max()
+    assert np.abs(gy - oy).max() <= FIELD_RTOL * np.abs(oy).max()
+    # the same span again on a quiet GPU: the cached plan is found and no longer waits for anybody (no second fallback)
+    planes2 = [np.asfortranarray(v.copy()) for v in (c["ux"].real, c["ux"].imag, c["uy"].real, c["uy"].imag)]
+    lib.call("plx_matrix_ssfm", *[_vp(p) for p in planes2], C.byref(d), _vp(z), _vp(z), _vp(z), C.byref(fd), C.byref(nc))
+    s2 = stats()
+    assert s2[8] == s1[8] and s2[4] == s1[4] + 1
+    for a, b in zip(planes, planes2):
+        np.testing.assert_array_equal(a, b)
+    lib.call("plx_release_all")
+
+
+def test_share_device_plan_runs_the_receiver_beside_the_next_fibre_bit_equal(lib):
+    """plx_ssfm_create_ex(..., PLX_SSFM_SHARE_DEVICE): a 2^20-sample frame is the whole grid of the fused sweep, so its receiver
+    used to wait on the fibre's stream.  On the barrier-free three-sweep step the receiver of batch i runs on its own stream
+    beside the fibre of batch i + 1: symbols, error counts and step counts equal the same batches run one stage after the other."""
+    import torch
+    from polmux_amd import pipeline
+    cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, cma_mu=1 / 600, share_device=True)
+    F = 2
+    hp = pipeline.HotPath(cfg, max_frames=F)
+    assert not hp.fused() and hp.overlap_ok() and hp.info()[2] == 12        # three sweeps on the 256 x 4096 split
+    side = torch.cuda.Stream()
+    scales = [np.array([1.0, 1.6]), np.array([0.7, 2.2])]
+    serial = []
+    for sc in scales:
+        ux, uy = hp.make_batch(F, sc)
+        hp.fibre(ux, uy)
+        _sync()
+        e = hp.receive(ux, uy, noise_sigma=0.05, noise_seed=5)
+        _sync()
+        serial.append((hp.sym[:F].clone(), e.clone(), hp.last_ncycle(F).copy()))
+    got = []
+    ux0, uy0 = hp.make_batch(F, scales[0])
+    hp.fibre(ux0, uy0)
+    nc0 = hp.last_ncycle(F).copy()
+    e0 = hp.receive(ux0, uy0, noise_sigma=0.05, noise_seed=5, side_stream=side)     # enqueued, not waited for ...
+    with torch.cuda.stream(side):
+        keep = (hp.sym[:F].clone(), e0.clone())
+    ux1, uy1 = hp.make_batch(F, scales[1])
+    hp.fibre(ux1, uy1)                                                              # ... while the next batch propagates
+    nc1 = hp.last_ncycle(F).copy()
+    _sync()
+    got.append((keep[0], keep[1], nc0))
+    e1 = hp.receive(ux1, uy1, noise_sigma=0.05, noise_seed=5)
+    _sync()
+    got.append((hp.sym[:F].clone(), e1.clone(), nc1))
+    for (s_, e_, n_), (gs, ge, gn) in zip(serial, got):
+        assert torch.equal(s_, gs) and torch.equal(e_, ge) and n_.tolist() == gn.tolist()
+    hp.close()

@@ -17,7 +17,8 @@ BUILD = os.path.join(STUB, "_build")
 
 
 class MxArray(C.Structure):
-    _fields_ = [("m", C.c_size_t), ("n", C.c_size_t), ("pr", C.POINTER(C.c_double)), ("pi", C.POINTER(C.c_double))]
+    _fields_ = [("m", C.c_size_t), ("n", C.c_size_t), ("pr", C.POINTER(C.c_double)), ("pi", C.POINTER(C.c_double)),
+                ("str", C.c_char_p)]
 
 
 def test_every_shim_compiles_against_the_abi_header():
@@ -41,6 +42,8 @@ def _load(shim):
     lib = C.CDLL(so)
     lib.mxCreateDoubleMatrix.restype = C.POINTER(MxArray)
     lib.mxCreateDoubleMatrix.argtypes = [C.c_size_t, C.c_size_t, C.c_int]
+    lib.mxCreateString.restype = C.POINTER(MxArray)
+    lib.mxCreateString.argtypes = [C.c_char_p]
     lib.mexstub_call.argtypes = [C.c_int, C.POINTER(C.POINTER(MxArray)), C.c_int, C.POINTER(C.POINTER(MxArray))]
     lib.mexstub_last_error.restype = C.c_char_p
     lib.mexstub_lock_count.restype = C.c_int
@@ -252,6 +255,85 @@ def test_mfile_twin_shims_return_the_updated_taps():
     np.testing.assert_allclose(_np(out[1]), g1, atol=1e-11)
     np.testing.assert_allclose(_np(out[2]), g2, atol=1e-11)
     assert np.abs(_np(out[1]).imag - k1.imag).max() > 1e-5
+
+
+@pytest.mark.gpu
+def test_poldemux_driver_shims_make_the_whole_pass_loop_in_one_call():
+    """plx_cmapolardemux_mex / plx_easipolardemux_mex: y = cmapolardemux(x, params) / easipolardemux(x, params) as ONE MEX
+    call each (DspPdmCohQpsk.m:142-244): output of the last pass, final taps and the number of passes equal the oracle's
+    driver loop around the per-pass filter (C1's L = 1024, 7 taps, mu = 1/6000 among the cases: 47 passes on this input)."""
+    from oracle import plxo as oracle
+    lib = _load("plx_cmapolardemux_mex")
+    r = np.random.default_rng(3)
+    for L, taps, mu, noise, phi in ((1024, 7, 1 / 6000, 0.05, 0.0), (400, 5, 1 / 500, 0.0, 0.3), (256, 1, 1 / 300, 0.02, 0.0)):
+        a = np.exp(1j * (np.pi / 4 + np.pi / 2 * r.integers(0, 4, (L, 2))))
+        x = a @ np.array([[np.cos(0.35), np.sin(0.35)], [-np.sin(0.35), np.cos(0.35)]]) + noise * (r.standard_normal((L, 2)) + 1j * r.standard_normal((L, 2)))
+        M = np.array([[np.cos(phi), np.sin(phi)], [-np.sin(phi), np.cos(phi)]])        # :157-158
+        rc, out, err = _call(lib, 4, _mx(lib, x), _mx(lib, [[1.0, 1.0]]), _mx(lib, [[mu]]), _mx(lib, [[taps]]), _mx(lib, M))
+        assert rc == 0, err
+        oy, h1, h2, n = oracle.cmapolardemux(x, M, taps, mu, [1.0, 1.0])
+        assert int(_np(out[3])[0, 0]) == n
+        assert 1 < n < 50 * int(np.ceil(1 / (L * mu)))                                 # converged inside the budget of :175-176
+        np.testing.assert_allclose(_np(out[0]), oy, atol=1e-9)
+        np.testing.assert_allclose(_np(out[1]), h1.reshape(taps, 2), atol=1e-9)
+        np.testing.assert_allclose(_np(out[2]), h2.reshape(taps, 2), atol=1e-9)
+    rc, _, err = _call(lib, 1, _mx(lib, x), _mx(lib, [[1.0, 1.0]]), _mx(lib, [[1e-3]]), _mx(lib, [[4]]), _mx(lib, M))
+    assert rc == 1 and err == "Ntaps should be an ODD INTEGER."
+    rc, _, err = _call(lib, 1, _mx(lib, x), _mx(lib, [[1.0, 1.0]]), _mx(lib, [[1e-3]]), _mx(lib, [[3]]))
+    assert rc == 1 and err == "Five inputs required."
+    assert lib.mexstub_lock_count() == 1
+    lib2 = _load("plx_easipolardemux_mex")
+    L, mu = 512, 1 / 400
+    a = np.exp(1j * (np.pi / 4 + np.pi / 2 * r.integers(0, 4, (L, 2))))
+    x = a @ np.array([[np.cos(0.2), np.sin(0.2)], [-np.sin(0.2), np.cos(0.2)]]) + 0.03 * (r.standard_normal((L, 2)) + 1j * r.standard_normal((L, 2)))
+    M = np.eye(2) + 0j
+    rc, out, err = _call(lib2, 4, _mx(lib2, x), _mx(lib2, [[mu]]), _mx(lib2, M))
+    assert rc == 0, err
+    oy, h1, h2, n = oracle.easipolardemux(x, M, mu)
+    assert int(_np(out[3])[0, 0]) == n
+    np.testing.assert_allclose(_np(out[0]), oy, atol=1e-9)
+    np.testing.assert_allclose(_np(out[1]).ravel(), np.ravel(h1), atol=1e-9)
+    rc, out, err = _call(lib2, 4, _mx(lib2, x), _mx(lib2, [[mu]]), _mx(lib2, M), _mx(lib2, [[1]]))     # around the .m twin of the filter
+    assert rc == 0, err
+    oy, h1, h2, n = oracle.easipolardemux_m(x, M, mu)
+    assert int(_np(out[3])[0, 0]) == n
+    np.testing.assert_allclose(_np(out[0]), oy, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_scalar_a_ssfm_shim_and_release_request():
+    """plx_scalar_a_ssfm_mex: [firstdz,ncycle,u,nrej] = scalar_a_ssfm(...) (fiber.m:639-679, 938-1009) against the oracle;
+    then <shim>('release'): the library's state is freed and the MEX file unlocked (clearable), and the next call works."""
+    from oracle import plxo as oracle
+    from polmux_amd import _abi, synth
+    lib = _load("plx_scalar_a_ssfm_mex")
+    nsymb, nt = 64, 16
+    u = synth.pdm_qpsk_field(nsymb, nt, 12.0)[0].reshape(-1, 1)
+    omega = 2 * np.pi * 28 * synth.fn_grid(nsymb, nt)
+    betat = (0.5 * omega ** 2 * -2.17e-8).reshape(-1, 1)
+    gam = [1.3e-6]
+
+    def call():
+        return _call(lib, 4, _mx(lib, u), _mx(lib, betat), _mx(lib, [[4e4]]), _mx(lib, [[np.inf]]), _mx(lib, [gam]), _mx(lib, [[4.6e-5]]),
+                     _mx(lib, [[1]]), _mx(lib, [[4e4]]), _mx(lib, [[1, 0, 1, 0]]), _mx(lib, [[2]]), _mx(lib, [[1e-6]]), _mx(lib, [[0.9]]))
+    rc, out, err = call()
+    assert rc == 0, err
+    ofd, onc, onrej, ou = oracle.scalar_a_ssfm(u, betat, 4e4, np.inf, gam, 4.6e-5, 4e4, 1e-6, 0.9, [1, 0, 1, 0])
+    assert int(_np(out[1])[0, 0]) == onc and onc > 3 and int(_np(out[3])[0, 0]) == onrej
+    assert _np(out[0])[0, 0] == pytest.approx(ofd, rel=1e-9)
+    assert np.abs(_np(out[2]) - ou).max() <= 1e-9 * np.abs(ou).max()
+    first = _np(out[2])
+    assert lib.mexstub_lock_count() == 1 and _gw_stats()["dev_bytes"] > 0
+    rc, _, err = _call(lib, 0, lib.mxCreateString(b"release"))
+    assert rc == 0, err
+    assert lib.mexstub_lock_count() == 0 and _gw_stats()["dev_bytes"] == 0      # clearable, nothing held
+    rc, _, err = _call(lib, 0, lib.mxCreateString(b"relax"))
+    assert rc == 1 and err == "Twelve inputs required."                          # any other string is just a bad call
+    rc, out, err = call()
+    assert rc == 0, err
+    np.testing.assert_array_equal(_np(out[2]), first)
+    assert lib.mexstub_lock_count() == 1                                          # locked again by the first ordinary call
+    _abi.get().call("plx_release_all")
 
 
 def _gw_stats():
