@@ -78,10 +78,17 @@ def parse():
                          "of a serial recurrence) and its waves keep column workgroups off their CUs meanwhile, so few LARGE rounds beat many "
                          "small ones: 128 x 8 rounds, 8 in flight: 3800/s; 512 x 2, 2 in flight: 5000/s (profiles/r03_mc.txt); the statistics "
                          "are identical (rounds are replayed in realisation order)")
+    ap.add_argument("--mc-total", type=int, default=1024,
+                    help="second Monte-Carlo leg, STRONG scaling: this many realisations IN TOTAL (BASELINE config[3]: 1024 over 8 GPUs = "
+                         "128 per GPU), one round of mc_total / N per GPU, one all-reduce (0: skip)")
     ap.add_argument("--mc-nf", type=float, default=31.0, help="noise figure [dB] of the amplifier in the Monte-Carlo leg")
     ap.add_argument("--spans", type=int, default=1, help="spans per step, with in-line amplifiers between them (config[4]: 40)")
     ap.add_argument("--nf", type=float, default=None, help="noise figure [dB] of the in-line amplifiers (default: noiseless)")
     ap.add_argument("--no-overlap", action="store_true", help="run the receiver on the fibre stream (no stream overlap)")
+    ap.add_argument("--share-device", default="auto", choices=["auto", "yes", "no"],
+                    help="fibre plan on the barrier-free three-sweep step (plx_ssfm_create_ex, PLX_SSFM_SHARE_DEVICE) so that a frame "
+                         "that is the whole grid of the fused sweep (2^20 samples, 16 channels) can propagate BESIDE the previous "
+                         "batch's receiver; auto: where such a plan's receiver takes more than a quarter of its fibre's time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rx-thread", action="store_true", help="enqueue the receiver from the fibre's host thread (A/B)")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame latency measurement after the timed region")
@@ -329,6 +336,55 @@ def gateway_bench(cfg, hp):
         out["plx_matrix_ssfm"] = {"what": "one 2^%d-sample frame, one span, %d steps" % (int(np.log2(cfg.nfft)), nc.value),
                                   "first_call_ms": first, "ms_per_call": per, "allocations_in_repeats": allocs,
                                   "oracle_ms_per_call": (time.perf_counter() - t0) * 1e3}
+    # -- the whole pol-demux DRIVER of one frame (DspPdmCohQpsk.m:142-192): (a) ONE call of plx_cmapolardemux (pass loop on the
+    #    device), (b) what the unchanged driver pays: one plx_cmaadaptivefilter MEX call per pass with the 5e-5 test on the host,
+    #    (c) the oracle's driver on one host core.  Input: frame 0 of the last batch after CDE, 1 sps, /4 sqrt(P) (:12-23)
+    try:
+        eq = hp.eq[0].cpu().numpy()                                   # [2, 2 nsymb]
+        xs = np.ascontiguousarray(eq[:, ::2].T) / (4.0 * math.sqrt(hp.power_mw))
+        Ld, tp, mu = xs.shape[0], cfg.cma_taps, cfg.cma_mu
+        xr, xi = np.asfortranarray(xs.real), np.asfortranarray(xs.imag)
+        Mi = np.array([1.0, 0, 0, 0, 0, 0, 1.0, 0])                     # phizero = 0: M = I (:157-158)
+        yr, yi = np.zeros((Ld, 2), order="F"), np.zeros((Ld, 2), order="F")
+        hh = [np.zeros((tp, 2), order="F") for _ in range(4)]
+        npass = C.c_int32()
+
+        def one_call():
+            lib.call("plx_cmapolardemux", xr.ctypes.data, xi.ctypes.data, Ld, tp, mu, R.ctypes.data, Mi.ctypes.data, yr.ctypes.data,
+                     yi.ctypes.data, hh[0].ctypes.data, hh[1].ctypes.data, hh[2].ctypes.data, hh[3].ctypes.data, C.byref(npass))
+        first, per, allocs = timed(one_call, 5)
+        half = tp // 2
+        ext = np.concatenate([xs[Ld - half:], xs, xs[:half]]) if half else xs      # :161-165
+        er, ei = np.asfortranarray(ext.real), np.asfortranarray(ext.imag)
+        budget = 50 * int(math.ceil(1.0 / (Ld * mu)))
+        y2r, y2i = np.zeros((Ld, 2), order="F"), np.zeros((Ld, 2), order="F")
+
+        def per_pass_driver():
+            h1r = np.zeros((tp, 2), order="F"); h1r[half, 0] = 1.0
+            h2r = np.zeros((tp, 2), order="F"); h2r[half, 1] = 1.0
+            h1i, h2i = np.zeros((tp, 2), order="F"), np.zeros((tp, 2), order="F")
+            c = 1
+            while c < budget:                                                      # :176-191
+                o = (h1r.copy(), h1i.copy(), h2r.copy(), h2i.copy())
+                lib.call("plx_cmaadaptivefilter", er.ctypes.data, ei.ctypes.data, ext.shape[0], h1r.ctypes.data, h1i.ctypes.data,
+                         h2r.ctypes.data, h2i.ctypes.data, float(tp), mu, R.ctypes.data, 1.0, y2r.ctypes.data, y2i.ctypes.data)
+                d = max(np.abs((o[0] - h1r) + 1j * (o[1] - h1i)).max(), np.abs((o[2] - h2r) + 1j * (o[3] - h2i)).max())
+                c += 1
+                if d < 5e-5:
+                    break
+            return c - 1
+        t0 = time.perf_counter()
+        n_loop = per_pass_driver()
+        loop_ms = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter()
+        _, _, _, n_or = plxo.cmapolardemux(xs, np.eye(2), tp, mu, [1.0, 1.0])
+        or_ms = (time.perf_counter() - t0) * 1e3
+        out["plx_cmapolardemux"] = {"what": "the pol-demux driver of ONE frame (L = %d, %d taps, mu = 1/%.0f): %d passes" % (Ld, tp, 1 / mu, npass.value),
+                                    "first_call_ms": first, "ms_per_call": per, "allocations_in_repeats": allocs, "passes": int(npass.value),
+                                    "per_pass_mex_loop_ms": loop_ms, "per_pass_mex_loop_passes": int(n_loop),
+                                    "oracle_ms_per_call": or_ms, "oracle_passes": int(n_or)}
+    except Exception as exc:           # (a side measurement: never takes the line down)
+        out["plx_cmapolardemux"] = {"error": repr(exc)}
     v = stats()
     out["library_state"] = {"device_bytes": int(v[5]), "pinned_bytes": int(v[6]), "plans_built": int(v[3]), "plans_found": int(v[4])}
     out["note"] = ("host arrays in and out (PCIe both ways) with the library's cached plans and buffers; first_call_ms includes "
@@ -430,10 +486,27 @@ def main():
     cfg = pipeline.HotPathConfig(nsymb=a.nsymb, nt=a.nt, pavg_mw=a.pavg, flag=a.flag, frontend=a.frontend, nspans=a.spans,
                                  span_nf_db=a.nf, variants=a.variants, nch=nch, chspacing=a.chspacing)
     F = a.frames
+    cfg.share_device = a.share_device == "yes"
     hp = pipeline.HotPath(cfg, max_frames=F)
-    hp.profile(True)          # a HIP event between consecutive launches of the step loop: per-kernel durations, live
     n = cfg.nfft
     scales = ladder_scales(F, a.pavg, rank, world) if a.power_ladder else None
+    share_why = "asked for" if cfg.share_device else None
+    if a.share_device == "auto" and not a.no_overlap and not hp.overlap_ok():
+        # A frame of this plan is the whole grid of the fused sweep: its receiver cannot run beside the next fibre.  One
+        # calibration batch (not timed, not counted): is the receiver long enough to be worth the three-sweep step's ~15 %?
+        cx, cy = hp.make_batch(F, scales)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        hp.fibre(cx, cy)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        hp.receive(cx, cy, noise_sigma=a.noise, noise_seed=1)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        del cx, cy
+        if (t2 - t1) > 0.25 * (t1 - t0):
+            hp.close()
+            cfg.share_device = True
+            hp = pipeline.HotPath(cfg, max_frames=F)
+            share_why = "auto: receiver %.0f ms against fibre %.0f ms on the fused step, serial" % ((t2 - t1) * 1e3, (t1 - t0) * 1e3)
+    hp.profile(True)          # a HIP event between consecutive launches of the step loop: per-kernel durations, live
     # inputs for every step are staged in HBM before the timed region (fibre works in place)
     total = a.steps + a.warmup
     # (bounded by free HBM: with more steps than buffers a buffer is refilled from a pristine copy by one
@@ -621,6 +694,30 @@ def main():
                                                     "waveplates, amplifier ASE, receiver_cohmix + ADC + decimate, CDE, CMA + CPE), busiest "
                                                     "process %.1f s" % (cores, per, camp.hp.nplates, res_cpu[1])}
         camp.close()
+        # ---- the same campaign as BASELINE config[3] STATES it: mc_total realisations in total, sharded r mod N -- strong
+        # scaling: N GPUs take mc_total / N each in ONE round (one all-reduce).  Its floor is a latency, not a rate: the fibre of
+        # mc_total / N realisations + ONE receiver (the CMA of a noise-loaded realisation runs all of its 299 passes, ~55 ms
+        # whatever the batch size) + the front end, so the curve flattens as N grows.
+        if a.mc_total > 0 and a.mc_total % world == 0:
+            per = a.mc_total // world
+            camp2 = pipeline.McCampaignPool(mcfg, frames_per_call=per, n=1)
+            camp2.simulate(list(range(2 * 10 ** 6 + rank * per, 2 * 10 ** 6 + (rank + 1) * per)))       # warm-up, not counted
+            sb2 = mc.ShardedBer(camp2.simulate, camp2.bits_per_realisation, x, per_rank_per_round=per, device=cdev)
+            sync_all()
+            t1 = time.perf_counter()
+            res2 = sb2.run(max_realisations=a.mc_total, depth=1)
+            sync_all()
+            sdt = time.perf_counter() - t1
+            if world > 1:
+                tm = torch.tensor([sdt], dtype=torch.float64, device=cdev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                sdt = float(tm.item())
+            mc_out["strong_scaling"] = {"realisations_total": a.mc_total, "realisations": len(sb2.counts), "per_gpu": per, "rounds": sb2.rounds,
+                                        "exchanges": sb2.exchanges, "seconds": sdt, "realisations_per_s": len(sb2.counts) / sdt,
+                                        "avgber": float(res2[1][0]), "stopped_by_rule": bool(not res2[0][0]),
+                                        "shape": "BASELINE config[3] as stated: %d realisations in total, realisation r on GPU r mod %d, "
+                                                 "one round, one all_reduce(SUM) of int64[%d]" % (a.mc_total, world, a.mc_total)}
+            camp2.close()
 
     # SURVEY 8d's M1 read literally -- ONE frame through fibre + receiver, nothing else on the GPU (outside the timed region)
     single = None
@@ -725,6 +822,10 @@ def main():
                        "fibre_ms_per_step": fib / a.steps, "rxdsp_ms_per_step": rxm / a.steps,
                        "frames_per_s": float(world) * a.steps * F / dt, "fresh_pmd_per_realisation": bool(a.mc),
                        "fused_grid_workgroups": hp.info()[3], "column_tiles_per_frame": hp.info()[4],
+                       "fibre_step": ("three sweeps per step, barrier-free (PLX_SSFM_SHARE_DEVICE; %s): the receiver of batch i runs beside the "
+                                      "fibre of batch i+1" % share_why) if cfg.share_device else
+                                     ("two sweeps per step (fused column sweep)" if fused else "three sweeps per step"),
+                       "receiver_beside_next_fibre": bool(rx_stream is not None),
                        "bit_errors_xy": err_total.cpu().tolist(),
                        "bit_errors_resolved": int(res_total.item()) if a.mc else None,
                        "bits": int(world) * a.steps * F * nch * 4 * a.nsymb, "restaged_batches": restaged,

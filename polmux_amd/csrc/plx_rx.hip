@@ -221,6 +221,9 @@ __device__ __forceinline__ double max16(double v)
 #endif
 __global__ __launch_bounds__(CMA16_THREADS) void k_cma16(DemuxArgs a)
 {
+#if defined(PLX_CMA_PRIO) && !defined(PLX_EMU)
+    __builtin_amdgcn_s_setprio(PLX_CMA_PRIO);   // (A/B: the few latency-bound waves of this kernel ahead of a neighbour's streaming waves)
+#endif
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const int l16 = threadIdx.x & 15, r = l16 >> 3, t = l16 & 7;
     const int grp = gtid >> 4;
@@ -244,37 +247,49 @@ __global__ __launch_bounds__(CMA16_THREADS) void k_cma16(DemuxArgs a)
         ha = M[2 * r]; hb = M[2 * r + 1];
     }
     const double Rr = r ? a.R2 : a.R1, mu = a.mu;
-    const int64_t off = single ? (int64_t)t : (int64_t)t - a.halftaps;
-    const int64_t nout = single ? L - a.taps + 1 : L;
+    const int Li = (int)L;                                  // (32-bit indices: L < 2^31, checked by the host)
+    const int off = single ? t : t - a.halftaps;
+    const int nout = (int)(single ? L - a.taps + 1 : L);
     int c = 1, npass = 0;
     bool active = c < a.max_passes;
-    const int64_t nchunks = nout / CMA_U, tail0 = nchunks * CMA_U;
+    const int nchunks = nout / CMA_U, tail0 = nchunks * CMA_U;
+    // The wave is ISSUE-bound: in order, ~5 clocks per instruction whatever their dependencies (profiles/r04_notes.md: the
+    // recurrence with its loop-carried dependency cut runs no faster), so what counts is the instruction count per symbol --
+    // 28 FP64 operations + 12 DPP moves are the recurrence itself; everything around them is kept off the symbol loop:
+    //  * the samples of the NEXT chunk are loaded unconditionally by every lane (a lane beyond the last tap keeps zero taps and
+    //    a zero step size instead of a predicate per load: eight exec-masked blocks of 28 instructions per chunk before), from
+    //    a position kept modulo L by one compare per sample instead of 64-bit wrap arithmetic;
+    //  * two chunks per trip, the second computing from the registers the first one's prefetch landed in (no register copies).
+    //    the samples of an INTERIOR chunk k (0 < k < nchunks - 2: no lane's window leaves [0, L)) sit at one per-lane pointer
+    //    plus a wave-uniform offset and eight immediates; only the chunks at the two ends of a pass wrap around;
+    //  * two chunks per trip, the second computing from the registers the first one's prefetch landed in (no register copies).
+    const double mul_lane = tap_ok ? mu : 0.0;
+    const cplx *const q1 = x1 + off, *const q2 = x2 + off;  // (only dereferenced where 0 <= i + off < L)
+    auto load8 = [&](int k, cplx *da, cplx *db) {           // the samples of chunk k: symbols 8 k .. 8 k + 7
+        const int i0 = k * CMA_U;
+        if (k > 0 && k < nchunks - 2) {
+#pragma unroll
+            for (int u = 0; u < CMA_U; u++) { da[u] = q1[i0 + u]; db[u] = q2[i0 + u]; }
+        } else {                                            // cyclic extension (:161-165): positions modulo L
+            int base = i0 + off;
+            base = base < 0 ? base + Li : (base >= Li ? base - Li : base);
+#pragma unroll
+            for (int u = 0; u < CMA_U; u++) {
+                int idx = base + u;
+                idx = idx >= Li ? idx - Li : idx;
+                da[u] = x1[idx]; db[u] = x2[idx];
+            }
+        }
+    };
     while (__any(active)) {
         const cplx oa = ha, ob = hb;
-        const double mua = active ? mu : 0.0;
-        cplx ca[CMA_U], cb[CMA_U], na[CMA_U], nb[CMA_U];
-#pragma unroll
-        for (int u = 0; u < CMA_U; u++) {
-            int64_t idx = u + off;
-            if (idx < 0) idx += L; else if (idx >= L) idx -= L;
-            ca[u] = tap_ok ? x1[idx] : make_double2(0, 0);
-            cb[u] = tap_ok ? x2[idx] : make_double2(0, 0);
-        }
-        for (int64_t ch = 0; ch < nchunks; ch++) {
-            const int64_t i0 = ch * CMA_U;
-            if (ch + 1 < nchunks) {
-#pragma unroll
-                for (int u = 0; u < CMA_U; u++) {
-                    int64_t idx = i0 + CMA_U + u + off;
-                    if (idx < 0) idx += L; else if (idx >= L) idx -= L;
-                    na[u] = tap_ok ? x1[idx] : make_double2(0, 0);
-                    nb[u] = tap_ok ? x2[idx] : make_double2(0, 0);
-                }
-            }
+        const double mua = active ? mul_lane : 0.0;
+        // one chunk of CMA_U symbols from the samples in (sa, sb); its outputs go to yo[i0 ...]
+        auto chunk = [&](const cplx *sa, const cplx *sb, int i0) {
             cplx yk[CMA_U];                // the chunk's outputs: stored once, outside the dependent chain
 #pragma unroll
             for (int u = 0; u < CMA_U; u++) {
-                const cplx xa = ca[u], xb = cb[u];
+                const cplx xa = sa[u], xb = sb[u];
                 double yr = (xa.x * ha.x - xa.y * ha.y) + (xb.x * hb.x - xb.y * hb.y);
                 double yi = (xa.x * ha.y + xa.y * ha.x) + (xb.x * hb.y + xb.y * hb.x);
                 sum8x2(yr, yi);
@@ -291,13 +306,21 @@ __global__ __launch_bounds__(CMA16_THREADS) void k_cma16(DemuxArgs a)
 #pragma unroll
                 for (int u = 0; u < CMA_U; u++) yo[i0 + u] = yk[u];
             }
-#pragma unroll
-            for (int u = 0; u < CMA_U; u++) { ca[u] = na[u]; cb[u] = nb[u]; }
+        };
+        cplx ca[CMA_U], cb[CMA_U], na[CMA_U], nb[CMA_U];
+        if (nchunks > 0) load8(0, ca, cb);
+        int ch = 0;
+        for (; ch + 1 < nchunks; ch += 2) {
+            load8(ch + 1, na, nb);                           // chunk ch+1 lands while chunk ch computes
+            chunk(ca, cb, ch * CMA_U);
+            if (ch + 2 < nchunks) load8(ch + 2, ca, cb);     // chunk ch+2 lands while chunk ch+1 computes
+            chunk(na, nb, (ch + 1) * CMA_U);
         }
-        for (int64_t i = tail0; i < nout; i++) { // the outputs beyond the last whole chunk
-            int64_t idx = i + off;
-            if (idx < 0) idx += L; else if (idx >= L) idx -= L;
-            const cplx xa = tap_ok ? x1[idx] : make_double2(0, 0), xb = tap_ok ? x2[idx] : make_double2(0, 0);
+        if (ch < nchunks) chunk(ca, cb, ch * CMA_U);         // (an odd number of chunks: the last one is in ca, cb)
+        for (int i = tail0; i < nout; i++) { // the outputs beyond the last whole chunk
+            int idx = i + off;
+            if (idx < 0) idx += Li; else if (idx >= Li) idx -= Li;
+            const cplx xa = x1[idx], xb = x2[idx];
             double yr = (xa.x * ha.x - xa.y * ha.y) + (xb.x * hb.x - xb.y * hb.y);
             double yi = (xa.x * ha.y + xa.y * ha.x) + (xb.x * hb.y + xb.y * hb.x);
             sum8x2(yr, yi);
@@ -921,7 +944,7 @@ extern "C" int plx_cde_ofde(const double *xr, const double *xi, const double *yr
 static const int kCmaPackMin = 64;    // (measured with four Monte-Carlo rounds of 128 in flight: +2...8 %, profiles/r03_mc.txt)
 static int launch_demux(int method, DemuxArgs &a, void *stream)
 {
-    if (method == PLX_DEMUX_CMA && a.taps <= 8 && a.dontskip && a.L >= 16 && (!a.single_pass || a.L - a.taps + 1 >= 1)) {
+    if (method == PLX_DEMUX_CMA && a.taps <= 8 && a.dontskip && a.L >= 16 && a.L < ((int64_t)1 << 30) && (!a.single_pass || a.L - a.taps + 1 >= 1)) {
         // big batches travel four waves to a workgroup (see k_cma16); a few frames keep a CU per wave (sharing one costs the
         // recurrence ~14 %: 16 frames of 2^20 samples, 148 -> 170 ms)
         static const int pack_min = getenv("PLX_CMA_PACK_MIN") ? atoi(getenv("PLX_CMA_PACK_MIN")) : kCmaPackMin;   // (read once)

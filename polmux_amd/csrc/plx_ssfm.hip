@@ -59,11 +59,6 @@ static_assert(sizeof(FrameCtl) == 128 && offsetof(FrameCtl, done) == 124, "done 
 
 struct SsfmArgs {
     cplx *ux, *uy;
-    // the plan's WORKING COPY of the field (fused sweep with 4096-point rows): [frame][channel][N1][wpitch] with a row
-    // pitch that is NOT a multiple of 64 KiB.  The first fused launch of a span reads the caller's arrays and stores here,
-    // the sweeps in between work here in place, the launch that finishes a frame stores it back into the caller's arrays.
-    cplx *wx, *wy;
-    int wpitch;                    // complex samples between consecutive rows of the working copy
     const double *betat_p, *db1_p; // [nfc][N], bit-reversed/transposed order
     const cplx *tpass;             // [N] inter-pass twiddles W_N^(n2*k1), same order
     const cplx *hmul;              // [N] general spectral multiplier replacing exp(-i betat dz) (filter passes), same order
@@ -87,7 +82,7 @@ struct SsfmArgs {
     long long spin_ticks;          // frame-barrier timeout in ticks of plx_clock() (10 ns)
     unsigned long long *slots;     // [2][nframes][tiles per frame] per-tile max |u|^2 by launch parity (k_colx16), ~0 = not arrived
     int row_rev;                   // k_row256r takes the listed frames in DESCENDING order (the column sweep takes them ascending: each kernel starts on the frames the other finished with, which are still in the Infinity Cache)
-    int store_late;                // fused sweep: a tile's stores are issued AFTER the next tile has landed (one-team launches: see k_colx16)
+    int store_late;                // fused sweep: a tile's stores are issued AFTER the next tile has landed (multi-team launches: see k_colx16)
     int safe_land;                 // PLX_SSFM_SAFE_LANDING=1: the staged tile is also waited for with s_waitcnt vmcnt(0) (checks the sentinel landing)
     int round;                     // launch index of the fused sweep within this propagate call
     int *grab;                     // [2] frames claimed beyond the first of every team, by launch parity (k_colx16)
@@ -689,14 +684,11 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
     const size_t N = (size_t)1 << (a.p1 + a.p2);
     const int j0 = blockIdx.x * R;
     const int nel = R << a.p2;
-    // the field: the caller's arrays (rows N2 apart: the R rows of this workgroup are contiguous), or the plan's working copy
-    // with its own row pitch (SsfmArgs::wx).  gofs(e): where element e = (row, point) of this workgroup's rows lives.
-    const bool wk = a.wx != nullptr;
-    cplx *const fx = wk ? a.wx : a.ux;
-    cplx *const fy = wk ? a.wy : (a.dual ? a.uy : a.ux);
-    const size_t base = wk ? ((size_t)fc << a.p1) * a.wpitch + (size_t)j0 * a.wpitch : (size_t)fc * N + (size_t)j0 * N2;
-    const int rowadd = wk ? a.wpitch - N2 : 0;
-    auto gofs = [&](int e) -> size_t { return base + e + (size_t)(e >> a.p2) * rowadd; };
+    // the field (rows N2 apart: the R rows of this workgroup are contiguous).  gofs(e): where element e = (row, point) lives.
+    cplx *const fx = a.ux;
+    cplx *const fy = a.dual ? a.uy : a.ux;
+    const size_t base = (size_t)fc * N + (size_t)j0 * N2;
+    auto gofs = [&](int e) -> size_t { return base + e; };
     const size_t rowbase = (size_t)j0 * N2;      // (position of the workgroup's rows in the per-frequency tables)
     // the inter-pass twiddles of a thread's points: with exactly ROW_CH points per thread (the usual shape) they stay
     // in registers for the conjugate multiply on the way out
@@ -1040,9 +1032,7 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     cplx *t8 = bk + 16;                          // W_256^e at e + (e >> 2), e < 128
     const size_t N = (size_t)1 << (a.p1 + a.p2);
     const size_t rowbase = (size_t)brow << 12;
-    // (a.wx: the plan's working copy with its own row pitch, see SsfmArgs)
-    cplx *const u = a.wx ? (bpol ? a.wy : a.wx) + ((size_t)fc << a.p1) * a.wpitch + (size_t)brow * a.wpitch
-                         : (bpol ? a.uy : a.ux) + (size_t)fc * N + rowbase;
+    cplx *const u = (bpol ? a.uy : a.ux) + (size_t)fc * N + rowbase;
     const cplx *const tp = a.tpass + rowbase;
 
     const Tw4096 w1{tw};
@@ -1281,31 +1271,20 @@ __device__ __forceinline__ void emu_lockstep() {}
 #endif
 
 
-// WP2 > 0: the plan keeps a working copy of the field with its own row pitch (SsfmArgs::wx); such plans are single-field
-// frames of 256 x 2^WP2 samples, and the kernel takes that geometry as constants (it has no register to spare).
-template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf)
+__global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf)
 {
-    constexpr bool WORK = WP2 > 0;
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, t = tid & 15, j = tid >> 4;
-    const int N2 = WORK ? (1 << WP2) : 1 << a.p2;
-    const int LOGN = WORK ? 8 + WP2 : a.p1 + a.p2;
+    const int N2 = 1 << a.p2;
+    const int LOGN = a.p1 + a.p2;
     cplx *s = (cplx *)lds;                 // [256][16] exchange buffer
     cplx *tw = s + 4096;                   // W_256^k, k < 128
     double *red = (double *)(tw + 128);
     FrameCtl *lctl = (FrameCtl *)(red + 32);
     lds_load_twiddles(tw, a.tw1, 128, tid, 256);
     cplx *const fld = (t < 8) ? a.ux : a.uy;
-    // Where a tile is read and written.  Round 0 of a span reads the caller's arrays (every listed frame is unstarted then,
-    // and started in every later round); a frame's last round writes them.  In between the field lives in the plan's
-    // working copy when there is one (WORK: row pitch a.wpitch), else in the caller's arrays as well.  The working copy's
-    // addresses are formed where they are used (this kernel has no register to spare for loop invariants).
     const int round = a.round;
-    const bool first_round = !WORK || round == 0;
-    const size_t wp = WORK ? (size_t)a.wpitch : (size_t)N2;                                      // row pitch of the copy worked on
-    const size_t wfs = WORK ? ((size_t)a.wpitch << 8) : ((size_t)1 << LOGN);                     // its frame-channel stride
-    const size_t sp = first_round ? (size_t)N2 : wp, sfs = first_round ? ((size_t)1 << LOGN) : wfs;   // the same for this launch's SOURCE
     const int colt = t & 7;
     const bool isx = t < 8;
     const int lane = tid & 63, row0 = (tid >> 6) * 64;     // this wave stages rows row0 .. row0+63
@@ -1320,7 +1299,7 @@ template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a
     // team's workgroups run without meeting, and its first may be any number of iterations ahead of its slowest.
     const int nact = a.nactive[0];
     const int NT = gridDim.x / tiles_pf, team = blockIdx.x / tiles_pf, ti = blockIdx.x - team * tiles_pf;
-    const int c = WORK ? 0 : ti / tiles_x, bx = ti - c * tiles_x;
+    const int c = ti / tiles_x, bx = ti - c * tiles_x;
     const unsigned long long rtag = (unsigned long long)(((unsigned)round + 1u) & 0xfffffu) << 22;
     unsigned long long *const mbox = a.mbox + (size_t)a.mbox_stride * team;
     if (blockIdx.x == 0 && tid == 0) a.grab[(round & 1) ^ 1] = 0;        // (the other parity's counter: for the next launch)
@@ -1338,17 +1317,15 @@ template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a
     // (record copies: [iteration parity][wave] -- the copy of the tile in hand is still needed while the next one lands)
     int it = 0;
     auto stage = [&](int f, int par) {
-        const int fc = WORK ? f : f * a.nfc + c;
+        const int fc = f * a.nfc + c;
         // (lane & 15 == t: the lane stages a piece of the same column of the same polarisation it later works on)
         int lq = lane >> 4;
         pin(lq);                           // (addresses are formed where they are used: hoisted out of the tile loop they end up in scratch)
-        const cplx *sfld = fld;
-        if (WORK && !first_round) { int tq = t; pin(tq); sfld = tq < 8 ? a.wx : a.wy; }
-        const cplx *src = sfld + (size_t)fc * sfs + (size_t)bx * 8 + colt + (size_t)(row0 + lq) * sp;
+        const cplx *src = fld + ((size_t)fc << LOGN) + (size_t)bx * 8 + colt + (size_t)(row0 + lq) * N2;
         FrameCtl *const rec = lctl + 4 * par + (tid >> 6);
         if (lane == (int)(offsetof(FrameCtl, done) / 16)) rec->done = PLX_REC_SENTINEL;   // (the lane whose piece of the record holds the word)
         lds_settle();                      // (the sentinel is in place before the copy that replaces it can land)
-        glds_rows(src, (size_t)4 * sp, s + (size_t)row0 * 16, lane);
+        glds_rows(src, (size_t)4 * N2, s + (size_t)row0 * 16, lane);
         static_assert(sizeof(FrameCtl) % 16 == 0, "the record travels as 16-byte pieces");
         int ln = lane;
         pin(ln);                           // (the address is formed here: kept across the tile loop it would sit in scratch)
@@ -1383,7 +1360,7 @@ template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a
     //  end of an iteration, and the next iteration may write its successor with no workgroup barrier in between)
     for (;; it++) {
         FrameCtl *const wrec = lctl + 4 * (it & 1) + (tid >> 6);
-        const int fc = WORK ? f : f * a.nfc + c;
+        const int fc = f * a.nfc + c;
         // [phase 0] loop top
         if (a.safe_land) drain_vmem();     // (checking mode: the ordinary wait as well -- results must not depend on it)
         while (lds_peek(&wrec->done) == PLX_REC_SENTINEL) nap();   // this wave's rows of the tile and its copy of the record are in LDS
@@ -1593,10 +1570,12 @@ template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a
                 if (nf >= 0) stage(nf, (it & 1) ^ 1);
             }
             r16_dif(x);                    // ... during the last register transform and the stores of this one
-            // One-team launches (a frame = the whole grid: 2^20 samples): every workgroup reaches this point at the same moment,
-            // and 32 MiB of stores issued on the heels of the 32 MiB of staging requests share the memory system with them -- the
-            // tile lands twice as late, and the frame barrier that follows waits for the last landing.  There the stores are
-            // held back until this wave's rows of the next tile are in LDS: requests first, stores while the next tile computes.
+            // store_late (what ships: ON for multi-team launches such as C1, OFF where a frame is the whole grid): the tile's stores
+            // are held back until this wave's rows of the NEXT tile are in LDS -- requests first, stores while the next tile
+            // computes.  Multi-team: the landing no longer shares the workgroup's memory queue with 64 KiB of stores, k_colx16
+            // beside the receiver 1170 -> 1138 us (+3...4 %).  One team (2^20-sample frames): the whole grid would wait for the
+            // last landing before ANY store is issued, 359 -> 395 us per 16 frames, so the plan leaves it off there
+            // (profiles/r03_store_late_ab.txt).
             if (a.store_late) {
                 const int nf = (int)red[10 + (it & 1)];
                 if (nf >= 0) {
@@ -1604,16 +1583,8 @@ template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a
                     while (lds_peek(&nrec->done) == PLX_REC_SENTINEL) nap();
                 }
             }
-            if (WORK) {
-                int tq = t;
-                pin(tq);
-                cplx *const wd = (tq < 8 ? a.wx : a.wy) + (size_t)fc * wfs + (size_t)bx * 8 + colt;
 #pragma unroll
-                for (int k = 0; k < 16; k++) wd[(size_t)(16 * j + k) * wp] = x[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 16; k++) st_field(&fld[cbase + (size_t)(16 * j + k) * N2], x[k]);
-            }
+            for (int k = 0; k < 16; k++) st_field(&fld[cbase + (size_t)(16 * j + k) * N2], x[k]);
             // [phase 7] staging issue + r16_dif + stores issued
         }
         f = (int)red[10 + (it & 1)];
@@ -1645,8 +1616,6 @@ struct plx_ssfm {
     int brf_sets = 0;
     size_t lds_col = 0, lds_row = 0;
     cplx *d_e1 = nullptr, *d_e2 = nullptr;   // per-frame, per-trunk row / column phasors of PMD plans with a linear db1 (k_pmd_tab)
-    cplx *d_work = nullptr;                  // working copy of the field with a padded row pitch (fused sweep, 4096-point rows), x then y
-    int wpitch = 0;
     unsigned long long *d_slots = nullptr;   // slot barrier of the fused column sweep: [launch parity][frame][tile]
     unsigned long long *d_mbox = nullptr;    // [teams][frames + 4] mailboxes of the fused column sweep's teams, then the two claim counters
     size_t mbox_bytes = 0;
@@ -1664,8 +1633,6 @@ struct plx_ssfm {
     double *h_brf[2] = {nullptr, nullptr}; // pinned staging of the waveplate tables
     hipEvent_t brf_ev[2] = {nullptr, nullptr};
     int brf_slot = 0;
-    int group_frames = 0;          // frames per cache-resident group of a propagate call (0: the whole batch at once)
-    int last_group_steps = 0;      // launches the previous group of the current call needed (sizes the next group's first chunk)
     int64_t row_launches = 0, sample_steps = 0;
     int64_t slots_launched = 0, slots_listed = 0, frame_steps = 0;   // utilisation accounting of the last propagate
     // optional per-kernel timing of the step loop (plx_ssfm_profile): one event between consecutive launches
@@ -1680,12 +1647,6 @@ struct plx_ssfm {
 };
 
 static const double kInv2Pi = 0.15915494309189533577;
-static const int kDefaultWorkPad = -1;        // working copy (2^16- and 2^20-sample single-field frames): off.  Measured (profiles/r03_wpad_ab.txt):
-                                              // at 2^20 pads of 0 ... 2056 samples leave k_colx16 at 360-373 us per 16 frames against 361-365 without
-                                              // the copy; at 2^16 a pad evens out the four slow tiles of a frame (bx = 3 mod 8: 2 us late at every
-                                              // barrier, whatever XCD runs them) but k_colx16 gains < 1 % and k_row loses 1.4 %.
-                                              // PLX_SSFM_WPAD=<pad> keeps the path testable
-static const double kDefaultGroupMiB = 0.0;   // field MiB per cache-resident frame group (0: off); PLX_SSFM_GROUP_MIB overrides
 
 static int ilog2(int64_t v)
 {
@@ -1700,7 +1661,7 @@ static void free_plan(plx_ssfm *P)
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
     hipFree(P->d_dzlist); hipFree(P->d_dzlog);
-    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active); hipFree(P->d_work); hipFree(P->d_e1); hipFree(P->d_e2);
+    hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active); hipFree(P->d_e1); hipFree(P->d_e2);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     if (P->ev) hipEventDestroy(P->ev);
     for (hipEvent_t e : P->evfree) hipEventDestroy(e);
@@ -1738,12 +1699,15 @@ template <class K> static hipError_t allow_lds(K, size_t) { return hipSuccess; }
 template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 #endif
 
-// Plan-time tuning overrides for development sweeps (scripts/experiments/): read ONCE, in plx_ssfm_create.
-// PLX_SSFM_NO_FUSE=1 is the supported switch (barrier-free three-sweep step, e.g. when several processes share a GPU).
+// Plan-time overrides, read ONCE in plx_ssfm_create: the geometry switches the tests use to reach other splits and kernels
+// (P1, LOGW, COL_THREADS, NO_ROW_SPLIT, SHORT_ROWS, ROWR, NO_PMD_TAB), A/B switches of shipped choices (STORE_LATE, ROW_REV,
+// SAFE_LANDING) and the barrier time-out.  PLX_SSFM_NO_FUSE=1 = plx_ssfm_create_ex(..., PLX_SSFM_SHARE_DEVICE) for a whole
+// process (barrier-free three-sweep step, e.g. when several processes share a GPU).  The switches of experiments that were
+// not adopted (working copy, frame groups, grid sizing: profiles/r03_notes.md) are gone with their code.
 namespace {
 struct Tune {
-    int short_rows = 0, no_fuse = 0, p1 = -1, logW = -1, rows = -1, row_threads = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, wpad = -2, no_pmd_tab = 0, rowr = 0, store_late = -1, fused_per_cu = 0, row_rev = 0;
-    double barrier_timeout_ms = 500.0, group_mib = -1.0;
+    int short_rows = 0, no_fuse = 0, p1 = -1, logW = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, no_pmd_tab = 0, rowr = 0, store_late = -1, row_rev = 0;
+    double barrier_timeout_ms = 500.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
     {
@@ -1751,19 +1715,14 @@ struct Tune {
         short_rows = geti("PLX_SSFM_SHORT_ROWS", 0);   // (A/B) three-sweep plans of 2^20-sample frames on the 512 x 2048 split instead of 256 x 4096
         p1 = geti("PLX_SSFM_P1", -1);
         logW = geti("PLX_SSFM_LOGW", -1);
-        rows = geti("PLX_SSFM_ROWS", -1);
-        row_threads = geti("PLX_SSFM_ROW_THREADS", -1);
         col_threads = geti("PLX_SSFM_COL_THREADS", -1);
         no_row_split = geti("PLX_SSFM_NO_ROW_SPLIT", 0);
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
-        fused_per_cu = geti("PLX_SSFM_FUSED_PER_CU", 0);  // fused sweep: workgroups per CU the grid is sized for (0: what fits; 1: half the chip's slots, for two plans propagating side by side)
         store_late = geti("PLX_SSFM_STORE_LATE", -1);  // fused sweep: stores after the next tile's landing; -1: where a launch has more than one team
         row_rev = geti("PLX_SSFM_ROW_REV", 1);         // 0: the row pass takes the listed frames in ascending order as well (A/B)
         rowr = geti("PLX_SSFM_ROWR", 1);               // 0: the LDS-resident k_row also where the register form k_row256r applies (A/B, tests)
         no_pmd_tab = geti("PLX_SSFM_NO_PMD_TAB", 0);   // PMD plans: one exponential per bin and trunk instead of the phasor tables (A/B, tests)
-        wpad = geti("PLX_SSFM_WPAD", -2);         // complex samples added to the working copy's row pitch; -1: no working copy
         if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
-        if (const char *e = getenv("PLX_SSFM_GROUP_MIB")) group_mib = atof(e);
     }
 };
 bool pow2_in(int v, int lo, int hi) { return v >= lo && v <= hi && (v & (v - 1)) == 0; }
@@ -1829,14 +1788,12 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
     {
         int R = 1, npol = a.dual ? 2 : 1;
         while (R * npol * (N2 / 16) < ROW_THREADS / 2 && R * 2 <= N1) R *= 2;   // measured: 2 rows x 2 pols at N2 = 256
-        if (pow2_in(tune.rows, 1, N1)) R = tune.rows;
         a.R = R; a.logR = ilog2(R);
         // row pass: ~8 points per thread (128 threads for 2 rows x 2 polarisations x 256 points); long rows leave room
         // for only one or two workgroups per CU, so those get proportionally more waves (up to 1024 threads)
         int rowthr = ROW_THREADS;
         const int64_t pts = (int64_t)npol * R * N2;
         while (rowthr < 1024 && (int64_t)rowthr * 8 < pts) rowthr *= 2;
-        if (pow2_in(tune.row_threads, 64, 1024)) rowthr = tune.row_threads;
         P->row_threads = rowthr;
     }
     // Long rows leave room for a single dual-polarisation workgroup per CU.  Without PMD the two polarisations only
@@ -1931,7 +1888,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
     P->col_threads = P->lds_col > 80 * 1024 ? 1024 : 512;   // measured: 512-thread column workgroups (2 per CU, 16 waves) beat
                                                             // 256 by 3-12 %; tall tiles of large frames: one workgroup per CU, 16 waves
     if (tune.col_threads == 128 || tune.col_threads == 256 || tune.col_threads == 512 || tune.col_threads == 1024) P->col_threads = tune.col_threads;
-    if (allow_lds(k_colx16<0>, P->lds_col) != hipSuccess || allow_lds(k_colx16<8>, P->lds_col) != hipSuccess || allow_lds(k_colx16<12>, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
+    if (allow_lds(k_colx16, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
         allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
         (!P->tw_compact && allow_lds(k_row, P->lds_row > P->rs_lds ? P->lds_row : P->rs_lds) != hipSuccess) ||
         (P->tw_compact && allow_lds(k_row4k, P->rs_lds) != hipSuccess)) {
@@ -1954,8 +1911,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
                 ncu = v;
         }
         const int tiles_pf = nfc * (N2 / a.W);
-        int per_cu = std::min(blocks_per_cu(k_colx16<0>, 256, P->lds_col), std::min(blocks_per_cu(k_colx16<8>, 256, P->lds_col), blocks_per_cu(k_colx16<12>, 256, P->lds_col)));
-        if (tune.fused_per_cu > 0 && tune.fused_per_cu < per_cu) per_cu = tune.fused_per_cu;
+        const int per_cu = blocks_per_cu(k_colx16, 256, P->lds_col);
         const int cap = ncu * per_cu;
         if (tiles_pf <= cap) {
             P->fused = 1;
@@ -1996,33 +1952,6 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
                 a.e1tab = P->d_e1; a.e2tab = P->d_e2; a.d1slope = D; a.tmax = tmax;
             }
         }
-    }
-    // Optional working copy with a padded row pitch for the fused sweep (single-field frames of 256 x 256 or 256 x 4096
-    // samples).  The hypotheses it was built to test -- rows 64 KiB apart camp on one L2 channel; the four slow tiles of a
-    // 2^16 frame set the pace of its barrier -- did not pay (profiles/r03_notes.md): off unless PLX_SSFM_WPAD >= 0.
-    if (P->fused && nfc == 1 && !a.pmd && (P->tw_compact || P->p2 == 8)) {
-        const int pad = tune.wpad >= -1 ? tune.wpad : kDefaultWorkPad;
-        if (pad >= 0) {
-            P->wpitch = N2 + pad;
-            const size_t per_pol = (size_t)F * nfc * N1 * P->wpitch;
-            if (hipMalloc((void **)&P->d_work, 2 * per_pol * sizeof(cplx)) != hipSuccess) {
-                free_plan(P);
-                PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed (working copy of the field)");
-            }
-        }
-    }
-    // Cache-resident frame groups (plx_ssfm_propagate_dev): group_mib MiB of field per group, a whole number of rounds of
-    // the fused sweep's teams.  0 / unset groups: the whole batch at once.
-    {
-        const double frame_mib = (double)nfc * (double)N * (a.dual ? 32.0 : 16.0) / (1024.0 * 1024.0);
-        const double mib = tune.group_mib >= 0 ? tune.group_mib : kDefaultGroupMiB;
-        int G = mib > 0 ? (int)(mib / frame_mib) : 0;
-        if (G > 0) {
-            const int teams = P->fused ? P->fused_grid / P->tiles_pf : 1;
-            if (G > teams) G -= G % teams;
-            if (G < 1) G = 1;
-        }
-        P->group_frames = G;
     }
     if (a.pmd && !a.dual) { free_plan(P); PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_create: PMD needs a dual-polarisation plan"); }
     if (!a.pmd) { // fiber.m:291-297: birefringence off
@@ -2114,7 +2043,7 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         }
         return;
     }
-    if (P->rowr && !a.force && !a.hmul && !a.umat && !a.wx) {
+    if (P->rowr && !a.force && !a.hmul && !a.umat) {
         if (a.pmd) PLX_LAUNCH(k_row256r<true>, dim3(128u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
         else PLX_LAUNCH(k_row256r<false>, dim3(128u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
         return;
@@ -2144,24 +2073,13 @@ static int resolve_profiles(plx_ssfm *P)
     return PLX_OK;
 }
 
-// One GROUP of frames through the whole step loop (fiber.m:518-552).  g0: first frame of the group within the call.
-static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nframes, hipStream_t st)
+// The frames of one call through the whole step loop (fiber.m:518-552).
+static int propagate_frames(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int nframes, hipStream_t st)
 {
     SsfmArgs a = P->a;
     const int nfc = a.nfc, N1 = 1 << a.p1, N2 = 1 << a.p2;
-    // everything indexed by frame is addressed from the group's first frame: the kernels see frames 0 .. nframes-1
-    a.ux = d_ux + (size_t)g0 * nfc * P->N;
-    a.uy = d_uy ? d_uy + (size_t)g0 * nfc * P->N : nullptr;
-    a.ctl = P->d_ctl + g0;
-    a.umax = P->d_umax + (size_t)g0 * nfc;
-    if (a.brf_per_frame) a.brf = P->d_brf + (size_t)g0 * a.nplates * BRF_STRIDE;
-    if (a.psum) a.psum = P->d_psum + (size_t)g0 * P->N;
-    if (P->d_work) {
-        const size_t per_pol = (size_t)P->d.max_frames * nfc * N1 * P->wpitch;
-        a.wx = P->d_work + (size_t)g0 * nfc * N1 * P->wpitch;
-        a.wy = a.wx + per_pol;
-        a.wpitch = P->wpitch;
-    }
+    a.ux = d_ux;
+    a.uy = d_uy;
     a.nframes = nframes;
     a.active = P->d_active;
     a.nactive = P->d_ndone + 2;
@@ -2189,9 +2107,6 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
     // steps are launch-bound: the sweeps skip a listed frame that has finished meanwhile)
     const bool compact_every_step = nframes >= 64;
     int chunk = 4, steps = 0;
-    // (a group that follows another one of the same call starts with the steps the previous group needed, less a
-    //  margin: frames of a batch usually resemble each other, and every launch past a group's end is an idle one)
-    if (g0 > 0 && P->last_group_steps > 12) chunk = P->last_group_steps - 4;
     const int kMaxSteps = 1 << 19;      // (far beyond any physical span; also below the period of the mailbox tags of k_colx16)
     bool pending = false, aborted = false;
     // profiling: an event in front of every launch of the loop (and one after the last); intervals are attributed to
@@ -2231,9 +2146,7 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
 #endif
                 a.round = steps + sidx;
                 PLX_MARK(0, steps + sidx);
-                if (a.wx && a.p2 == 12) PLX_LAUNCH(k_colx16<12>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
-                else if (a.wx) PLX_LAUNCH(k_colx16<8>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
-                else PLX_LAUNCH(k_colx16<0>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
+                PLX_LAUNCH(k_colx16, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
 #endif
@@ -2285,7 +2198,7 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
         else if (chunk < (compact_every_step ? 8 : 16)) chunk *= 2;   // (small batches are launch-bound: longer chunks keep the queue fed)
         if (steps > kMaxSteps) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: step loop did not terminate");
     }
-    PLX_HIP(hipMemcpyAsync(P->h_ctl.data() + g0, a.ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost, st));
+    PLX_HIP(hipMemcpyAsync(P->h_ctl.data(), a.ctl, sizeof(FrameCtl) * nframes, hipMemcpyDeviceToHost, st));
     PLX_HIP(hipMemcpyAsync(P->h_ndone, P->d_ndone, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
     PLX_HIP(hipStreamSynchronize(st));
     P->slots_listed += P->h_ndone[3];
@@ -2301,13 +2214,12 @@ static int propagate_group(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int g0, int nfra
                                   "or create such plans with plx_ssfm_create_ex(..., PLX_SSFM_SHARE_DEVICE)");
     }
     int maxnc = 0;
-    for (int f = g0; f < g0 + nframes; f++) {
+    for (int f = 0; f < nframes; f++) {
         P->frame_steps += P->h_ctl[f].ncycle + (fused ? 1 : 0);   // (the fused sweep's last round writes the field out)
         if (!P->h_ctl[f].done) PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_propagate_dev: a frame did not reach the fibre end");
         P->sample_steps += (int64_t)P->h_ctl[f].ncycle * (int64_t)P->N * nfc;
         if (P->h_ctl[f].ncycle > maxnc) maxnc = P->h_ctl[f].ncycle;
     }
-    P->last_group_steps = maxnc + (fused ? 1 : 0);
     if (!run.ev.empty()) {
         run.maxnc = maxnc; run.fused = fused;
         P->prof_pending.push_back(std::move(run));
@@ -2325,15 +2237,8 @@ extern "C" int plx_ssfm_propagate_dev(plx_ssfm *P, double *d_ux, double *d_uy, i
     if (P->a.brf_per_frame && P->brf_sets < nframes)
         PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_propagate_dev: fewer birefringence sets than frames");
     P->slots_launched = 0; P->slots_listed = 0; P->row_launches = 0; P->sample_steps = 0; P->frame_steps = 0;
-    // Frames are independent (fiber.m:518: each has its own step sequence), so a large batch is taken through the span in
-    // GROUPS whose fields fit the 256 MiB Infinity Cache: a group's ~50 steps x 2 sweeps then re-read what the previous
-    // sweep left on the die instead of streaming the whole batch from HBM twice per step (plan: group_frames).
-    const int G = P->group_frames > 0 ? P->group_frames : nframes;
-    for (int g0 = 0; g0 < nframes; g0 += G) {
-        const int nf = nframes - g0 < G ? nframes - g0 : G;
-        const int rc = propagate_group(P, (cplx *)d_ux, (cplx *)d_uy, g0, nf, (hipStream_t)stream);
-        if (rc) return rc;
-    }
+    const int rc = propagate_frames(P, (cplx *)d_ux, (cplx *)d_uy, nframes, (hipStream_t)stream);
+    if (rc) return rc;
     PLX_HIP(hipGetLastError());
     return PLX_OK;
 }

@@ -288,8 +288,8 @@ def test_power_ladder_batch_every_frame_keeps_the_reference_step_count(lib, orac
     hp.close()
 
 
-@pytest.mark.parametrize("nspans,wpad", [(3, None), (40, None), (3, "8")])
-def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monkeypatch, nspans, wpad):
+@pytest.mark.parametrize("nspans", [3, 40])
+def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monkeypatch, nspans):
     """Config[4]'s shape: 8 frames of 2^20 samples on a steep launch-power ladder, three spans -- and the FORTY spans
     config[4] states (the shape whose stale-list walk once stalled the fused sweep).  A 2^20 frame is ONE
     team of the fused column sweep (512 tiles = the whole grid), and batches under 64 frames rebuild the active list only once
@@ -302,8 +302,7 @@ def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monk
     F = 8
     dbm = -4.0 + 12.0 * np.arange(F) / (F - 1)
     out = []
-    # (wpad: the fused sweep on the plan's own working copy of the field, rows 64 KiB + 128 B apart: PLX_SSFM_WPAD)
-    for env in (({"PLX_SSFM_WPAD": wpad} if wpad else {}), {"PLX_SSFM_NO_FUSE": "1"}):
+    for env in ({}, {"PLX_SSFM_NO_FUSE": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, nspans=nspans)
@@ -393,15 +392,11 @@ def test_sentinel_landing_of_the_staged_tile_equals_the_ordinary_wait(lib, monke
     F = 5
     dbm = np.array([-3.0, 0.0, 2.0, 4.0, 6.0])
     res = {}
-    # ("wpad": the same sweeps on the plan's own working copy of the field, rows 4 KiB + 128 B apart -- PLX_SSFM_WPAD, off by
-    #  default: the arithmetic does not depend on where the field lives)
-    # (the working copy's padded rows are served by the LDS-resident k_row, which rounds the inter-pass twiddles differently
-    #  from the register form k_row256r: "wpad" is compared with "ldsrow", the same row pass on the caller's arrays)
-    # ("early": the fused sweep's stores issued before the next tile has landed, the order of one-team launches; "fwdrows":
+    # ("ldsrow": the LDS-resident k_row, which rounds the inter-pass twiddles differently from the register form k_row256r)
+    # ("early": the fused sweep's stores issued before the next tile has landed, the order one-team launches keep; "fwdrows":
     #  the row pass over the listed frames in ascending order -- both only move work in time)
     for name, env in (("eager", {}), ("safe", {"PLX_SSFM_SAFE_LANDING": "1"}), ("early", {"PLX_SSFM_STORE_LATE": "0"}),
-                      ("fwdrows", {"PLX_SSFM_ROW_REV": "0"}), ("ldsrow", {"PLX_SSFM_ROWR": "0"}),
-                      ("wpad", {"PLX_SSFM_WPAD": "8", "PLX_SSFM_ROWR": "0"})):
+                      ("fwdrows", {"PLX_SSFM_ROW_REV": "0"}), ("ldsrow", {"PLX_SSFM_ROWR": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         cfg = pipeline.HotPathConfig(nsymb=1024, nt=64, variants=2)
@@ -427,7 +422,7 @@ def test_sentinel_landing_of_the_staged_tile_equals_the_ordinary_wait(lib, monke
         hp.close()
     ref = res["eager"][0]
     assert max(ref[2]) > min(ref[2])           # frames leave the loop at different steps
-    for name, base in (("eager", "eager"), ("safe", "eager"), ("early", "eager"), ("fwdrows", "eager"), ("ldsrow", "ldsrow"), ("wpad", "ldsrow")):
+    for name, base in (("eager", "eager"), ("safe", "eager"), ("early", "eager"), ("fwdrows", "eager"), ("ldsrow", "ldsrow")):
         ref = res[base][0]
         for o in res[name]:
             assert torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]), name
