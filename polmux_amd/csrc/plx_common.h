@@ -77,6 +77,30 @@ __device__ __forceinline__ cplx cexp_neg_turns(double x)
     return make_double2(c, -sI);
 }
 
+// The same value through a 64-entry table of the unit circle, T[k] = (cos, -sin)(2 pi k / 64) (LDS or L1), and a short
+// polynomial on the remainder |d| <= pi/64: 20 FP64 operations and no quadrant logic where cexp_neg_turns needs 26 plus a
+// four-way select -- for kernels that are bound by their instruction issue (k_row4k: profiles/r04_notes.md).  The
+// remainder r - q/64 is exact (both on r's grid), the truncation terms d^11/11! and d^10/10! are below 1e-20.
+#define PLX_CTAB 64
+__device__ __forceinline__ cplx cexp_neg_turns_tab(double x, const cplx *T)
+{
+    const double r = x - rint(x);            // [-0.5, 0.5] turns, exact
+    const double q = rint(64.0 * r);         // -32 .. 32
+    const double d = fma(q, -0.015625, r) * 6.28318530717958647692;
+    const cplx w = T[(int)q & (PLX_CTAB - 1)];
+    const double z = d * d;
+    double ps = fma(z, 1.0 / 362880.0, -1.0 / 5040.0);
+    ps = fma(z, ps, 1.0 / 120.0);
+    ps = fma(z, ps, -1.0 / 6.0);
+    const double sn = fma(d * z, ps, d);
+    double pc = fma(z, 1.0 / 40320.0, -1.0 / 720.0);
+    pc = fma(z, pc, 1.0 / 24.0);
+    pc = fma(z, pc, -0.5);
+    const double cs = fma(z, pc, 1.0);
+    // exp(-i (a + d)) with w = (cos a, -sin a): (cos a cos d - sin a sin d, -(sin a cos d + cos a sin d))
+    return make_double2(fma(w.y, sn, w.x * cs), fma(-w.x, sn, w.y * cs));
+}
+
 // Keep a batch of global loads issued back-to-back: an empty asm that "uses" the loaded value
 // stops the compiler from sinking each load next to its (conditional) consumer, where it would
 // be followed by s_waitcnt vmcnt(0) and serialise the batch.
@@ -97,25 +121,6 @@ __device__ __forceinline__ void pin_uniform(int &v) { asm volatile("" : "+s"(v))
 // the instruction scheduler moves nothing across this point (keeps the live ranges of unrolled iterations apart)
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
-
-// A field store with a cache policy chosen at build time (A/B of the sweeps' stores; PLX_STORE_POLICY 0 plain, 1 nt, 2 sc1)
-#ifndef PLX_STORE_POLICY
-#define PLX_STORE_POLICY 0
-#endif
-__device__ __forceinline__ void st_field(cplx *p, cplx v)
-{
-#if defined(PLX_EMU) || PLX_STORE_POLICY == 0
-    *p = v;
-#else
-    typedef double d2v __attribute__((ext_vector_type(2)));
-    d2v w; w[0] = v.x; w[1] = v.y;
-#if PLX_STORE_POLICY == 1
-    __builtin_nontemporal_store(w, (d2v *)p);
-#else
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
-#endif
-#endif
-}
 
 // ---- DPP lane exchange inside a 16-lane row (no LDS crossbar on the critical path) ----
 // xor-1 / xor-2 are quad permutes; 7 and 15 are the row_half_mirror / row_mirror pairings

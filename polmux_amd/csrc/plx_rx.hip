@@ -221,9 +221,6 @@ __device__ __forceinline__ double max16(double v)
 #endif
 __global__ __launch_bounds__(CMA16_THREADS) void k_cma16(DemuxArgs a)
 {
-#if defined(PLX_CMA_PRIO) && !defined(PLX_EMU)
-    __builtin_amdgcn_s_setprio(PLX_CMA_PRIO);   // (A/B: the few latency-bound waves of this kernel ahead of a neighbour's streaming waves)
-#endif
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x;
     const int l16 = threadIdx.x & 15, r = l16 >> 3, t = l16 & 7;
     const int grp = gtid >> 4;

@@ -64,6 +64,7 @@ struct SsfmArgs {
     const cplx *hmul;              // [N] general spectral multiplier replacing exp(-i betat dz) (filter passes), same order
     const cplx *umat;              // [F][N][3] per frequency: SU(2) row (U11, U12) and scalar Hgvd; applies (Hgvd U)^H (inverse_pmd.m:130-141)
     const cplx *tw1, *tw2;         // half tables W_N1^k, W_N2^k
+    const cplx *ctab;              // [PLX_CTAB] (cos, -sin)(2 pi k / 64): cexp_neg_turns_tab (k_row4k)
     const double *gam;             // [nfc] effective gamma (x8/9 when Manakov, :499-501)
     const double *brf;             // [sets][nplates][9]: R11 R12 R21 R22 (re,im) db0
     // PMD plans whose db1 is LINEAR in the signed frequency index m (fiber.m:358: db1 = dgdrms*omega): the trunk phase
@@ -1030,6 +1031,7 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     cplx *tw = s + 4352;                         // W_4096^{4k}, k < 512, then W_4096^0..3
     cplx *bk = tw + 516;                         // tpass[256 k], k < 16
     cplx *t8 = bk + 16;                          // W_256^e at e + (e >> 2), e < 128
+    cplx *ct = t8 + 160;                         // the unit circle in 64 steps (cexp_neg_turns_tab)
     const size_t N = (size_t)1 << (a.p1 + a.p2);
     const size_t rowbase = (size_t)brow << 12;
     cplx *const u = (bpol ? a.uy : a.ux) + (size_t)fc * N + rowbase;
@@ -1050,6 +1052,7 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
             if (tid < 4) tw[512 + tid] = t2;
             if (tid < 16) bk[tid] = t3;
             if (tid < 128) t8[tid + (tid >> 2)] = t4;
+            if (tid < PLX_CTAB) ct[tid] = a.ctab[tid];
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) pin(x[k]);
@@ -1089,7 +1092,7 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
         } else {
             const double cur = a.force ? a.f_cur : ctl->cur;
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = cmul(cexp_neg_turns(btv[k] * cur), x[k]);
+            for (int k = 0; k < 16; k++) x[k] = cmul(cexp_neg_turns_tab(btv[k] * cur, ct), x[k]);
         }
     }
     r16_dit(x);
@@ -1109,7 +1112,7 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     for (int k = 0; k < 16; k++) x[k] = s[row_phys(tid + 256 * k)];
     lvl2_dit<256>(x, tid, w1);
 #pragma unroll
-    for (int k = 0; k < 16; k++) st_field(&u[jo + 256 * k], cmulc(x[k], cmul(tb, bk[k])));
+    for (int k = 0; k < 16; k++) u[jo + 256 * k] = cmulc(x[k], cmul(tb, bk[k]));
 }
 
 // ------------------------------------------------------ pass 3: inverse columns ---
@@ -1248,12 +1251,7 @@ __device__ __forceinline__ void glds_rows(const cplx *src, size_t stride, cplx *
     unsigned lb = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void *)lds_wave_base);
     unsigned long long p = (unsigned long long)src;
     const unsigned long long st = (unsigned long long)stride * sizeof(cplx);
-#ifdef PLX_GLDS_NT
-#define PLX_GLDS_AUX " nt"
-#else
-#define PLX_GLDS_AUX ""
-#endif
-#define PLX_GLDS_STEP "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" PLX_GLDS_AUX "\n\tv_lshl_add_u64 %0, %0, 0, %2\n\ts_add_u32 %1, %1, 0x400\n\t"
+#define PLX_GLDS_STEP "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off\n\tv_lshl_add_u64 %0, %0, 0, %2\n\ts_add_u32 %1, %1, 0x400\n\t"
     asm volatile(PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP
                  PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP PLX_GLDS_STEP
                  : "+v"(p), "+s"(lb) : "s"(st) : "memory", "m0", "scc");
@@ -1496,7 +1494,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             const int nf = (int)red[10 + (it & 1)];    // (the team's next frame, or -1: none left)
             if (nf >= 0) stage(nf, (it & 1) ^ 1);  // (every thread is past its reads of s: the barrier above)
 #pragma unroll
-            for (int k = 0; k < 16; k++) st_field(&fld[cbase + (size_t)(j + 16 * k) * N2], y[k]);
+            for (int k = 0; k < 16; k++) fld[cbase + (size_t)(j + 16 * k) * N2] = y[k];
         } else {
             if (a.spm) {                   // Kerr step of step s+1 (:832-852) on registers
                 const double gamleff = gaml[c] * leff;
@@ -1584,7 +1582,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                 }
             }
 #pragma unroll
-            for (int k = 0; k < 16; k++) st_field(&fld[cbase + (size_t)(16 * j + k) * N2], x[k]);
+            for (int k = 0; k < 16; k++) fld[cbase + (size_t)(16 * j + k) * N2] = x[k];
             // [phase 7] staging issue + r16_dif + stores issued
         }
         f = (int)red[10 + (it & 1)];
@@ -1605,7 +1603,7 @@ struct plx_ssfm {
     size_t N;
     SsfmArgs a;
     double *d_betat = nullptr, *d_db1 = nullptr, *d_gam = nullptr, *d_brf = nullptr, *d_psum = nullptr;
-    cplx *d_tpass = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr;
+    cplx *d_tpass = nullptr, *d_tw1 = nullptr, *d_tw2 = nullptr, *d_ctab = nullptr;
     FrameCtl *d_ctl = nullptr;
     unsigned long long *d_umax = nullptr;
     int *d_ndone = nullptr;   // [0] frames done, [1] abort word, [2] frames in the active list, [3] its running sum over the steps
@@ -1659,7 +1657,7 @@ static void free_plan(plx_ssfm *P)
 {
     if (!P) return;
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
-    hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctl); hipFree(P->d_umax);
+    hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctab); hipFree(P->d_ctl); hipFree(P->d_umax);
     hipFree(P->d_dzlist); hipFree(P->d_dzlog);
     hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active); hipFree(P->d_e1); hipFree(P->d_e2);
     if (P->h_ndone) hipHostFree(P->h_ndone);
@@ -1803,7 +1801,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
     if (a.dual && (N2 >= 2048 && !tune.no_row_split)) {   // measured: 2^20 frames 74 -> 66 ms; at N2 = 1024 it loses (47 -> 52)
         P->row_split = 1;
         P->rs_threads = N2 / 8 < ROW_THREADS ? ROW_THREADS : (N2 / 8 > 1024 ? 1024 : N2 / 8);
-        P->rs_lds = ((size_t)(N2 + N2 / 16) + (P->tw_compact ? N2 / 8 + 4 + 16 + 160 : N2 / 2)) * sizeof(cplx);   // (+16: k_row4k's bk, +160: its padded W_256 table)
+        P->rs_lds = ((size_t)(N2 + N2 / 16) + (P->tw_compact ? N2 / 8 + 4 + 16 + 160 + PLX_CTAB : N2 / 2)) * sizeof(cplx);   // (+16: k_row4k's bk, +160: its padded W_256 table, + the unit-circle table)
     }
     if (P->tw_compact && (!P->row_split || a.pmd)) {
         free_plan(P);
@@ -1868,6 +1866,14 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
     UP(P->d_tpass, tp, cplx);
     UP(P->d_tw1, t1, cplx);
     UP(P->d_tw2, t2, cplx);
+    {
+        std::vector<cplx> ctv(PLX_CTAB);
+        for (int k = 0; k < PLX_CTAB; k++) {
+            const long double ang = 2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)PLX_CTAB;
+            ctv[k] = make_double2((double)cosl(ang), (double)-sinl(ang));
+        }
+        UP(P->d_ctab, ctv, cplx);
+    }
     UP(P->d_gam, gam, double);
 #undef UP
     bool ok = hipMalloc((void **)&P->d_ctl, sizeof(FrameCtl) * F) == hipSuccess &&
@@ -1878,7 +1884,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
               hipEventCreateWithFlags(&P->ev, hipEventDisableTiming) == hipSuccess;
     if (ok && !a.dual && a.xpm) ok = hipMalloc((void **)&P->d_psum, sizeof(double) * (size_t)F * N) == hipSuccess;
     if (!ok) { free_plan(P); PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed"); }
-    a.betat_p = P->d_betat; a.db1_p = P->d_db1; a.tpass = P->d_tpass; a.tw1 = P->d_tw1; a.tw2 = P->d_tw2;
+    a.betat_p = P->d_betat; a.db1_p = P->d_db1; a.tpass = P->d_tpass; a.tw1 = P->d_tw1; a.tw2 = P->d_tw2; a.ctab = P->d_ctab;
     a.gam = P->d_gam; a.ctl = P->d_ctl; a.umax = P->d_umax; a.ndone = P->d_ndone; a.psum = P->d_psum;
     P->h_ctl.resize(F);
 
