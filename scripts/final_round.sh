@@ -12,9 +12,11 @@ if [ $part = lines ]; then
   timeout -k 10 300 python3 bench.py --frontend cohmix --no-cpu-baseline --mc-rounds 0 --no-gateway > $O/bench_cohmix.json 2>/dev/null || exit 1
   timeout -k 10 300 python3 bench.py --power-ladder --no-cpu-baseline --mc-rounds 0 --no-gateway > $O/bench_ladder.json 2>/dev/null || exit 1
   timeout -k 10 300 python3 bench.py --mc --no-cpu-baseline --no-gateway > $O/bench_mc.json 2>/dev/null || exit 1
-  timeout -k 10 300 python3 bench.py --nsymb 16384 --frames 16 --steps 2 --warmup 1 --variants 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_c4_frame.json 2>/dev/null || exit 1
-  timeout -k 10 600 python3 bench.py --nsymb 16384 --frames 8 --spans 40 --power-ladder --steps 1 --warmup 0 --variants 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_c4_40spans.json 2>/dev/null || exit 1
-  cat $O/bench_default.json $O/bench_no_overlap.json $O/bench_cohmix.json $O/bench_ladder.json $O/bench_mc.json $O/bench_c4_frame.json $O/bench_c4_40spans.json > $O/bench.jsonl
+  timeout -k 10 300 python3 bench.py --nsymb 16384 --frames 16 --steps 4 --warmup 1 --variants 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_c4_frame.json 2>/dev/null || exit 1
+  timeout -k 10 300 python3 bench.py --nsymb 16384 --frames 16 --steps 4 --warmup 1 --variants 1 --share-device no --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_c4_frame_fused.json 2>/dev/null || exit 1
+  timeout -k 10 600 python3 bench.py --nsymb 16384 --frames 8 --spans 40 --power-ladder --steps 2 --warmup 1 --variants 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_c4_40spans.json 2>/dev/null || exit 1
+  timeout -k 10 600 python3 bench.py --nch 16 --spans 10 --nf 5 --frames 32 --steps 3 --warmup 1 --mc-rounds 0 --no-gateway > $O/bench_c2.json 2>/dev/null || exit 1
+  cat $O/bench_default.json $O/bench_no_overlap.json $O/bench_cohmix.json $O/bench_ladder.json $O/bench_mc.json $O/bench_c4_frame.json $O/bench_c4_frame_fused.json $O/bench_c4_40spans.json $O/bench_c2.json > $O/bench.jsonl
   python3 - <<PY
 import json
 for l in open("$O/bench.jsonl"):
@@ -44,6 +46,11 @@ if [ $part = trace ]; then
   python3 scripts/prof_summary.py $f > $O/kernel_trace_2pow20_summary.md
   head -6 $O/kernel_trace_2pow20_summary.md
   rm -rf $O/prof3
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof4 -- python3 bench.py --nch 16 --spans 2 --nf 5 --frames 32 --steps 2 --warmup 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-overlap --no-gateway > /dev/null 2>&1 || exit 1
+  f=$(find $O/prof4 -name "*kernel_trace.csv" | head -1)
+  python3 scripts/prof_summary.py $f > $O/kernel_trace_wdm16_summary.md
+  head -6 $O/kernel_trace_wdm16_summary.md
+  rm -rf $O/prof4
 fi
 if [ $part = traffic ]; then
   scripts/traffic_pmc.sh 256 > $O/traffic.log 2>&1 && cp gpurun_out/traffic/traffic.json $O/traffic.json

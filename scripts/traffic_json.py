@@ -47,4 +47,11 @@ if os.path.exists(os.path.join(d, "big_FETCH_SIZE.txt")):      # 2^20-sample fra
                             "bytes_per_sample_step": sum(per.values()),
                             "note": "k_row4k: with the users of a row's tables (frames x polarisations) dealt to one XCD the tables come out of its L2 "
                                     "(64.7 B per sample; 75.5 B under the (row, frame, polarisation) grid of round 2: betat and the inter-pass twiddles re-read from HBM)"}
+if os.path.exists(os.path.join(d, "wdm_FETCH_SIZE.txt")):      # BASELINE config[2]'s frame: 16 'sepfields' channels of 2^16 samples, 'gps-', 32 frames per launch
+    fe, wr = read("wdm", "FETCH_SIZE"), read("wdm", "WRITE_SIZE")
+    sw = 32 * 16 * 65536
+    per = {k: (2 * fe[k] + wr[k]) * 1024 / sw for k in ("k_colx16", "k_row256r") if k in fe and k in wr}
+    res["wdm_16ch"] = {"samples_per_launch": sw, "kernels": list(per), "fetch_kb": [fe.get(k) for k in per], "write_kb": [wr.get(k) for k in per],
+                       "bytes_per_sample_by_kernel": per, "bytes_per_sample_step": sum(per.values()),
+                       "note": "a frame = 16 channels x 2^16 samples = one team of the fused sweep (512 tiles); row pass = k_row256r<PMD> (100 waveplates)"}
 print(json.dumps(res, indent=1))

@@ -54,9 +54,9 @@ def _rx_oracle(oracle, cfg, hp, ox, oy):
     return ref, oracle.samp2pat_coherent(np.angle(ref))
 
 
-def _screened_equal(got_bits, ref_sym, want_bits, tol=1e-6):
+def _screened_equal(got_bits, ref_sym, want_bits, tol=1e-10):
     """decisions bit-exact, except symbols whose phase sits within tol rad of a decision boundary (there the two sides'
-    1e-8 symbol difference may legitimately flip the bit)"""
+    1e-12 symbol difference may legitimately flip the bit: none observed)"""
     ph = np.angle(ref_sym)
     near = (np.abs(np.abs(ph) - np.pi / 2) < tol) | (np.abs(ph) < tol) | (np.abs(np.abs(ph) - np.pi) < tol)    # [nsymb x 2]
     mask = np.repeat(~near, 2, axis=1)
@@ -84,7 +84,7 @@ def test_c1_end_to_end_at_the_stated_cma_step(lib, oracle):
     assert np.abs(uy[0].cpu().numpy() - oy[:, 0]).max() <= FIELD_RTOL * np.abs(oy).max()
     ref, want = _rx_oracle(oracle, cfg, hp, ox[:, 0], oy[:, 0])
     sym = hp.sym[0].cpu().numpy().T
-    np.testing.assert_allclose(sym, ref, atol=1e-7)
+    np.testing.assert_allclose(sym, ref, atol=1e-11)
     e = [int((want[:, :2] != hp.bits[:, :2]).sum()), int((want[:, 2:] != hp.bits[:, 2:]).sum())]
     assert err.cpu().numpy()[0].tolist() == e
     assert int(hp.errors_min_over_rotations(2).sum()) == 0      # noise-free span: error-free once the pi/2 ambiguity is resolved
@@ -92,17 +92,19 @@ def test_c1_end_to_end_at_the_stated_cma_step(lib, oracle):
 
 
 # ================================================================================ C3 ===
-def test_c3_monte_carlo_realisations_pmd_and_ase_vs_oracle(lib, oracle):
+@pytest.mark.parametrize("mu,sampled", [(1 / 600, (0, 5, 11, 15)), (1 / 6000, (0, 2, 4, 7, 9, 11, 13, 15))])
+def test_c3_monte_carlo_realisations_pmd_and_ase_vs_oracle(lib, oracle, mu, sampled):
     """BASELINE config[3] (ex24_pmd.m-style PMD + ex20_coherent_polmux.m:132-175's noisy amplifier): McCampaign at the
     C1 frame (1024 x 64), fiber('gps-') with 100 waveplates drawn per realisation (fiber.m:260-276, set_random_pmd),
     then ampliflat(Gerbio,'gain',{f, noise}) with the ASE INJECTED (options.noise, ampliflat.m:123-129) so that the
     oracle sees the same noise, then the reference's own front end (receiver_cohmix gauss 1.9 / bessel5 0.65 + timing +
     decimate: the white ASE of the 1.8 THz simulation band must be filtered; no ADC, as in ex20) -> CDE_OFDE -> CMA + CPE.
-    Four sampled realisations of a 16-realisation batch are compared with oracle.matrix_ssfm + amplifier + receiver
+    Sampled realisations of a 16-realisation batch -- four at mu = 1/600, eight at the mu = 1/6000 that config[1] states (the
+    CMA's full 299-pass budget on every noise-loaded realisation) -- are compared with oracle.matrix_ssfm + amplifier + receiver
     chain: field 1e-9, ncycle, symbols, error counts."""
     from polmux_amd import pipeline
     from polmux_amd.ampliflat import ase_sigma
-    cfg = pipeline.HotPathConfig(flag="gps-", nplates=100, dgd=0.1, rx_amp=True, span_nf_db=31.0, cma_mu=1 / 600,
+    cfg = pipeline.HotPathConfig(flag="gps-", nplates=100, dgd=0.1, rx_amp=True, span_nf_db=31.0, cma_mu=mu,
                                  frontend="cohmix", adcbits=0)
     n = cfg.nfft
 
@@ -126,7 +128,7 @@ def test_c3_monte_carlo_realisations_pmd_and_ase_vs_oracle(lib, oracle):
     gain = math.exp(hp.alphalin * cfg.length)
     sigma = float(ase_sigma(cfg.span_nf_db, gain, 1)[0])
     ncs = set()
-    for pos in (0, 5, 11, 15):
+    for pos in sampled:
         r = idx[pos]
         db0, th, ep = (a[0] for a in hp.set_random_pmd([r]))           # the draw of realisation r (keyed by r alone)
         rc, fd, nc, ox, oy = oracle.matrix_ssfm(hp.tx_host[0], hp.tx_host[1], betat, db1, cfg.dzmax, cfg.dphimax, gam, hp.alphalin,
@@ -140,7 +142,7 @@ def test_c3_monte_carlo_realisations_pmd_and_ase_vs_oracle(lib, oracle):
         assert np.abs(kept["x"][pos] - ox).max() <= FIELD_RTOL * sc
         assert np.abs(kept["y"][pos] - oy).max() <= FIELD_RTOL * sc
         ref, want = _rx_oracle(oracle, cfg, hp, ox, oy)
-        np.testing.assert_allclose(sym_dev[pos].T, ref, atol=1e-6)
+        np.testing.assert_allclose(sym_dev[pos].T, ref, atol=1e-10)
         # the campaign's count = errors after pol-swap / pi/2 resolution (ex20:160-173): same resolution on the oracle's symbols
         best = None
         for swap in (False, True):
@@ -242,7 +244,7 @@ def test_c0_32gbaud_single_pol_linear_span_with_post_compensation(lib, oracle):
     op = oracle.dsp_params(power_mw=float(GSTATE.POWER[0]), applypol=False, freqavg=500, phasavg=3, poworder=2)
     ref = oracle.dsp_pdm_coh_qpsk(rx, op)
     got = amp.cpu().numpy() * np.exp(1j * phase.cpu().numpy())
-    np.testing.assert_allclose(got, ref, atol=1e-7)
+    np.testing.assert_allclose(got, ref, atol=1e-11)
     pat_hat = px.samp2pat(x, None, phase.cpu().numpy())
     want = oracle.samp2pat_coherent(np.angle(ref))
     np.testing.assert_array_equal(pat_hat, want)
