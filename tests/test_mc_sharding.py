@@ -82,6 +82,11 @@ def test_shard_indices():
     assert shard_indices(0, 8, 1, 4) == [1, 5]
     assert shard_indices(8, 8, 0, 4) == [8, 12]
     assert sum(len(shard_indices(0, 1024, r, 8)) for r in range(8)) == 1024
+    # BASELINE config[3] as stated (bench.py --mc-total 1024): one round of 1024 realisations over 8 ranks = 128 each,
+    # realisation r on rank r mod 8, every index taken exactly once
+    shards = [shard_indices(0, 1024, r, 8) for r in range(8)]
+    assert all(len(s_) == 128 for s_ in shards) and all(i % 8 == r for r, s_ in enumerate(shards) for i in s_)
+    assert sorted(i for s_ in shards for i in s_) == list(range(1024))
 
 
 class _FakeCampaign:
@@ -276,8 +281,8 @@ def test_bench_starts_its_own_ranks():
     env = dict(os.environ, PLX_BENCH_REHEARSAL="1")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--frames", "8",
-                          "--nsymb", "256", "--nt", "32", "--variants", "2", "--mc-rounds", "2", "--mc-frames", "4", "--no-cpu-baseline",
-                          "--no-single-frame"], env=env, capture_output=True, text=True, timeout=600)
+                          "--nsymb", "256", "--nt", "32", "--variants", "2", "--mc-rounds", "2", "--mc-frames", "4", "--mc-total", "12",
+                          "--no-cpu-baseline", "--no-single-frame"], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -285,6 +290,9 @@ def test_bench_starts_its_own_ranks():
     assert d["n_gpus"] == 2 and d["config"]["rehearsal_all_ranks_on_one_gpu"] is True
     assert d["config"]["bits"] == 2 * 8 * 4 * 256
     assert d["mc"]["realisations"] == 2 * 2 * 4 and d["mc"]["rounds"] == 2 and "gloo" in d["mc"]["exchange"]
+    # the strong-scaling leg (BASELINE config[3] as stated: a fixed total): 12 realisations in total = 6 per rank, ONE round, one exchange
+    ss = d["mc"]["strong_scaling"]
+    assert ss["realisations_total"] == 12 and ss["per_gpu"] == 6 and ss["realisations"] == 12 and ss["rounds"] == 1 and ss["exchanges"] == 1
     # without a rehearsal switch and without that many devices it refuses instead of silently running on one GPU
     env.pop("PLX_BENCH_REHEARSAL")
     if torch.cuda.device_count() < 2:
@@ -302,7 +310,7 @@ def test_bench_line_carries_the_contract_fields():
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PLX_BENCH_REHEARSAL"):
         env.pop(k, None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--frames", "32", "--nsymb", "256",
-                          "--nt", "64", "--variants", "2", "--mc-rounds", "1", "--mc-frames", "8", "--cpu-frames", "2"],
+                          "--nt", "64", "--variants", "2", "--mc-rounds", "1", "--mc-frames", "8", "--mc-total", "16", "--cpu-frames", "2"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -322,6 +330,10 @@ def test_bench_line_carries_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["unit"] == "Gsample/s" and c["value"] > 0 and "frame" in c["sample"]
     assert d["mc"]["realisations"] == 8 and d["mc"]["evm_mc_estimate"]["nruns"] == 8
+    assert d["mc"]["strong_scaling"]["per_gpu"] == 16 and d["mc"]["strong_scaling"]["realisations"] == 16
+    g = d["gateway"]["plx_cmapolardemux"]
+    assert g["passes"] == g["per_pass_mex_loop_passes"] == g["oracle_passes"] and g["allocations_in_repeats"] == 0
+    assert "fibre_step" in d["config"] and d["config"]["channels_per_frame"] == 1
 
 
 def _nccl_worker(q):
