@@ -1710,7 +1710,7 @@ struct Tune {
     Tune()
     {
         no_fuse = geti("PLX_SSFM_NO_FUSE", 0);
-        short_rows = geti("PLX_SSFM_SHORT_ROWS", 0);   // (A/B) three-sweep plans of 2^20-sample frames on the 512 x 2048 split instead of 256 x 4096
+        short_rows = geti("PLX_SSFM_SHORT_ROWS", 0);   // (A/B, tests) 2^20-sample frames on the 512 x 2048 split instead of 256 x 4096
         p1 = geti("PLX_SSFM_P1", -1);
         logW = geti("PLX_SSFM_LOGW", -1);
         col_threads = geti("PLX_SSFM_COL_THREADS", -1);
@@ -1759,10 +1759,10 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
         const int npol = desc->dual_pol ? 2 : 1;
         logW = desc->dual_pol ? 3 : 4;                       // 8 (dual) / 16 (scalar) columns per tile (measured best)
         int p1 = 12 - (logW + (npol == 2 ? 1 : 0));          // N1 * T = 4096 complex = 64 KiB
-        // 2^20-sample dual-polarisation frames without PMD keep the 256-row tile of the fused column sweep and take
-        // 4096-point rows instead (one polarisation per row workgroup, compact twiddle table: two workgroups per CU);
-        // everything else stops at 2048-point rows and gets taller column tiles
-        const bool long_rows = desc->dual_pol && !desc->fls[1] && desc->nfc == 1 && !tune.no_row_split && !(tune.no_fuse && tune.short_rows);
+        // 2^20-sample dual-polarisation frames without PMD -- one field or several 'sepfields' channels, fused or three-sweep
+        // step -- keep the 256-row column tile and take 4096-point rows instead (one polarisation per row workgroup, compact
+        // twiddle table: two workgroups per CU, k_row4k); everything else stops at 2048-point rows and gets taller column tiles
+        const bool long_rows = desc->dual_pol && !desc->fls[1] && !tune.no_row_split && !tune.short_rows;
         const int p2max = long_rows ? 12 : 11;
         if (p - p1 > p2max) p1 = p - p2max;                  // large frames: taller tiles instead
         if (p1 > p - 4) p1 = p - 4;                          // keep N2 >= 16

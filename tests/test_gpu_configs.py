@@ -553,3 +553,34 @@ def test_share_device_plan_runs_the_receiver_beside_the_next_fibre_bit_equal(lib
     for (s_, e_, n_), (gs, ge, gn) in zip(serial, got):
         assert torch.equal(s_, gs) and torch.equal(e_, ge) and n_.tolist() == gn.tolist()
     hp.close()
+
+
+def test_two_channel_2pow20_frames_long_rows_equal_the_short_row_split(lib, monkeypatch):
+    """A 'sepfields' field of two channels of 2^20 samples each (1024 column tiles per frame: more than the fused grid, so the
+    plan takes the three-sweep step) on the 256 x 4096 split -- k_col_fwd / k_col_inv on 256-row tiles, k_row4k with the channel
+    index in its workgroup map -- against the same frames on the 512 x 2048 split (PLX_SSFM_SHORT_ROWS=1: taller column tiles,
+    the LDS-resident k_row per polarisation): same step counts, fields to 1e-9; the channels walk off and carry different powers."""
+    import torch
+    from polmux_amd import pipeline
+    out = []
+    for env in ({}, {"PLX_SSFM_SHORT_ROWS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, nch=2, flag="g-s-", length=3e4, pavg_mw=4.0, variants=3)
+        hp = pipeline.HotPath(cfg, max_frames=2)
+        for k in env:
+            monkeypatch.delenv(k)
+        info = hp.info()
+        assert info[0] == 0 and info[2] == (11 if env else 12)
+        ux, uy = hp.make_batch(2, np.array([1.0, 2.5]))
+        hp.fibre(ux, uy)
+        _sync()
+        out.append((hp.last_ncycle(2).copy(), ux.cpu().numpy(), uy.cpu().numpy()))
+        hp.close()
+        del ux, uy
+        torch.cuda.empty_cache()
+    (nc0, x0, y0), (nc1, x1, y1) = out
+    assert nc0.tolist() == nc1.tolist() and nc0[1] > nc0[0] > 3
+    for a, b in ((x0, x1), (y0, y1)):
+        assert np.abs(a - b).max() <= FIELD_RTOL * np.abs(b).max()
+    assert np.abs(x0[0, 0] - x0[0, 1]).max() > 0.1 * np.abs(x0).max()          # the two channels really differ
