@@ -736,3 +736,94 @@ def test_emu_new_plan_argument_errors(emu):
     nt1 = np.array([2], dtype=np.int32)
     assert code("plx_pmdinv_set_link", plan, 1, _vp(nt1), _vp(z), _vp(z), _vp(z), _vp(z), _vp(one), _vp(one), None, 1, 2) == PLX_ERR_ARG
     emu.call("plx_pmdinv_destroy", plan)
+
+
+def test_emu_poldemux_driver_gateways(emu, oracle):
+    """plx_cmapolardemux / plx_easipolardemux: the whole driver loop (DspPdmCohQpsk.m:142-244) as one gateway call on host arrays
+    with MATLAB's separate planes -- staging layout x | M up, y | h | passes down --, against the oracle's driver loop.  L = 44
+    leaves a tail behind the last whole chunk of eight symbols; three taps make a one-sample cyclic extension."""
+    for L, taps, mu, phi in ((44, 7, 1 / 40, 0.0), (40, 3, 1 / 60, 0.25), (24, 1, 1 / 30, 0.0)):
+        x = _mixed_qpsk(L, 31 + taps, noise=0.003, th=0.03)
+        M = np.array([[np.cos(phi), np.sin(phi)], [-np.sin(phi), np.cos(phi)]], dtype=complex)       # :157-158
+        xr, xi = np.asfortranarray(x.real), np.asfortranarray(x.imag)
+        yr, yi = np.zeros((L, 2), order="F"), np.zeros((L, 2), order="F")
+        h = [np.zeros((taps, 2), order="F") for _ in range(4)]
+        n = C.c_int32()
+        R = np.array([1.0, 1.0])
+        Mi = _il(M.reshape(-1))
+        emu.call("plx_cmapolardemux", _vp(xr), _vp(xi), L, taps, mu, _vp(R), _vp(Mi), _vp(yr), _vp(yi), _vp(h[0]), _vp(h[1]), _vp(h[2]),
+                 _vp(h[3]), C.byref(n))
+        oy, h1, h2, on = oracle.cmapolardemux(x, M, taps, mu, R)
+        assert n.value == on and 1 <= on < 50 * int(np.ceil(1 / (L * mu)))
+        np.testing.assert_allclose(yr + 1j * yi, oy, atol=1e-11)
+        np.testing.assert_allclose(h[0] + 1j * h[1], h1.reshape(taps, 2), atol=1e-11)
+        np.testing.assert_allclose(h[2] + 1j * h[3], h2.reshape(taps, 2), atol=1e-11)
+    # a real-valued input without an imaginary plane, outputs without the optional taps / pass count
+    xr = np.asfortranarray(np.sign(np.random.default_rng(2).standard_normal((32, 2))))
+    yr, yi = np.zeros((32, 2), order="F"), np.zeros((32, 2), order="F")
+    emu.call("plx_cmapolardemux", _vp(xr), None, 32, 3, 1 / 50, _vp(R), _vp(_il(np.eye(2, dtype=complex).reshape(-1))), _vp(yr), _vp(yi),
+             None, None, None, None, None)
+    oy = oracle.cmapolardemux(xr.astype(complex), np.eye(2), 3, 1 / 50, R)[0]
+    np.testing.assert_allclose(yr + 1j * yi, oy, atol=1e-11)
+    with pytest.raises(Exception, match="Ntaps should be an ODD INTEGER"):
+        emu.call("plx_cmapolardemux", _vp(xr), None, 32, 4, 1 / 50, _vp(R), _vp(Mi), _vp(yr), _vp(yi), None, None, None, None, None)
+    # EASI: the C filter and its .m twin
+    L, mu = 40, 1 / 40
+    x = _mixed_qpsk(L, 77, noise=0.003, th=0.02)
+    xr, xi = np.asfortranarray(x.real), np.asfortranarray(x.imag)
+    for twin, ref in ((0, oracle.easipolardemux), (1, oracle.easipolardemux_m)):
+        yr, yi = np.zeros((L, 2), order="F"), np.zeros((L, 2), order="F")
+        n = C.c_int32()
+        emu.call("plx_easipolardemux", _vp(xr), _vp(xi), L, mu, _vp(_il(np.eye(2, dtype=complex).reshape(-1))), twin, _vp(yr), _vp(yi),
+                 None, None, None, None, C.byref(n))
+        oy, _, _, on = ref(x, np.eye(2), mu)
+        assert n.value == on
+        np.testing.assert_allclose(yr + 1j * yi, oy, atol=1e-11)
+
+
+def test_emu_step_sequence_replay_and_log(emu, oracle, monkeypatch):
+    """plx_ssfm_set_step_sequence / plx_ssfm_log_steps (the diagnostics behind the config[2] parity test), fused sweep and
+    three-sweep step: a plan that replays the oracle's list of step lengths makes the oracle's steps (same ncycle, first step
+    bit-equal, field to 1e-12); left to itself it logs a sequence that agrees with the oracle's to 1e-12 on this
+    band-limited frame; a replayed list that differs from the rule's changes the result (the list really is used)."""
+    n, nt, L = 4096, 64, 4e3
+    fls = [1, 0, 1, 0]
+    betat, db1 = _tables(n, nt, fls, 1)
+    f = _qpsk_field(n, nt, 40.0)
+    rc, ofd, onc, ox, oy, odz = oracle.matrix_ssfm(f[0], f[1], betat, db1, 2e3, 0.08, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0],
+                                                   return_dz=True)
+    assert rc == 0 and onc == len(odz) and 4 <= onc <= 12
+    for env in ({"PLX_EMU_CUS": "1"}, {"PLX_SSFM_NO_FUSE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 2e3, 0.08, betat, db1)
+        plan = C.c_void_p()
+        emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+        for k in env:
+            monkeypatch.delenv(k)
+        nc, fd = np.zeros(1, np.int32), np.zeros(1)
+
+        def run():
+            ux, uy = _il(f[0]), _il(f[1])
+            emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 1, None)
+            emu.call("plx_ssfm_results", plan, 1, _vp(fd), _vp(nc))
+            return ux.view(np.complex128), uy.view(np.complex128)
+        emu.call("plx_ssfm_log_steps", plan, 64)
+        gx, gy = run()                                              # free-running, logged
+        log = np.zeros(64)
+        emu.call("plx_ssfm_step_sequence", plan, 0, _vp(log), 64)
+        assert nc[0] == onc
+        np.testing.assert_allclose(log[:onc], odz, rtol=1e-12)
+        emu.call("plx_ssfm_log_steps", plan, 0)
+        emu.call("plx_ssfm_set_step_sequence", plan, _vp(np.ascontiguousarray(odz)), len(odz))
+        rx, ry = run()                                              # the oracle's sequence replayed
+        assert nc[0] == onc and fd[0] == ofd
+        assert np.abs(rx - ox[:, 0]).max() < 1e-12 * np.abs(ox).max() and np.abs(ry - oy[:, 0]).max() < 1e-12 * np.abs(oy).max()
+        other = np.full(3, L / 3 + 1.0)                             # three equal steps instead of the rule's
+        emu.call("plx_ssfm_set_step_sequence", plan, _vp(other), 3)
+        sx, _ = run()
+        assert nc[0] == 3 and np.abs(sx - rx).max() > 1e-6 * np.abs(rx).max()
+        emu.call("plx_ssfm_set_step_sequence", plan, None, 0)
+        tx, _ = run()                                               # switched off again: the free-running result
+        np.testing.assert_array_equal(tx, gx)
+        emu.call("plx_ssfm_destroy", plan)
