@@ -70,11 +70,17 @@ __device__ __forceinline__ cplx cexp_neg_turns(double x)
     pc = fma(z, pc, 1.0 / 24.0);
     pc = fma(z, pc, -0.5);
     const double cs = fma(z, pc, 1.0);
-    // angle = psi + q*pi/2; result = cos(angle) - i sin(angle)
+    // angle = psi + q*pi/2; result = cos(angle) - i sin(angle):
+    //   q mod 4 = 0: (cs, -sn)   1: (-sn, -cs)   2: (-cs, sn)   3: (sn, cs)
+    // as a swap for odd q and two sign flips on the high words -- no branch (the four-way selects compiled to exec-masked
+    // blocks: ~20 instructions and two branches per call; the values are the same to the bit)
     const int qi = (int)q & 3;               // -2 -> 2, -1 -> 3
-    const double c = (qi == 0) ? cs : (qi == 1) ? -sn : (qi == 2) ? -cs : sn;
-    const double sI = (qi == 0) ? sn : (qi == 1) ? cs : (qi == 2) ? -sn : -cs;
-    return make_double2(c, -sI);
+    const bool odd = (qi & 1) != 0;
+    const double c0 = odd ? sn : cs, s0 = odd ? cs : sn;
+    const unsigned long long cflip = (unsigned long long)((qi + 1) & 2) << 62;   // the real part is negated for q = 1, 2
+    const unsigned long long sflip = (unsigned long long)((qi & 2) ^ 2) << 62;   // the imaginary part is -s0 for q = 0, 1, +s0 for q = 2, 3
+    return make_double2(__longlong_as_double((long long)((unsigned long long)__double_as_longlong(c0) ^ cflip)),
+                        __longlong_as_double((long long)((unsigned long long)__double_as_longlong(s0) ^ sflip)));
 }
 
 // The same value through a 64-entry table of the unit circle, T[k] = (cos, -sin)(2 pi k / 64) (LDS or L1), and a short
