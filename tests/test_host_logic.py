@@ -131,6 +131,23 @@ def test_reset_all_and_lasersource():
     np.testing.assert_array_equal(px.GSTATE.POWER, [2.0, 2.0, 2.0])
     with pytest.raises(ValueError, match="missing the channel-spacing"):
         px.lasersource(2.0, 1550.0)
+    # the reference's own documented example, lasersource.m:18: Nch=4, lam=1550, spac=0.8 -> lambda=[1548.8 1549.6 1550.4 1551.2]
+    px.reset_all(32, 8, 4)
+    px.lasersource(1.0, 1550.0, 0.8)
+    np.testing.assert_allclose(px.GSTATE.LAMBDA, [1548.8, 1549.6, 1550.4, 1551.2], rtol=0, atol=1e-9)
+
+
+def test_corrdelay_reference_signal_of_the_documented_example():
+    """corrdelay.m:12-15: 'if PAT='1101' and Nt=4 the reference transmitted signal turns out to be ... x=1111111100001111': a
+    current equal to that signal delayed by k samples is found k samples late, reported as (k + Nt/2) / Nt symbols (:113: the
+    delay is counted from the symbol's centre), with rho = 2 max(c) / Nfft (:114) = 2 x 12 ones / 16."""
+    import polmux_amd as px
+    pat, nt = np.array([1, 1, 0, 1]), 4
+    x = np.array([int(c) for c in "1111111100001111"], dtype=float)
+    np.testing.assert_array_equal(np.repeat(pat, nt), x)                     # the signal the function builds, :91
+    for k in (0, 3, 6):
+        delay, wrn, rho, _ = px.corrdelay(np.roll(x, k), pat, nt, 4)
+        assert delay == pytest.approx((k + nt / 2) / nt) and rho == pytest.approx(1.5) and not wrn
 
 
 # --------------------------------------------------------------------- synth ---
