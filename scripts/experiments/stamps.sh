@@ -18,7 +18,7 @@ if [ "$1" = build ]; then
   hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o polmux_amd/lib/libpolmux_hip_stamps.so
   exit 0
 fi
-F=${2:-1024} MK=${3:-no} NSYMB=${4:-1024} timeout -k 10 200 python - <<'PY'
+F=${2:-1024} MK=${3:-no} NSYMB=${4:-1024} NCH=${5:-1} FLAG=${6:-g-s-} timeout -k 10 200 python - <<'PY'
 import os, sys, time, ctypes as C
 sys.path.insert(0, os.getcwd())
 import torch
@@ -26,7 +26,7 @@ from polmux_amd import _abi
 _abi.LIB_PATH = os.path.join(os.path.dirname(_abi.LIB_PATH), "libpolmux_hip_stamps.so")
 from polmux_amd import pipeline
 F = int(os.environ["F"])
-hp = pipeline.HotPath(pipeline.HotPathConfig(flag="g-s-", manakov=os.environ["MK"], nsymb=int(os.environ["NSYMB"])), max_frames=F)
+hp = pipeline.HotPath(pipeline.HotPathConfig(flag=os.environ["FLAG"], manakov=os.environ["MK"], nsymb=int(os.environ["NSYMB"]), nch=int(os.environ["NCH"])), max_frames=F)
 lib = _abi.get().lib
 out = (C.c_longlong * (32 + 3072))()
 hp.profile(True)

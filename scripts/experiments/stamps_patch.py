@@ -21,12 +21,12 @@ HOST = 'extern "C" void plx_ssfm_stamps(long long *out, int reset)\n{\n    hipDe
 
 def main():
     s = open(SRC).read()
-    anchor = "template <int WP2> __global__ __launch_bounds__(256, 2) void k_colx16("
+    anchor = "__global__ __launch_bounds__(256, 2) void k_colx16("
     assert anchor in s
     s = s.replace(anchor, DEFS + "\n" + anchor, 1)
-    rot = "    const int c = WORK ? 0 : ti / tiles_x, bx = ti - c * tiles_x;"
+    rot = "    const int c = ti / tiles_x, bx = ti - c * tiles_x;"
     assert rot in s
-    s = s.replace(rot, "#ifndef PLX_TILE_ROT\n#define PLX_TILE_ROT 0\n#endif\n    const int tiq = (ti + PLX_TILE_ROT) % tiles_pf;\n    const int c = WORK ? 0 : tiq / tiles_x, bx = tiq - c * tiles_x;", 1)
+    s = s.replace(rot, "#ifndef PLX_TILE_ROT\n#define PLX_TILE_ROT 0\n#endif\n    const int tiq = (ti + PLX_TILE_ROT) % tiles_pf;\n    const int c = tiq / tiles_x, bx = tiq - c * tiles_x;", 1)
     s, n = re.subn(r"^(\s*)// \[phase (\d+)\]", lambda m: "%sPLX_STAMP(%s); //" % (m.group(1), m.group(2)), s, flags=re.M)
     assert n >= 9, n
     for name, body in BLOCKS.items():
@@ -36,7 +36,7 @@ def main():
     s += "\n" + HOST + "\n"
     csrc = os.path.join(ROOT, "polmux_amd", "csrc")
     s = s.replace('#include "../../include/polmux_hip.h"', '#include "%s"' % os.path.join(ROOT, "include", "polmux_hip.h"))
-    for h in ("plx_fft.h", "plx_internal.h"):
+    for h in ("plx_fft.h", "plx_internal.h", "plx_gateway.h"):
         s = s.replace('#include "%s"' % h, '#include "%s"' % os.path.join(csrc, h))
     os.makedirs(os.path.dirname(DST), exist_ok=True)
     open(DST, "w").write(s)
