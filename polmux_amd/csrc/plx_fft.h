@@ -205,6 +205,54 @@ __device__ __forceinline__ void lvl2_dit256(cplx *y, int j, const cplx *tw)
         y[r1] = cadd(s0, s2); y[r1 + 4] = cadd(s1, s3); y[r1 + 8] = csub(s0, s2); y[r1 + 12] = csub(s1, s3);
     }
 }
+// The same two levels with the ODD twiddles of the m = 256 stage (W^k8, W^3k8) taken from a second table, twa.  With twa = -tw
+// the stage's odd outputs change sign, which for the inverse form is the same as delivering the upper and lower halves of
+// y[] swapped (y[r1] <-> y[r1+8], y[r1+4] <-> y[r1+12]: s0 +- s2, s1 +- s3 with s2, s3 negated), and for the forward form the
+// same as ACCEPTING them swapped -- exactly, bit for bit (negations are exact).  k_colx16 gives the lanes of the second
+// polarisation the negated table, so that between its two transforms the register pair (k, k + 8) of a lane pair (t, t ^ 8)
+// holds the two polarisations of ONE sample without any per-lane select.
+__device__ __forceinline__ void lvl2_dit256s(cplx *y, int j, const cplx *tw, const cplx *twa)
+{
+    const int k6 = 4 * j;
+    const cplx u1 = tw[k6], u2 = tw[2 * k6], u3 = tw3(tw, 3 * k6, 128);
+#pragma unroll
+    for (int r2 = 0; r2 < 4; r2++) { // m = 64
+        cplx c0 = y[4 * r2], c2 = y[4 * r2 + 1], c1 = y[4 * r2 + 2], c3 = y[4 * r2 + 3];
+        c1 = cmulc(c1, u1); c2 = cmulc(c2, u2); c3 = cmulc(c3, u3);
+        const cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
+        y[4 * r2] = cadd(s0, s2); y[4 * r2 + 1] = cadd(s1, s3); y[4 * r2 + 2] = csub(s0, s2); y[4 * r2 + 3] = csub(s1, s3);
+    }
+#pragma unroll
+    for (int r1 = 0; r1 < 4; r1++) { // m = 256
+        const int k8 = j + 16 * r1;
+        cplx c0 = y[r1], c2 = y[r1 + 4], c1 = y[r1 + 8], c3 = y[r1 + 12];
+        c1 = cmulc(c1, twa[k8]); c2 = cmulc(c2, tw[2 * k8]); c3 = cmulc(c3, tw3(twa, 3 * k8, 128));
+        const cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
+        y[r1] = cadd(s0, s2); y[r1 + 4] = cadd(s1, s3); y[r1 + 8] = csub(s0, s2); y[r1 + 12] = csub(s1, s3);
+    }
+}
+__device__ __forceinline__ void lvl2_dif256s(cplx *y, int j, const cplx *tw, const cplx *twa)
+{
+#pragma unroll
+    for (int r1 = 0; r1 < 4; r1++) { // m = 256
+        const int k8 = j + 16 * r1;
+        const cplx a0 = y[r1], a1 = y[r1 + 4], a2 = y[r1 + 8], a3 = y[r1 + 12];
+        const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
+        cplx y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+        y1 = cmul(y1, twa[k8]); y2 = cmul(y2, tw[2 * k8]); y3 = cmul(y3, tw3(twa, 3 * k8, 128));
+        y[r1] = cadd(t0, t2); y[r1 + 4] = y2; y[r1 + 8] = y1; y[r1 + 12] = y3;
+    }
+    const int k6 = 4 * j;
+    const cplx u1 = tw[k6], u2 = tw[2 * k6], u3 = tw3(tw, 3 * k6, 128);
+#pragma unroll
+    for (int r2 = 0; r2 < 4; r2++) { // m = 64
+        const cplx a0 = y[4 * r2], a1 = y[4 * r2 + 1], a2 = y[4 * r2 + 2], a3 = y[4 * r2 + 3];
+        const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
+        cplx y1 = cadd(t1, t3), y2 = csub(t0, t2), y3 = csub(t1, t3);
+        y1 = cmul(y1, u1); y2 = cmul(y2, u2); y3 = cmul(y3, u3);
+        y[4 * r2] = cadd(t0, t2); y[4 * r2 + 1] = y2; y[4 * r2 + 2] = y1; y[4 * r2 + 3] = y3;
+    }
+}
 __device__ __forceinline__ void lvl2_dif256(cplx *y, int j, const cplx *tw)
 {
 #pragma unroll

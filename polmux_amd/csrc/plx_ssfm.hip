@@ -1332,6 +1332,17 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     // [stamps:init]
     double *const gaml = (double *)((char *)(lctl + 8) + 128);    // gam[channel] (at most COLX_NFC channels: checked by the plan)
     for (int k = tid; k < a.nfc; k += 256) gaml[k] = a.gam[k];
+    // The lanes of the second polarisation (t >= 8) take the odd twiddles of the two m = 256 stages from a NEGATED copy of the
+    // table (lvl2_dit256s / lvl2_dif256s): between the inverse and the forward transform their registers hold the halves of
+    // the tile's points swapped, y[k] = point j + 16 (k ^ 8), so that the register pair (k, k + 8) of the lane pair (t, t ^ 8)
+    // is the two polarisations of ONE sample -- for k < 8 the X lane's sample k and the Y lane's sample k + 8 -- and the
+    // frame maximum and the Kerr step need no per-lane selects (130 v_cndmask per tile before).  Exact: negations only.
+    cplx *const twn = (cplx *)(gaml + COLX_NFC);
+    if (tid < 128) { const cplx w = a.tw1[tid]; twn[tid] = make_double2(-w.x, -w.y); }
+    // (the per-lane table pointer and the LDS distance between the halves of a column, 2048 elements for the lanes that swap
+    //  them, are re-derived from t where they are used: held across the tile loop they cost the two registers that spill)
+#define COLX_TWA(tp) (((tp) >= 8) ? (const cplx *)twn : (const cplx *)tw)
+#define COLX_HSW(tp) (((tp) >= 8) ? 2048 : 0)
     int f = team < nact ? a.active[team] : -1;
     if (f < 0) return;                     // (more teams than frames)
     stage(f, 0);
@@ -1404,22 +1415,34 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         }
         lds_barrier();
         // [phase 2] r16_dit + exchange write + workgroup barrier
-        cplx y[16];                        // point j + 16k
+        cplx y[16];                        // point j + 16k (lanes t >= 8: j + 16 (k ^ 8) from here to the forward transform)
+        {
+            // (a frame that has not started yet is read with the halves swapped; a started one gets them swapped by the
+            //  negated twiddles of the inverse transform's last stage)
+            int tp = t;
+            pin(tp);
+            const int ysw = started ? 0 : COLX_HSW(tp);
 #pragma unroll
-        for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
+            for (int k = 0; k < 8; k++) y[k] = s[((j + 16 * k) << 4) + t + ysw];
+#pragma unroll
+            for (int k = 8; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t - ysw];
+        }
         double sc = 1.0;
         if (started) {                     // finish step s: ifft (1/N), attenuation (:531-532)
-            lvl2_dit256(y, j, tw);
+            lvl2_dit256s(y, j, tw, COLX_TWA(t));
             sc = wrec->att * a.invN;
         }
+#pragma unroll
+        for (int k = 0; k < 16; k++) y[k] = cscale(y[k], sc);
         double m = 0;
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            y[k] = cscale(y[k], sc);
-            // the other polarisation of the same sample lives in lane t^8: |ux|^2 + |uy|^2 from the two lanes' own
-            // powers (the same instructions on both, and a + b == b + a: the pair agrees to the bit)
+        for (int k = 0; k < 8; k++) {
+            // |ux|^2 + |uy|^2 of ONE sample: this lane's y[k] and the partner lane's y[k + 8] (lane t ^ 8).  The X lane forms
+            // it for the samples k < 8, the Y lane for k + 8: the pair covers the column, each sum once (the same two powers
+            // added as before: a + b == b + a, the maximum is the same to the bit)
             const double po = fma(y[k].y, y[k].y, y[k].x * y[k].x);
-            const double p = po + lane_xchg<8>(po);
+            const double pq = fma(y[k + 8].y, y[k + 8].y, y[k + 8].x * y[k + 8].x);
+            const double p = po + lane_xchg<8>(pq);
             m = fmax(p, m);
         }
         m = wave_max(m);
@@ -1493,8 +1516,16 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         if (finished) {                    // the frame has reached the fibre end: write the field out
             const int nf = (int)red[10 + (it & 1)];    // (the team's next frame, or -1: none left)
             if (nf >= 0) stage(nf, (it & 1) ^ 1);  // (every thread is past its reads of s: the barrier above)
+            {
+                int tq = t, jq = j;        // (opaque here: the sixteen row offsets of this once-per-frame store are not loop invariants
+                pin(tq);                   //  worth thirty-two registers of the tile loop)
+                pin(jq);
+                const int rsw = tq >= 8 ? 128 : 0;         // (the second polarisation's lanes hold the halves swapped)
 #pragma unroll
-            for (int k = 0; k < 16; k++) fld[cbase + (size_t)(j + 16 * k) * N2] = y[k];
+                for (int k = 0; k < 8; k++) fld[cbase + (size_t)(jq + 16 * k + rsw) * N2] = y[k];
+#pragma unroll
+                for (int k = 8; k < 16; k++) fld[cbase + (size_t)(jq + 16 * k - rsw) * N2] = y[k];
+            }
         } else {
             if (a.spm) {                   // Kerr step of step s+1 (:832-852) on registers
                 const double gamleff = gaml[c] * leff;
@@ -1514,10 +1545,8 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                         constexpr bool CNLSE = decltype(cn)::value;
 #pragma unroll
                         for (int k = 0; k < 8; k++) {
-                            int tk = tq;
-                            pin(tk);               // (the pair's operands are selected HERE: not for all pairs ahead of the loop,
-                            const bool isx = tk < 8;   //  nor -- common to the two equations -- ahead of the branch between them)
-                            const cplx own = isx ? y[k] : y[k + 8], snd = isx ? y[k + 8] : y[k];
+                            // (y[k] is this lane's polarisation of ITS sample, y[k + 8] the partner's sample: see twn above)
+                            const cplx own = y[k], snd = y[k + 8];
                             const cplx oth = make_double2(lane_xchg<8>(snd.x), lane_xchg<8>(snd.y));
                             const double P = fma(own.y, own.y, own.x * own.x) + fma(oth.y, oth.y, oth.x * oth.x);
                             double sn, cs;
@@ -1536,25 +1565,32 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                                 A = A2;
                             }
                             const cplx back = make_double2(lane_xchg<8>(B.x), lane_xchg<8>(B.y));
-                            y[k] = isx ? A : back;
-                            y[k + 8] = isx ? back : A;
+                            y[k] = A;
+                            y[k + 8] = back;
                             sched_fence();         // (one sample pair at a time: a lone wave's FP64 rate does not depend on
                         }                          //  interleaving, and the pairs' operands need not all be selected up front)
                     };
                     if (a.manakov) kerr16(std::false_type{}); else kerr16(std::true_type{});
                 } else {
+                    int tp = t;            // (the tile goes through the exchange buffer in its natural layout)
+                    pin(tp);
+                    const int ksw = COLX_HSW(tp);
 #pragma unroll
-                    for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
+                    for (int k = 0; k < 8; k++) s[((j + 16 * k) << 4) + t + ksw] = y[k];
+#pragma unroll
+                    for (int k = 8; k < 16; k++) s[((j + 16 * k) << 4) + t - ksw] = y[k];
                     lds_barrier();
                     if (isx) kerr_full_range(j, t, gamleff, a.manakov);
                     lds_barrier();
 #pragma unroll
-                    for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
+                    for (int k = 0; k < 8; k++) y[k] = s[((j + 16 * k) << 4) + t + ksw];
+#pragma unroll
+                    for (int k = 8; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t - ksw];
                     lds_barrier();
                 }
             }
             // [phase 5] Kerr step
-            lvl2_dif256(y, j, tw);
+            lvl2_dif256s(y, j, tw, COLX_TWA(t));
 #pragma unroll
             for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
             lds_barrier();
@@ -1888,7 +1924,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
     a.gam = P->d_gam; a.ctl = P->d_ctl; a.umax = P->d_umax; a.ndone = P->d_ndone; a.psum = P->d_psum;
     P->h_ctl.resize(F);
 
-    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double) + 8 * sizeof(FrameCtl) + 128 + COLX_NFC * sizeof(double);   // (128: CtrlK)
+    P->lds_col = (((size_t)N1 << a.logT) + N1 / 2) * sizeof(cplx) + 32 * sizeof(double) + 8 * sizeof(FrameCtl) + 128 + COLX_NFC * sizeof(double) + 128 * sizeof(cplx);   // (128: CtrlK; 128 cplx: k_colx16's negated W_256 table)
     // [stamps:lds]
     P->lds_row = ((size_t)(a.dual ? 2 : 1) * a.R * (N2 + N2 / 16) + N2 / 2) * sizeof(cplx);
     P->col_threads = P->lds_col > 80 * 1024 ? 1024 : 512;   // measured: 512-thread column workgroups (2 per CU, 16 waves) beat

@@ -25,3 +25,6 @@ extern "C" int plx_test_spin(int workgroups, int threads, int lds_bytes, double 
                        (long long)(seconds * 1e8), sink);           // wall_clock64: 100 MHz on gfx950
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
+
+// the host waits for the spinner (a helper process keeps the device until its kernel has finished)
+extern "C" int plx_test_spin_wait(void) { return hipDeviceSynchronize() == hipSuccess ? 0 : -1; }

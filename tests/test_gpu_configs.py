@@ -468,17 +468,27 @@ def test_campaign_on_a_plan_that_cannot_share_the_gpu_keeps_one_stream(lib):
 
 def test_gateway_falls_back_to_three_sweeps_when_another_kernel_holds_the_gpu(lib, oracle, monkeypatch):
     """fiber.m:372-389 always returns a field.  A 16-channel frame is ONE team of the fused sweep (512 tiles = the whole grid):
-    its workgroups must all be resident to meet at the frame barrier.  With a bounded spinning kernel of another stream holding
-    the LDS of half the CUs (tests/gpuhelpers/spin.hip: 'another process on the device') they cannot; the barrier times out,
+    its workgroups must all be resident to meet at the frame barrier.  With a bounded spinning kernel of ANOTHER PROCESS holding
+    the LDS of half the CUs (tests/gpuhelpers/spin.hip, launched by a helper process: streams of one process may share a
+    hardware queue, in which case the two kernels would simply run one after the other) they cannot; the barrier times out,
     nothing is stored after the time-out, and plx_matrix_ssfm repeats the span from its pinned staging copy on the barrier-free
     three-sweep step: the call SUCCEEDS, the field is the oracle's, plx_gateway_stats_ex counts the fallback, and the cached
     plan stays on the three-sweep step afterwards."""
     import os
+    import subprocess
+    import sys
     import torch
     from tests.test_gpu_parity import _desc, _fibre_case, _vp
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spin = C.CDLL(os.path.join(root, "tests", "gpuhelpers", "_build", "libplxspin.so"))
-    spin.plx_test_spin.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    so = os.path.join(root, "tests", "gpuhelpers", "_build", "libplxspin.so")
+    # 128 workgroups x 120 KiB of LDS for 3 s: no column workgroup (70 KiB) fits beside one, so at most 2 x 128 of the 512 are
+    # resident.  The helper prints a line once its kernel is launched and exits when the kernel has finished.
+    helper = ("import ctypes as C, sys\n"
+              "s = C.CDLL(%r)\n"
+              "s.plx_test_spin.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]\n"
+              "rc = s.plx_test_spin(128, 256, 120 * 1024, 3.0, None)\n"
+              "print('spinning' if rc == 0 else 'failed %%d' %% rc, flush=True)\n"
+              "sys.exit(s.plx_test_spin_wait() if rc == 0 else 1)\n") % so
     lib.call("plx_release_all")
     monkeypatch.setenv("PLX_SSFM_BARRIER_TIMEOUT_MS", "150")
     c = _fibre_case(1024, 64, "g-s-", 1.0, nfc=16, length=1.5e4)
@@ -492,11 +502,14 @@ def test_gateway_falls_back_to_three_sweeps_when_another_kernel_holds_the_gpu(li
         lib.call("plx_gateway_stats_ex", v.ctypes.data, 9)
         return v
     s0 = stats()
-    side = torch.cuda.Stream()
-    # 128 workgroups x 120 KiB of LDS: no column workgroup (66 KiB) fits beside one, so at most 2 x 128 of the 512 are resident
-    assert spin.plx_test_spin(128, 256, 120 * 1024, 2.0, C.c_void_p(side.cuda_stream)) == 0
-    lib.call("plx_matrix_ssfm", *[_vp(p) for p in planes], C.byref(d), _vp(z), _vp(z), _vp(z), C.byref(fd), C.byref(nc))
-    s1 = stats()
+    torch.cuda.synchronize()
+    proc = subprocess.Popen([sys.executable, "-c", helper], stdout=subprocess.PIPE, text=True)
+    try:
+        assert proc.stdout.readline().strip() == "spinning"
+        lib.call("plx_matrix_ssfm", *[_vp(p) for p in planes], C.byref(d), _vp(z), _vp(z), _vp(z), C.byref(fd), C.byref(nc))
+        s1 = stats()
+    finally:
+        assert proc.wait(timeout=60) == 0
     torch.cuda.synchronize()
     assert s1[8] == s0[8] + 1, "the span did not take the fallback (was the frame co-resident after all?)"
     rc, ofd, onc, ox, oy = oracle.matrix_ssfm(c["ux"], c["uy"], c["t"]["betat"], c["t"]["db1"], c["dzm"], c["dph"], c["t"]["gam"],
