@@ -89,7 +89,7 @@ def parse():
                     help="fibre plan on the barrier-free three-sweep step (plx_ssfm_create_ex, PLX_SSFM_SHARE_DEVICE) so that a frame "
                          "that is the whole grid of the fused sweep (2^20 samples, 16 channels) can propagate BESIDE the previous "
                          "batch's receiver; auto: where such a plan's receiver takes more than 0.18 of its fibre's time (the three-sweep "
-                         "step costs the fibre ~15 %: profiles/r04_three_sweep_rows_ab.txt)")
+                         "step costs the fibre ~15 %%: profiles/r04_three_sweep_rows_ab.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rx-thread", action="store_true", help="enqueue the receiver from the fibre's host thread (A/B)")
     ap.add_argument("--no-single-frame", action="store_true", help="skip the one-frame latency measurement after the timed region")

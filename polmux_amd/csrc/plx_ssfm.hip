@@ -997,11 +997,19 @@ struct Tw256pad {
         return make_double2(neg ? -w.x : w.x, neg ? -w.y : w.y);
     }
 };
-__global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
+// PAIR (PMD plans, and the matrix tables of inverse_pmd): the waveplate trunks of matrix_step (fiber.m:907-933) need both
+// polarisations of a bin in one lane.  One workgroup of 512 threads then holds the row of BOTH polarisations (two padded rows,
+// 148 KiB: one workgroup per CU, the same eight waves): lanes 0-31 of a wave are 32 threads of the X row, lanes 32-63 the
+// same 32 threads of the Y row, so that the holders of a bin's two polarisations are lanes i and i + 32 of one wave and trade
+// halves (half_trade: v_permlane32_swap, no LDS, no barrier) around the multiplier exactly as k_row256r<PMD> does.  Everything
+// else -- the three register levels, the four exchanges, the blocks of sixteen threads that stay inside a wave -- is the
+// one-polarisation kernel with the thread's index within its row (tj) in the place of tid.
+template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void k_row4k(SsfmArgs a)
 {
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
-    const int tid = threadIdx.x;
+    const int tid = PAIR ? (int)((threadIdx.x >> 6) * 32u + (threadIdx.x & 31u)) : (int)threadIdx.x;   // the thread's index within its row
+    const int ts = threadIdx.x;                  // (staging of the shared tables: the workgroup's first 256 threads)
     // Workgroup -> (row, frame-channel, polarisation).  The users of a row's tables (betat: 32 KiB, tpass: 64 KiB per row, the
     // same for every frame and both polarisations) are dealt to ONE XCD -- workgroups 8 apart under the round-robin dealing --
     // and next to each other in time: id = 8 K g + 8 k + c with row = 8 g + c and k = 2 (frame-channel) + polarisation < K,
@@ -1010,15 +1018,20 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     // Measured (profiles/r03_row4k_map_ab.txt): FETCH_SIZE 3.57e5 -> 2.68e5 KB per 16-frame launch, 319 -> 314 us; no change at 64
     // frames; but 8 frames (config[4]'s ladder) run 3 - 5 % SLOWER that way, so batches under 16 frames keep the plain order
     // (row fastest, then frame-channel, then polarisation).
+    // (PAIR: k = the frame-channel, both polarisations in the workgroup)
     const int K = (int)(gridDim.x >> a.p1), lg = a.p1 < 3 ? a.p1 : 3, G = 1 << lg;     // (G = 8 rows to a group; fewer rows: all of them)
     int brow, by, bpol;
-    if (K >= 32) {
+    if (K >= (PAIR ? 16 : 32)) {
         const int g8 = (int)blockIdx.x / (G * K), rem = (int)blockIdx.x - g8 * G * K, bk2 = rem >> lg;
-        brow = g8 * G + (rem & (G - 1)); by = bk2 >> 1; bpol = bk2 & 1;
+        brow = g8 * G + (rem & (G - 1)); by = PAIR ? bk2 : bk2 >> 1; bpol = bk2 & 1;
+    } else if (PAIR) {
+        const int N1 = 1 << a.p1;
+        brow = (int)blockIdx.x & (N1 - 1); by = (int)blockIdx.x >> a.p1; bpol = 0;
     } else {
         const int N1 = 1 << a.p1, q = (int)blockIdx.x >> a.p1, FCn = K >> 1;
         brow = (int)blockIdx.x & (N1 - 1); bpol = q / FCn; by = q - bpol * FCn;
     }
+    if (PAIR) bpol = (int)((threadIdx.x >> 5) & 1u);
     int slot = by / a.nfc;
     const int c = by - slot * a.nfc;
     if (!row_slot(a, slot)) return;
@@ -1027,8 +1040,8 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     const int fc = f * a.nfc + c;
     const FrameCtl *ctl = a.ctl + f;
     if (ctl->done) return;
-    cplx *s = (cplx *)lds;                       // [4352] padded row: physical(p) = p + (p >> 4)
-    cplx *tw = s + 4352;                         // W_4096^{4k}, k < 512, then W_4096^0..3
+    cplx *s = (cplx *)lds + (PAIR ? bpol * 4352 : 0);    // [4352] padded row: physical(p) = p + (p >> 4)
+    cplx *tw = (cplx *)lds + (PAIR ? 2 : 1) * 4352;      // W_4096^{4k}, k < 512, then W_4096^0..3
     cplx *bk = tw + 516;                         // tpass[256 k], k < 16
     cplx *t8 = bk + 16;                          // W_256^e at e + (e >> 2), e < 128
     cplx *ct = t8 + 160;                         // the unit circle in 64 steps (cexp_neg_turns_tab)
@@ -1046,13 +1059,13 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = u[tid + 256 * k];
         // (the row is asked for first: the tables, a few KiB out of the L2, arrive behind it under the same wait)
-        {
-            const cplx t0 = a.tw2[tid], t1 = a.tw2[tid + 256], t2 = a.tw2[512 + (tid & 3)], t3 = tp[256 * (tid & 15)], t4 = a.tw2[4 * (tid & 127)];
-            tw[tid] = t0; tw[tid + 256] = t1;
-            if (tid < 4) tw[512 + tid] = t2;
-            if (tid < 16) bk[tid] = t3;
-            if (tid < 128) t8[tid + (tid >> 2)] = t4;
-            if (tid < PLX_CTAB) ct[tid] = a.ctab[tid];
+        if (!PAIR || ts < 256) {
+            const cplx t0 = a.tw2[ts], t1 = a.tw2[ts + 256], t2 = a.tw2[512 + (ts & 3)], t3 = tp[256 * (ts & 15)], t4 = a.tw2[4 * (ts & 127)];
+            tw[ts] = t0; tw[ts + 256] = t1;
+            if (ts < 4) tw[512 + ts] = t2;
+            if (ts < 16) bk[ts] = t3;
+            if (ts < 128) t8[ts + (ts >> 2)] = t4;
+            if (ts < PLX_CTAB) ct[ts] = a.ctab[ts];
         }
 #pragma unroll
         for (int k = 0; k < 16; k++) pin(x[k]);
@@ -1073,16 +1086,75 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
     ROWR_SYNC();                                 // (the block's sixteen threads are lanes of one wave)
     // the step's multiplier at the 16 bins this thread holds (lin_step :771-773 / matrix_step with matR = I): the phases are
     // asked for HERE, one exchange and one register level ahead of their use (16 more registers fit beside r16_dif)
-    double btv[16];
-    if (!a.hmul) {
-        const double *bt = a.betat_p + (size_t)c * N + rowbase + 16 * tid;
+    // (PAIR: the eight bins whose two polarisations the lane holds after the trade -- the lower half of the wave the thread's
+    //  bins 0-7, the upper half bins 8-15)
+    const int ib = 16 * tid + (PAIR && bpol ? 8 : 0);
+    double btv[PAIR ? 8 : 16];
+    if (!a.hmul && !(PAIR && a.umat)) {
+        const double *bt = a.betat_p + (size_t)c * N + rowbase + ib;
 #pragma unroll
-        for (int k = 0; k < 16; k++) btv[k] = bt[k];
+        for (int k = 0; k < (PAIR ? 8 : 16); k++) btv[k] = bt[k];
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[17 * tid + k];             // row_phys(16 tid + k)
     r16_dif(x);
-    {
+    if (PAIR && !a.hmul) {
+        if (a.umat) {
+            // Uinv = conj(Hgvd) [conj(U11) -U12; conj(U12) U11] applied to [x; y]  (inverse_pmd.m:130-141; k_row's form, bin by bin)
+            const cplx *um = a.umat + 3 * ((size_t)f * N + rowbase + ib);
+#pragma unroll
+            for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);   // x[k] = ux, x[k + 8] = uy of bin ib + k
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const cplx u11 = um[3 * k], u12 = um[3 * k + 1], hg = um[3 * k + 2], p = x[k], q = x[k + 8];
+                x[k] = cmulc(csub(cmulc(p, u11), cmul(u12, q)), hg);
+                x[k + 8] = cmulc(cadd(cmulc(p, u12), cmul(u11, q)), hg);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
+        } else {
+            const double cur = a.force ? a.f_cur : ctl->cur;
+            const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * BRF_STRIDE : 0);
+            const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem;
+#pragma unroll
+            for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
+            if (a.e1tab && ntrunk <= a.tmax) {
+                const int N1 = 1 << a.p1;
+                const cplx *e1 = a.e1tab + (size_t)f * a.tmax * N1 + brow, *e2 = a.e2tab + ((size_t)f * a.tmax << 12) + ib;
+                // (pmd_trunks_tab with the trunk loop outside the bins: a trunk's plate and row phasor are fetched once)
+                for (int t = 0; t < ntrunk; t++) {
+                    int plate = n0 + t;
+                    plate = plate < 0 ? 0 : (plate >= a.nplates ? a.nplates - 1 : plate);
+                    const double *m = brf + (size_t)plate * BRF_STRIDE;
+                    const double s11 = m[0];
+                    const cplx s12 = make_double2(m[1], m[2]);
+                    const cplx e1v = e1[(size_t)t * N1];
+                    const cplx *e2t = e2 + ((size_t)t << 12);
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const cplx e = cmul(e1v, e2t[k]);
+                        const cplx u = x[k], v = x[k + 8];
+                        const cplx sx = cadd(cscale(u, s11), cmul(s12, v));
+                        const cplx sy = csub(cmulc(u, s12), cscale(v, s11));
+                        x[k] = make_double2(e.x * u.x - e.y * sx.y, e.x * u.y + e.y * sx.x);
+                        x[k + 8] = make_double2(e.x * v.x - e.y * sy.y, e.x * v.y + e.y * sy.x);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const cplx h = cexp_neg_turns_tab(btv[k] * cur, ct);
+                    x[k] = cmul(h, x[k]);
+                    x[k + 8] = cmul(h, x[k + 8]);
+                }
+            } else {
+                const double *d1 = a.db1_p + (size_t)c * N + rowbase + ib;
+                const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last;
+                for (int k = 0; k < 8; k++) pmd_trunks(x[k], x[k + 8], btv[k], d1[k], brf, a.nplates, n0, ntrunk, dzb_first, dzb_last, a.lcorr, cur);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
+        }
+    } else {
         if (a.hmul) {
             int o16 = 16 * tid;
             pin(o16);
@@ -1092,7 +1164,7 @@ __global__ __launch_bounds__(256, 2) void k_row4k(SsfmArgs a)
         } else {
             const double cur = a.force ? a.f_cur : ctl->cur;
 #pragma unroll
-            for (int k = 0; k < 16; k++) x[k] = cmul(cexp_neg_turns_tab(btv[k] * cur, ct), x[k]);
+            for (int k = 0; k < (PAIR ? 8 : 16); k++) x[k] = cmul(cexp_neg_turns_tab(btv[k] * cur, ct), x[k]);    // (PAIR comes here with hmul only)
         }
     }
     r16_dit(x);
@@ -1664,6 +1736,8 @@ struct plx_ssfm {
     int row_split = 0, rs_threads = 0; // long rows without PMD: one polarisation per workgroup (scalar row pass twice)
     size_t rs_lds = 0;
     int tw_compact = 0;            // 4096-point rows: compact twiddle table in d_tw2, register-blocked row pass k_row4k
+    int row_pair4k = 0;            // ... of a PMD-type plan: both polarisations of a row in one workgroup (k_row4k<true>)
+    size_t rs_lds_pair = 0;
     double *h_brf[2] = {nullptr, nullptr}; // pinned staging of the waveplate tables
     hipEvent_t brf_ev[2] = {nullptr, nullptr};
     int brf_slot = 0;
@@ -1795,10 +1869,11 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
         const int npol = desc->dual_pol ? 2 : 1;
         logW = desc->dual_pol ? 3 : 4;                       // 8 (dual) / 16 (scalar) columns per tile (measured best)
         int p1 = 12 - (logW + (npol == 2 ? 1 : 0));          // N1 * T = 4096 complex = 64 KiB
-        // 2^20-sample dual-polarisation frames without PMD -- one field or several 'sepfields' channels, fused or three-sweep
-        // step -- keep the 256-row column tile and take 4096-point rows instead (one polarisation per row workgroup, compact
-        // twiddle table: two workgroups per CU, k_row4k); everything else stops at 2048-point rows and gets taller column tiles
-        const bool long_rows = desc->dual_pol && !desc->fls[1] && !tune.no_row_split && !tune.short_rows;
+        // 2^20-sample dual-polarisation frames -- one field or several 'sepfields' channels, fused or three-sweep step, with or
+        // without PMD -- keep the 256-row column tile and take 4096-point rows instead (k_row4k, compact twiddle table: one
+        // polarisation per row workgroup and two workgroups per CU, or with PMD both polarisations in one workgroup of twice
+        // the size); everything else stops at 2048-point rows and gets taller column tiles
+        const bool long_rows = desc->dual_pol && !tune.no_row_split && !tune.short_rows;
         const int p2max = long_rows ? 12 : 11;
         if (p - p1 > p2max) p1 = p - p2max;                  // large frames: taller tiles instead
         if (p1 > p - 4) p1 = p - 4;                          // keep N2 >= 16
@@ -1839,9 +1914,13 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
         P->rs_threads = N2 / 8 < ROW_THREADS ? ROW_THREADS : (N2 / 8 > 1024 ? 1024 : N2 / 8);
         P->rs_lds = ((size_t)(N2 + N2 / 16) + (P->tw_compact ? N2 / 8 + 4 + 16 + 160 + PLX_CTAB : N2 / 2)) * sizeof(cplx);   // (+16: k_row4k's bk, +160: its padded W_256 table, + the unit-circle table)
     }
-    if (P->tw_compact && (!P->row_split || a.pmd)) {
+    if (P->tw_compact && !P->row_split) {
         free_plan(P);
-        PLX_FAIL(PLX_ERR_UNSUPPORTED, "plx_ssfm_create: 4096-point rows need the one-polarisation row pass (no PMD)");
+        PLX_FAIL(PLX_ERR_UNSUPPORTED, "plx_ssfm_create: 4096-point rows need a dual-polarisation plan");
+    }
+    if (P->tw_compact) {
+        P->row_pair4k = desc->fls[1] ? 1 : 0;
+        P->rs_lds_pair = P->rs_lds + (size_t)(N2 + N2 / 16) * sizeof(cplx);
     }
     a.spm = desc->fls[2]; a.xpm = desc->fls[3]; a.manakov = desc->manakov ? 1 : 0; a.pmd = desc->fls[1] ? 1 : 0;
     a.nplates = desc->nplates;
@@ -1933,7 +2012,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
     if (allow_lds(k_colx16, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
         allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
         (!P->tw_compact && allow_lds(k_row, P->lds_row > P->rs_lds ? P->lds_row : P->rs_lds) != hipSuccess) ||
-        (P->tw_compact && allow_lds(k_row4k, P->rs_lds) != hipSuccess)) {
+        (P->tw_compact && (allow_lds(k_row4k<false>, P->rs_lds) != hipSuccess || allow_lds(k_row4k<true>, P->rs_lds_pair) != hipSuccess))) {
         free_plan(P);
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
     }
@@ -2071,12 +2150,16 @@ extern "C" int plx_ssfm_set_birefringence_dev(plx_ssfm *P, const double *db0, co
 static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t st)
 {
     const int N1 = 1 << a.p1;
+    if (P->tw_compact && a.dual && (a.pmd || a.umat)) {      // the multiplier couples the polarisations: both rows in one workgroup
+        PLX_LAUNCH(k_row4k<true>, dim3((unsigned)N1 * FC), dim3(512), P->rs_lds_pair, st, a);
+        return;
+    }
     if (P->row_split && a.dual && !a.pmd) {
         SsfmArgs b = a;
         b.dual = 0; b.R = 1; b.logR = 0;
         const dim3 gs((unsigned)N1, FC), bs((unsigned)P->rs_threads);
         if (P->tw_compact) {                     // (both polarisations in one launch: one tail instead of two)
-            PLX_LAUNCH(k_row4k, dim3(gs.x * gs.y * 2u), dim3(256), P->rs_lds, st, b);   // (rows x frame-channels x polarisations: decoded in the kernel)
+            PLX_LAUNCH(k_row4k<false>, dim3(gs.x * gs.y * 2u), dim3(256), P->rs_lds, st, b);   // (rows x frame-channels x polarisations: decoded in the kernel)
             return;
         }
         for (int pol = 0; pol < 2; pol++) {
@@ -2333,7 +2416,7 @@ extern "C" int plx_ssfm_info(plx_ssfm *P, int32_t *info)
 {
     if (!P || !info) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_info: null argument");
     info[0] = P->fused; info[1] = P->p1; info[2] = P->p2; info[3] = P->fused_grid; info[4] = P->tiles_pf;
-    info[5] = P->col_threads; info[6] = P->rowr ? ROWR_THREADS : (P->tw_compact ? 256 : (P->row_split ? P->rs_threads : P->row_threads)); info[7] = P->row_split;
+    info[5] = P->col_threads; info[6] = P->rowr ? ROWR_THREADS : (P->tw_compact ? (P->row_pair4k ? 512 : 256) : (P->row_split ? P->rs_threads : P->row_threads)); info[7] = P->row_pair4k ? 0 : P->row_split;
     return PLX_OK;
 }
 
@@ -2394,7 +2477,7 @@ int plx_ssfm_filter_dev(plx_ssfm *P, cplx *d_ux, cplx *d_uy, const cplx *d_hmul,
     PLX_HIP(hipMemsetAsync(P->d_ndone, 0, 64, st));
     const dim3 gcol((unsigned)(N2 / b.W), FC), grow((unsigned)(N1 / b.R), FC);
     PLX_LAUNCH(k_col_fwd, gcol, dim3((unsigned)P->col_threads), P->lds_col, st, b);
-    if (d_umat) PLX_LAUNCH(k_row, grow, dim3((unsigned)P->row_threads), P->lds_row, st, b);   // matrix tables couple the polarisations
+    if (d_umat && !P->tw_compact) PLX_LAUNCH(k_row, grow, dim3((unsigned)P->row_threads), P->lds_row, st, b);   // matrix tables couple the polarisations
     else launch_row(P, b, FC, st);
     PLX_LAUNCH(k_col_inv, gcol, dim3((unsigned)P->col_threads), P->lds_col, st, b);
     PLX_HIP(hipGetLastError());

@@ -415,7 +415,11 @@ class HotPath:
         """name of the kernel that serves the step's row pass (for reports)"""
         info = (C.c_int32 * 8)()
         self.lib.call("plx_ssfm_info", self.ssfm, info)
-        return "k_row256r" if info[6] == 64 else ("k_row4k" if info[2] == 12 and info[7] else "k_row")
+        if info[6] == 64:
+            return "k_row256r"
+        if info[2] == 12:
+            return "k_row4k" if info[7] else "k_row4k<pair>"     # (PMD: both polarisations of a row in one workgroup)
+        return "k_row"
 
     def overlap_ok(self):
         """May a second stream (the receiver of the previous batch) share the GPU with fibre()?  The fused column sweep needs

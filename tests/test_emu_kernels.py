@@ -477,6 +477,86 @@ def test_emu_long_rows_compact_twiddles(emu, oracle, monkeypatch):
     assert np.abs(uy.view(np.complex128).reshape(n) - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
 
 
+@pytest.mark.parametrize("tables", [True, False])
+def test_emu_long_rows_both_polarisations_pmd(emu, oracle, monkeypatch, tables):
+    """k_row4k<true>: 4096-point rows of a PMD plan -- both polarisations of a row in one 512-thread workgroup, lanes i and
+    i + 32 of a wave trade halves around the waveplate trunks of matrix_step (fiber.m:907-933), phasor tables of k_pmd_tab or
+    one exponential per bin and trunk (PLX_SSFM_NO_PMD_TAB=1).  4 x 4096 split of a 2^14 frame with its own waveplates against
+    the oracle, and against the 2048-point rows of k_row's PMD branch (PLX_SSFM_SHORT_ROWS=1)."""
+    if not tables:
+        monkeypatch.setenv("PLX_SSFM_NO_PMD_TAB", "1")
+    n, nt, nplates, L = 16384, 64, 4, 9e2
+    fls = [1, 1, 1, 0]
+    betat, db1 = _tables(n, nt, fls, nplates)
+    r = np.random.default_rng(23)
+    brf = (r.random(nplates) * 2 * np.pi - np.pi, r.random(nplates) * np.pi - np.pi / 2, 0.5 * np.arcsin(r.random(nplates) * 2 - 1))
+    fx, fy = _qpsk_field(n, nt, 6.0)[:2]
+    rc, ofd, onc, ox, oy = oracle.matrix_ssfm(fx, fy, betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, nplates, 0, fls, *brf)
+    assert rc == 0 and onc >= 3
+    got = {}
+    for short in (False, True):
+        monkeypatch.setenv("PLX_SSFM_P1", "3" if short else "2")
+        monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
+        monkeypatch.setenv("PLX_SSFM_LOGW", "6")
+        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, nplates=nplates, frames=1)
+        plan = C.c_void_p()
+        emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+        for k in ("PLX_SSFM_P1", "PLX_SSFM_COL_THREADS", "PLX_SSFM_LOGW"):
+            monkeypatch.delenv(k)
+        info = (C.c_int32 * 8)()
+        emu.call("plx_ssfm_info", plan, info)
+        assert list(info)[:3] == ([0, 3, 11] if short else [0, 2, 12])
+        assert short or (info[6] == 512 and info[7] == 0)      # both rows in one workgroup of k_row4k
+        emu.call("plx_ssfm_set_birefringence", plan, _vp(brf[0]), _vp(brf[1]), _vp(brf[2]), 1)
+        ux = _il(fx[None]); uy = _il(fy[None])
+        emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 1, None)
+        ncyc = np.zeros(1, np.int32)
+        emu.call("plx_ssfm_results", plan, 1, None, _vp(ncyc))
+        emu.call("plx_ssfm_destroy", plan)
+        gx = ux.view(np.complex128).reshape(n); gy = uy.view(np.complex128).reshape(n)
+        assert ncyc[0] == onc
+        assert np.abs(gx - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
+        assert np.abs(gy - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
+        got[short] = (gx.copy(), gy.copy())
+    assert np.abs(got[True][0] - got[False][0]).max() < 1e-12 * np.abs(got[False][0]).max()
+
+
+def test_emu_inverse_pmd_long_rows(emu, oracle, monkeypatch):
+    """inverse_pmd's matrix tables (inverse_pmd.m:130-141) through the 4096-point row pass: the plan of plx_pmdinv is a PMD-type
+    plan, so k_row4k<true> applies (Hgvd U)^H bin by bin after the halves' trade.  4 x 4096 split against oracle/pmdinv.py."""
+    from oracle import pmdinv
+    nsymb, nt, n = 256, 64, 16384
+    fn = synth.fn_grid(nsymb, nt)
+    omega = 2 * np.pi * 10.0 * fn
+    betat = 0.5 * omega ** 2 * -2.17e-8 + omega ** 3 * 1.3e-10 / 6
+    nplates, L, dgd = 5, 4e4, 0.4
+    r = np.random.default_rng(5)
+    sets = (r.random(nplates) * 2 * np.pi - np.pi, r.random(nplates) * np.pi - np.pi / 2, 0.5 * np.arcsin(r.random(nplates) * 2 - 1))
+    db1 = dgd / nplates / 10.0 * omega
+    ux, uy, _, _ = synth.pdm_qpsk_field(nsymb, nt, 2.0)
+    fx = np.stack([ux]); fy = np.stack([1j * np.roll(uy, 7)])
+    monkeypatch.setenv("PLX_SSFM_P1", "2")
+    monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
+    monkeypatch.setenv("PLX_SSFM_LOGW", "6")
+    plan = C.c_void_p()
+    emu.call("plx_pmdinv_create", C.byref(plan), n, 1)
+    for k in ("PLX_SSFM_P1", "PLX_SSFM_COL_THREADS", "PLX_SSFM_LOGW"):
+        monkeypatch.delenv(k)
+    ntr = np.array([nplates], dtype=np.int32)
+    db0, th, ep = (np.ascontiguousarray(v[None]) for v in sets)
+    lc = np.array([L / nplates])
+    emu.call("plx_pmdinv_set_link", plan, 1, _vp(ntr), _vp(db0), _vp(th), _vp(ep), _vp(lc), _vp(np.ascontiguousarray(betat[None])),
+             _vp(np.ascontiguousarray(db1[None])), None, 1, 1)
+    gx, gy = _il(fx), _il(fy)
+    emu.call("plx_pmdinv_apply_dev", plan, _vp(gx), _vp(gy), 1, None)
+    emu.call("plx_pmdinv_destroy", plan)
+    gx = gx.view(np.complex128).reshape(n); gy = gy.view(np.complex128).reshape(n)
+    brf = [dict(db0=sets[0], theta=sets[1], epsilon=sets[2], lcorr=L / nplates, betat=betat, db1=db1)]
+    Uinv, U, wx, wy = pmdinv.inverse_pmd(brf, fx[0], fy[0], None)
+    assert np.abs(gx - wx).max() < 1e-12 * np.abs(wx).max()
+    assert np.abs(gy - wy).max() < 1e-12 * np.abs(wy).max()
+
+
 def test_emu_frame_barrier_timeout_aborts_cleanly(emu, monkeypatch):
     """A fused-sweep frame whose workgroups are not co-resident (here: the emulator runs ONE workgroup at a time) must
     end in a clean error, never a hang: the barrier times out (wall clock), raises the sticky abort word, nothing is

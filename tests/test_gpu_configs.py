@@ -597,3 +597,54 @@ def test_two_channel_2pow20_frames_long_rows_equal_the_short_row_split(lib, monk
     for a, b in ((x0, x1), (y0, y1)):
         assert np.abs(a - b).max() <= FIELD_RTOL * np.abs(b).max()
     assert np.abs(x0[0, 0] - x0[0, 1]).max() > 0.1 * np.abs(x0).max()          # the two channels really differ
+
+
+def test_pmd_2pow20_frames_fused_sweep_and_both_rows_in_one_workgroup_vs_oracle(lib, oracle, monkeypatch):
+    """fiber('gps-') has no size restriction (fiber.m:877-935).  2^20-sample frames with waveplates keep the 256 x 4096 split:
+    the fused column sweep (one team = the whole grid) and k_row4k<true> -- both polarisations of a 4096-point row in one
+    workgroup, the halves of every wave traded around the trunk loop.  Two frames with their own waveplate draws and launch
+    powers: the stronger one against oracle.matrix_ssfm (field 1e-9, ncycle), both against the three-sweep step on the same
+    split (PLX_SSFM_NO_FUSE=1) and against the 512 x 2048 split with the LDS-resident k_row (PLX_SSFM_SHORT_ROWS=1)."""
+    import torch
+    from polmux_amd import pipeline
+    out = []
+    scale = np.array([1.0, 2.0])
+    for env in ({}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_SHORT_ROWS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, flag="gps-", nplates=50, dgd=0.1, length=4e4, dphimax=2e-2)
+        hp = pipeline.HotPath(cfg, max_frames=2)
+        for k in env:
+            monkeypatch.delenv(k)
+        info = hp.info()
+        if not env:
+            assert list(info[:3]) == [1, 8, 12] and info[4] == info[3] == 512 and info[6] == 512 and info[7] == 0
+        elif "PLX_SSFM_NO_FUSE" in env:
+            assert list(info[:3]) == [0, 8, 12] and info[6] == 512
+        else:
+            assert info[0] == 0 and info[2] == 11
+        brf = hp.set_random_pmd([31, 32])
+        ux, uy = hp.make_batch(2, scale)
+        hp.fibre(ux, uy)
+        _sync()
+        out.append((hp.last_ncycle(2).copy(), ux.cpu().numpy(), uy.cpu().numpy()))
+        if not env:
+            gam, betat, db1 = hp._keep
+            hx, hy = hp.tx_host[0] * math.sqrt(scale[1]), hp.tx_host[1] * math.sqrt(scale[1])
+            rc, fd, nc, ox, oy = oracle.matrix_ssfm(hx, hy, betat, db1, cfg.dzmax, cfg.dphimax, gam, hp.alphalin, cfg.length, cfg.nplates,
+                                                    0, hp.fls, brf[0][1], brf[1][1], brf[2][1])
+            assert rc == 0 and nc == out[0][0][1] and nc > 4
+            sc = max(np.abs(ox).max(), np.abs(oy).max())
+            assert np.abs(out[0][1][1] - ox[:, 0]).max() <= FIELD_RTOL * sc
+            assert np.abs(out[0][2][1] - oy[:, 0]).max() <= FIELD_RTOL * sc
+        hp.close()
+        del ux, uy
+        torch.cuda.empty_cache()
+    nc0, x0, y0 = out[0]
+    assert nc0[1] > nc0[0]
+    for nc1, x1, y1 in out[1:]:
+        assert nc1.tolist() == nc0.tolist()
+        for a, b in ((x0, x1), (y0, y1)):
+            assert np.abs(a - b).max() <= FIELD_RTOL * np.abs(b).max()
+    # the waveplates really couple the polarisations: with equal launch fields per polarisation pattern the outputs differ per draw
+    assert np.abs(x0[0] * math.sqrt(2.0) - x0[1]).max() > 0.05 * np.abs(x0[1]).max()

@@ -1174,15 +1174,18 @@ def test_inverse_pmd_surface_restores_field_and_matches_oracle(lib, oracle):
         px.inverse_pmd(brf)
 
 
-def test_inverse_pmd_batch_per_frame_draws(lib, oracle):
+@pytest.mark.parametrize("nsymb,nt,F", [(256, 32, 5), (16384, 64, 2)])
+def test_inverse_pmd_batch_per_frame_draws(lib, oracle, nsymb, nt, F):
     """Monte-Carlo use: F frames, each with its own waveplate draw, through HotPath's fibre ('gp--') and one batched
-    plx_pmdinv_apply_dev: every frame returns to the transmitted field."""
+    plx_pmdinv_apply_dev: every frame returns to the transmitted field.  At 2^20 samples both legs run on 4096-point rows with
+    the two polarisations of a row in one workgroup (k_row4k<true>: waveplate trunks going out, matrix tables coming back)."""
     import torch
     from polmux_amd import pipeline
     from polmux_amd.pmdinv import PmdInverse
-    cfg = pipeline.HotPathConfig(nsymb=256, nt=32, flag="gp--", nplates=16, dgd=0.4)
-    F = 5
+    cfg = pipeline.HotPathConfig(nsymb=nsymb, nt=nt, flag="gp--", nplates=16, dgd=0.4)
     hp = pipeline.HotPath(cfg, max_frames=F)
+    if cfg.nfft == 1 << 20:
+        assert list(hp.info()[:3]) == [1, 8, 12] and hp.info()[6] == 512
     db0, th, ep = hp.set_random_pmd(range(10, 10 + F))
     ux, uy = hp.make_batch(F)
     hp.fibre(ux, uy)
@@ -1194,8 +1197,9 @@ def test_inverse_pmd_batch_per_frame_draws(lib, oracle):
     inv.close()
     _sync()
     att = math.exp(-0.5 * hp.alphalin * cfg.length)
+    tol = 1e-11 if cfg.nfft < 1 << 20 else 1e-10
     for f in range(F):
-        assert float((ux[f] / att - hp.tx[0]).abs().max()) < 1e-11 and float((uy[f] / att - hp.tx[1]).abs().max()) < 1e-11
+        assert float((ux[f] / att - hp.tx[0]).abs().max()) < tol and float((uy[f] / att - hp.tx[1]).abs().max()) < tol
     hp.close()
 
 
