@@ -162,7 +162,8 @@ int plx_ssfm_utilisation(plx_ssfm *plan, int64_t *frame_steps, int64_t *slots_li
  * [1] log2 N1, [2] log2 N2 of the four-step split; [3] grid of the fused sweep; [4] column tiles per frame;
  * [5] threads per column workgroup, [6] per row workgroup of the step's row pass (64: the register form k_row256r, one wave
  * per 2 rows x 2 polarisations; with [2] = 12: k_row4k, 256 threads on one polarisation of a row or -- PMD plans -- 512 on both);
- * [7] 1 = one polarisation per row workgroup.  8 entries. */
+ * [7] 1 = one polarisation per row workgroup, 2 = the register form for rows of 512 / 1024 / 2048 points (k_rowreg: 256
+ * threads on 8 / 4 / 2 row-polarisations), 0 = both polarisations of its rows in one workgroup.  8 entries. */
 int plx_ssfm_info(plx_ssfm *plan, int32_t *info);
 /* Per-kernel timing of the step loop: with profiling enabled an event is recorded between consecutive launches of
  * plx_ssfm_propagate_dev; plx_ssfm_kernel_times returns, per kernel class (0 the column sweep that starts a step, 1 the row

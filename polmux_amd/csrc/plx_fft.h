@@ -358,6 +358,84 @@ struct Tw256of4096 {
     }
 };
 
+// W_M^e (e < M) over the compact table of W_M: t[k] = W_M^{4k}, k < M/8, then W_M^0..3 (M/8 + 4 entries)
+template <int M> struct TwCompact {
+    const cplx *t;
+    __device__ __forceinline__ cplx operator()(int e) const
+    {
+        const int i = e & (M / 2 - 1);
+        const cplx w = cmul(t[i >> 2], t[M / 8 + (i & 3)]);
+        const bool neg = (e & (M - 1)) >= M / 2;
+        return make_double2(neg ? -w.x : w.x, neg ? -w.y : w.y);
+    }
+};
+
+// The MIDDLE register level of a row of M = 16 * R * 16 points (R = 2, 4, 8: rows of 512, 1024 and 2048 points, k_rowreg):
+// after the first level (lvl2_dif<M/16>) the row is sixteen independent blocks of M/16 = 16 R points; a thread holds, of a
+// 256-point chunk of the row, the points j + 16 kk (kk < 16) = point j + 16 k of block h, kk = R h + k: 16 / R radix-R
+// butterflies at stride 16, after which blocks of sixteen CONTIGUOUS points remain (r16_dif).  R = 8 is a radix-2 stage
+// (m = 128) followed by a radix-4 stage (m = 64), the order of lds_fft_dif's in-place stages: the output order is the
+// plain bit reversal whatever the grouping.  w: this lane's twiddles -- R = 2: W_32^j; R = 4: W_64^{j, 2j, 3j};
+// R = 8: W_128^{j + 16 k} (k < 4), then W_64^{j, 2j, 3j}.
+template <int R> __device__ __forceinline__ void lvlmid_dif(cplx *x, const cplx *w)
+{
+    if (R == 8) {
+#pragma unroll
+        for (int h = 0; h < 16; h += 8)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const cplx a = x[h + k], b = x[h + k + 4];
+                x[h + k] = cadd(a, b);
+                x[h + k + 4] = cmul(csub(a, b), w[k]);
+            }
+    }
+    if (R == 2) {
+#pragma unroll
+        for (int h = 0; h < 16; h += 2) {
+            const cplx a = x[h], b = x[h + 1];
+            x[h] = cadd(a, b);
+            x[h + 1] = cmul(csub(a, b), w[0]);
+        }
+    } else {
+        const cplx w1 = w[R == 8 ? 4 : 0], w2 = w[R == 8 ? 5 : 1], w3 = w[R == 8 ? 6 : 2];
+#pragma unroll
+        for (int b = 0; b < 16; b += 4) {
+            const cplx a0 = x[b], a1 = x[b + 1], a2 = x[b + 2], a3 = x[b + 3];
+            const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
+            x[b] = cadd(t0, t2); x[b + 1] = cmul(csub(t0, t2), w2); x[b + 2] = cmul(cadd(t1, t3), w1); x[b + 3] = cmul(csub(t1, t3), w3);
+        }
+    }
+}
+template <int R> __device__ __forceinline__ void lvlmid_dit(cplx *x, const cplx *w)
+{
+    if (R == 2) {
+#pragma unroll
+        for (int h = 0; h < 16; h += 2) {
+            const cplx a = x[h], b = cmulc(x[h + 1], w[0]);
+            x[h] = cadd(a, b);
+            x[h + 1] = csub(a, b);
+        }
+    } else {
+        const cplx w1 = w[R == 8 ? 4 : 0], w2 = w[R == 8 ? 5 : 1], w3 = w[R == 8 ? 6 : 2];
+#pragma unroll
+        for (int b = 0; b < 16; b += 4) {
+            const cplx c0 = x[b], c2 = cmulc(x[b + 1], w2), c1 = cmulc(x[b + 2], w1), c3 = cmulc(x[b + 3], w3);
+            const cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
+            x[b] = cadd(s0, s2); x[b + 1] = cadd(s1, s3); x[b + 2] = csub(s0, s2); x[b + 3] = csub(s1, s3);
+        }
+    }
+    if (R == 8) {
+#pragma unroll
+        for (int h = 0; h < 16; h += 8)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const cplx a = x[h + k], b = cmulc(x[h + k + 4], w[k]);
+                x[h + k] = cadd(a, b);
+                x[h + k + 4] = csub(a, b);
+            }
+    }
+}
+
 // T = 1<<logT padded rows of M = 1<<logM (M >= 16) points each, row t at s + t*row_pitch(M).
 __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
 {

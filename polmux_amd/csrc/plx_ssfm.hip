@@ -65,6 +65,7 @@ struct SsfmArgs {
     const cplx *umat;              // [F][N][3] per frequency: SU(2) row (U11, U12) and scalar Hgvd; applies (Hgvd U)^H (inverse_pmd.m:130-141)
     const cplx *tw1, *tw2;         // half tables W_N1^k, W_N2^k
     const cplx *ctab;              // [PLX_CTAB] (cos, -sin)(2 pi k / 64): cexp_neg_turns_tab (k_row4k)
+    const cplx *tw2c, *twmid;      // k_rowreg: compact table of W_N2 (TwCompact) and the middle level's lane twiddles [7][16]
     const double *gam;             // [nfc] effective gamma (x8/9 when Manakov, :499-501)
     const double *brf;             // [sets][nplates][9]: R11 R12 R21 R22 (re,im) db0
     // PMD plans whose db1 is LINEAR in the signed frequency index m (fiber.m:358: db1 = dgdrms*omega): the trunk phase
@@ -1187,6 +1188,111 @@ template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2
     for (int k = 0; k < 16; k++) u[jo + 256 * k] = cmulc(x[k], cmul(tb, bk[k]));
 }
 
+// ------------------------------------------------- pass 2 for rows of 512, 1024 and 2048 points, register form ---
+// Frames of 2^17 ... 2^19 samples on the 256-row split (2^18 = 4096 symbols x 64 samples is what Run_my_PDM_QPSK.m:21-24 ships
+// with): dual polarisation, no PMD.  M = 16 x R x 16 points (R = 2, 4, 8), S = M / 16 threads per row and polarisation, thread
+// t holds points t + S k; three register levels per direction -- lvl2_dif<S> on W_M, R-point butterflies at stride 16
+// (lvlmid_dif), r16_dif -- with one exchange through the padded LDS row between consecutive levels, as in k_row4k; the
+// multiplier is applied on the sixteen bins a thread then holds (bit-reversed order, where the tables are) and the inverse
+// mirrors the three levels.  A workgroup of 256 threads takes 256 / S row-polarisations: 512-point rows: 4 rows x 2 (a wave =
+// the two polarisations of a row), 1024: 2 rows x 2 (a wave = one polarisation of a row: no workgroup barrier at all), 2048:
+// one row x 2 (two waves per polarisation: one barrier per outer exchange).  The LDS-resident k_row makes 9 - 11
+// barrier-separated passes over the same rows (0.48 / 0.41 / 0.29 of 8 TB/s at 2^17 / 2^18 / 2^19 samples).
+// Twiddles: the compact table of W_M (TwCompact); the middle level's lane twiddles from a 7 x 16 table of the plan (twmid).
+#define ROWG_THREADS 256
+template <int LOGM> __global__ __launch_bounds__(ROWG_THREADS, 2) void k_rowreg(SsfmArgs a)
+{
+    constexpr int M = 1 << LOGM, S = M / 16, R = M / 256, RP = ROWG_THREADS / S, PITCH = M + M / 16, NTW = M / 8 + 4;
+    PLX_DYN_LDS(lds);
+    if (all_done_or_aborted(a)) return;
+    const int tid = threadIdx.x;
+    int slot = blockIdx.y / a.nfc;
+    const int c = blockIdx.y - slot * a.nfc;       // (channels of a frame: 'sepfields' WDM)
+    if (!row_slot(a, slot)) return;
+    int f;
+    if (!slot_frame(a, slot, f)) return;
+    const int fc = f * a.nfc + c;
+    const FrameCtl *ctl = a.ctl + f;
+    if (ctl->done) return;
+    const int rp = tid / S, t = tid - rp * S, rl = rp >> 1, pol = rp & 1;      // row-polarisation, thread within it, row within the workgroup
+    cplx *const s = (cplx *)lds + rp * PITCH;            // this row-polarisation's padded row: physical(p) = p + (p >> 4)
+    cplx *const tw = (cplx *)lds + RP * PITCH;           // compact W_M
+    cplx *const tm = tw + NTW;                           // [7][16]: the middle level's twiddles, lane-fastest
+    cplx *const ct = tm + 7 * 16;                        // the unit circle in 64 steps (cexp_neg_turns_tab)
+    cplx *const bk = ct + PLX_CTAB + 17 * rl;            // tpass[row][S k], k < 16 (the rows' entries on different banks)
+    const size_t N = (size_t)M << a.p1;
+    const size_t rowbase = ((size_t)blockIdx.x * (RP / 2) + rl) << LOGM;
+    cplx *const u = (pol ? a.uy : a.ux) + (size_t)fc * N + rowbase;
+    const cplx *const tp = a.tpass + rowbase;
+    const TwCompact<M> wm{tw};
+    const int b = t >> 4, j2 = t & 15;                   // middle level: chunk b of 256 points, point j2 + 16 kk of it
+    cplx x[16];
+    {
+        const cplx ta = tp[t];
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = u[t + S * k];
+        for (int i = tid; i < NTW; i += ROWG_THREADS) tw[i] = a.tw2c[i];
+        if (tid < 7 * 16) tm[tid] = a.twmid[tid];
+        if (tid < PLX_CTAB) ct[tid] = a.ctab[tid];
+        if (pol == 0 && t < 16) bk[t] = tp[S * t];
+        __syncthreads();                                 // tables staged
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = cmul(x[k], cmul(ta, bk[k]));
+    }
+    lvl2_dif<S>(x, t, wm);
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[row_phys(t + S * k)] = x[k];
+    if (S > 64) __syncthreads(); else ROWR_SYNC();       // (S <= 64: the row-polarisation's threads are lanes of one wave)
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+    cplx wl[7];
+#pragma unroll
+    for (int q = 0; q < (R == 8 ? 7 : (R == 4 ? 3 : 1)); q++) wl[q] = tm[16 * q + j2];     // (the plan lists this R's twiddles first)
+    lvlmid_dif<R>(x, wl);                                // (written back where this thread read it: no barrier in between)
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
+    ROWR_SYNC();                                         // (a chunk's sixteen threads are lanes of one wave)
+    double btv[16];
+    if (!a.hmul) {
+        const double *bt = a.betat_p + (size_t)c * N + rowbase + 16 * t;
+#pragma unroll
+        for (int k = 0; k < 16; k++) btv[k] = bt[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = s[17 * t + k];               // row_phys(16 t + k)
+    r16_dif(x);
+    if (a.hmul) {
+        int o16 = 16 * t;
+        pin(o16);
+        const cplx *h = a.hmul + rowbase + o16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = cmul(h[k], x[k]);
+    } else {
+        const double cur = a.force ? a.f_cur : ctl->cur;
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = cmul(cexp_neg_turns_tab(btv[k] * cur, ct), x[k]);
+    }
+    r16_dit(x);
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[17 * t + k] = x[k];
+    ROWR_SYNC();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+    lvlmid_dit<R>(x, wl);
+#pragma unroll
+    for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
+    if (S > 64) __syncthreads(); else ROWR_SYNC();
+    int jo = t;
+    pin(jo);
+    const cplx tb = tp[jo];                              // (asked for ahead of the last register level)
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k] = s[row_phys(t + S * k)];
+    lvl2_dit<S>(x, t, wm);
+#pragma unroll
+    for (int k = 0; k < 16; k++) u[jo + S * k] = cmulc(x[k], cmul(tb, bk[k]));
+}
+#define ROWG_LDS(M) ((size_t)((ROWG_THREADS / ((M) / 16)) * ((M) + (M) / 16) + (M) / 8 + 4 + 7 * 16 + PLX_CTAB + 17 * (ROWG_THREADS / ((M) / 16) / 2)) * sizeof(cplx))
+
 // ------------------------------------------------------ pass 3: inverse columns ---
 // Completes ifft (1/N), applies the attenuation of the step (:531-532) and feeds
 // nextstep's global maximum (:694-696) -- no extra pass over the field.
@@ -1733,6 +1839,8 @@ struct plx_ssfm {
     int col_threads = 512;         // workgroup size of k_col_fwd / k_col_inv
     int row_threads = ROW_THREADS; // workgroup size of k_row
     int rowr = 0;                  // k_row256r serves the step's row pass
+    int rowreg = 0;                // k_rowreg<p2> serves it (dual polarisation, no PMD, rows of 512 / 1024 / 2048 points)
+    cplx *d_tw2c = nullptr, *d_twmid = nullptr;
     int row_split = 0, rs_threads = 0; // long rows without PMD: one polarisation per workgroup (scalar row pass twice)
     size_t rs_lds = 0;
     int tw_compact = 0;            // 4096-point rows: compact twiddle table in d_tw2, register-blocked row pass k_row4k
@@ -1768,7 +1876,7 @@ static void free_plan(plx_ssfm *P)
     if (!P) return;
     hipFree(P->d_betat); hipFree(P->d_db1); hipFree(P->d_gam); hipFree(P->d_brf); hipFree(P->d_psum);
     hipFree(P->d_tpass); hipFree(P->d_tw1); hipFree(P->d_tw2); hipFree(P->d_ctab); hipFree(P->d_ctl); hipFree(P->d_umax);
-    hipFree(P->d_dzlist); hipFree(P->d_dzlog);
+    hipFree(P->d_dzlist); hipFree(P->d_dzlog); hipFree(P->d_tw2c); hipFree(P->d_twmid);
     hipFree(P->d_ndone); hipFree(P->d_slots); hipFree(P->d_mbox); hipFree(P->d_active); hipFree(P->d_e1); hipFree(P->d_e2);
     if (P->h_ndone) hipHostFree(P->h_ndone);
     if (P->ev) hipEventDestroy(P->ev);
@@ -1989,6 +2097,27 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
         }
         UP(P->d_ctab, ctv, cplx);
     }
+    // k_rowreg: register-form row pass for dual-polarisation plans without PMD whose rows have 512, 1024 or 2048 points
+    if (tune.rowr && a.dual && !desc->fls[1] && P->p2 >= 9 && P->p2 <= 11 && N1 >= (ROWG_THREADS / (N2 / 16)) / 2) {
+        const long double tau = -2.0L * 3.14159265358979323846264338327950288L;
+        std::vector<cplx> tc(N2 / 8 + 4), tm(7 * 16, make_double2(1.0, 0.0));
+        for (int k = 0; k < N2 / 8 + 4; k++) {
+            const int e = k < N2 / 8 ? 4 * k : k - N2 / 8;
+            tc[k] = make_double2((double)cosl(tau * e / N2), (double)sinl(tau * e / N2));
+        }
+        const int R = N2 / 256;
+        auto put = [&](int q, int j, int e, int m) { tm[16 * q + j] = make_double2((double)cosl(tau * e / m), (double)sinl(tau * e / m)); };
+        for (int j = 0; j < 16; j++) {
+            if (R == 2) put(0, j, j, 32);
+            const int q0 = R == 8 ? 4 : 0;
+            if (R >= 4) for (int q = 0; q < 3; q++) put(q0 + q, j, (q + 1) * j, 64);
+            if (R == 8) for (int q = 0; q < 4; q++) put(q, j, j + 16 * q, 128);
+        }
+        UP(P->d_tw2c, tc, cplx);
+        UP(P->d_twmid, tm, cplx);
+        const hipError_t e = P->p2 == 9 ? allow_lds(k_rowreg<9>, ROWG_LDS(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10>, ROWG_LDS(1024)) : allow_lds(k_rowreg<11>, ROWG_LDS(2048));
+        if (e == hipSuccess) P->rowreg = 1;
+    }
     UP(P->d_gam, gam, double);
 #undef UP
     bool ok = hipMalloc((void **)&P->d_ctl, sizeof(FrameCtl) * F) == hipSuccess &&
@@ -1999,7 +2128,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
               hipEventCreateWithFlags(&P->ev, hipEventDisableTiming) == hipSuccess;
     if (ok && !a.dual && a.xpm) ok = hipMalloc((void **)&P->d_psum, sizeof(double) * (size_t)F * N) == hipSuccess;
     if (!ok) { free_plan(P); PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: device allocation failed"); }
-    a.betat_p = P->d_betat; a.db1_p = P->d_db1; a.tpass = P->d_tpass; a.tw1 = P->d_tw1; a.tw2 = P->d_tw2; a.ctab = P->d_ctab;
+    a.betat_p = P->d_betat; a.db1_p = P->d_db1; a.tpass = P->d_tpass; a.tw1 = P->d_tw1; a.tw2 = P->d_tw2; a.ctab = P->d_ctab; a.tw2c = P->d_tw2c; a.twmid = P->d_twmid;
     a.gam = P->d_gam; a.ctl = P->d_ctl; a.umax = P->d_umax; a.ndone = P->d_ndone; a.psum = P->d_psum;
     P->h_ctl.resize(F);
 
@@ -2152,6 +2281,13 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
     const int N1 = 1 << a.p1;
     if (P->tw_compact && a.dual && (a.pmd || a.umat)) {      // the multiplier couples the polarisations: both rows in one workgroup
         PLX_LAUNCH(k_row4k<true>, dim3((unsigned)N1 * FC), dim3(512), P->rs_lds_pair, st, a);
+        return;
+    }
+    if (P->rowreg && a.dual && !a.pmd && !a.umat) {
+        const unsigned gx = (unsigned)(N1 / ((ROWG_THREADS / ((1 << a.p2) / 16)) / 2));
+        if (a.p2 == 9) PLX_LAUNCH(k_rowreg<9>, dim3(gx, FC), dim3(ROWG_THREADS), ROWG_LDS(512), st, a);
+        else if (a.p2 == 10) PLX_LAUNCH(k_rowreg<10>, dim3(gx, FC), dim3(ROWG_THREADS), ROWG_LDS(1024), st, a);
+        else PLX_LAUNCH(k_rowreg<11>, dim3(gx, FC), dim3(ROWG_THREADS), ROWG_LDS(2048), st, a);
         return;
     }
     if (P->row_split && a.dual && !a.pmd) {
@@ -2416,7 +2552,7 @@ extern "C" int plx_ssfm_info(plx_ssfm *P, int32_t *info)
 {
     if (!P || !info) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_info: null argument");
     info[0] = P->fused; info[1] = P->p1; info[2] = P->p2; info[3] = P->fused_grid; info[4] = P->tiles_pf;
-    info[5] = P->col_threads; info[6] = P->rowr ? ROWR_THREADS : (P->tw_compact ? (P->row_pair4k ? 512 : 256) : (P->row_split ? P->rs_threads : P->row_threads)); info[7] = P->row_pair4k ? 0 : P->row_split;
+    info[5] = P->col_threads; info[6] = P->rowr ? ROWR_THREADS : P->rowreg ? ROWG_THREADS : (P->tw_compact ? (P->row_pair4k ? 512 : 256) : (P->row_split ? P->rs_threads : P->row_threads)); info[7] = P->rowreg ? 2 : (P->row_pair4k ? 0 : P->row_split);
     return PLX_OK;
 }
 

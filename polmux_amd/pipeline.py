@@ -417,6 +417,8 @@ class HotPath:
         self.lib.call("plx_ssfm_info", self.ssfm, info)
         if info[6] == 64:
             return "k_row256r"
+        if info[7] == 2:
+            return "k_rowreg"                                     # rows of 512 / 1024 / 2048 points, register form
         if info[2] == 12:
             return "k_row4k" if info[7] else "k_row4k<pair>"     # (PMD: both polarisations of a row in one workgroup)
         return "k_row"

@@ -557,6 +557,46 @@ def test_emu_inverse_pmd_long_rows(emu, oracle, monkeypatch):
     assert np.abs(gy - wy).max() < 1e-12 * np.abs(wy).max()
 
 
+@pytest.mark.parametrize("logm", [9, 10, 11])
+def test_emu_register_form_rows_512_to_2048(emu, oracle, monkeypatch, logm):
+    """k_rowreg<9 / 10 / 11>: rows of 512, 1024 and 2048 points (frames of 2^17 ... 2^19 samples on the 256-row split; 2^18 is the
+    size Run_my_PDM_QPSK.m:21-24 ships with) as three register levels -- radix 16, radix 2 / 4 / 8 at stride 16, radix 16 -- on a
+    4 x M split, against the oracle and against the LDS-resident k_row (PLX_SSFM_ROWR=0)."""
+    M = 1 << logm
+    n, nt, L = 4 * M, (16 if logm == 10 else 32), 9e2
+    fls = [1, 0, 1, 0]
+    betat, db1 = _tables(n, nt, fls, 1)
+    f = _qpsk_field(n, nt, 6.0)
+    rc, fd, onc, ox, oy = oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0])
+    assert rc == 0 and onc >= 3
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PLX_SSFM_ROWR", mode)
+        monkeypatch.setenv("PLX_SSFM_P1", "2")
+        monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
+        monkeypatch.setenv("PLX_SSFM_LOGW", "6")
+        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=2)
+        plan = C.c_void_p()
+        emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+        for k in ("PLX_SSFM_ROWR", "PLX_SSFM_P1", "PLX_SSFM_COL_THREADS", "PLX_SSFM_LOGW"):
+            monkeypatch.delenv(k)
+        info = (C.c_int32 * 8)()
+        emu.call("plx_ssfm_info", plan, info)
+        assert list(info)[:3] == [0, 2, logm] and (info[7] == 2) == (mode == "1")
+        ux = _il(np.stack([f[0], 0.5 * f[1]])); uy = _il(np.stack([f[1], f[0]]))
+        emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 2, None)
+        nc = np.zeros(2, np.int32)
+        emu.call("plx_ssfm_results", plan, 2, None, _vp(nc))
+        gx = ux.view(np.complex128).reshape(2, n); gy = uy.view(np.complex128).reshape(2, n)
+        assert nc[0] == onc
+        assert np.abs(gx[0] - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
+        assert np.abs(gy[0] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
+        emu.call("plx_ssfm_destroy", plan)
+        got[mode] = (gx.copy(), gy.copy())
+    assert np.abs(got["1"][0] - got["0"][0]).max() < 1e-12 * np.abs(got["0"][0]).max()
+    assert not np.array_equal(got["1"][0], got["0"][0])      # (the switch really selects another kernel)
+
+
 def test_emu_frame_barrier_timeout_aborts_cleanly(emu, monkeypatch):
     """A fused-sweep frame whose workgroups are not co-resident (here: the emulator runs ONE workgroup at a time) must
     end in a clean error, never a hang: the barrier times out (wall clock), raises the sticky abort word, nothing is

@@ -363,13 +363,15 @@ def test_fibre_beside_a_busy_stream_is_bit_identical_to_the_fibre_alone(lib):
     hp.close()
 
 
-def test_front_end_at_2pow20_uses_the_long_row_filter_pass(lib, oracle):
+@pytest.mark.parametrize("nsymb", [16384, 4096])
+def test_front_end_at_2pow20_uses_the_long_row_filter_pass(lib, oracle, nsymb):
     """The coherent front end of a 2^20-sample frame: its two spectral filters run on the plan's FFT engine, i.e. through
     the 256 x 4096 split and the 4096-point row pass k_row4k with a general multiplier table -- photocurrents against the
-    numpy restatement of receiver_cohmix.m:165-307 (oracle/front.py)."""
+    numpy restatement of receiver_cohmix.m:165-307 (oracle/front.py).  And of a 2^18-sample frame (the size Run_my_PDM_QPSK.m
+    ships with): the optical filter through k_rowreg's 1024-point rows."""
     from oracle import front
     from polmux_amd import pipeline
-    cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, frontend="cohmix", adcbits=0)
+    cfg = pipeline.HotPathConfig(nsymb=nsymb, nt=64, frontend="cohmix", adcbits=0)
     hp = pipeline.HotPath(cfg, max_frames=1)
     ux, uy = hp.make_batch(1)
     tx, ty = ux[0].cpu().numpy(), uy[0].cpu().numpy()
@@ -648,3 +650,45 @@ def test_pmd_2pow20_frames_fused_sweep_and_both_rows_in_one_workgroup_vs_oracle(
             assert np.abs(a - b).max() <= FIELD_RTOL * np.abs(b).max()
     # the waveplates really couple the polarisations: with equal launch fields per polarisation pattern the outputs differ per draw
     assert np.abs(x0[0] * math.sqrt(2.0) - x0[1]).max() > 0.05 * np.abs(x0[1]).max()
+
+
+@pytest.mark.parametrize("nsymb,nt", [(1024, 128), (4096, 64), (4096, 128)])
+def test_frames_of_2pow17_to_2pow19_register_form_rows_vs_oracle(lib, oracle, monkeypatch, nsymb, nt):
+    """Frames between the BASELINE shapes -- 2^18 = 4096 symbols x 64 samples is what Run_my_PDM_QPSK.m:21-24 ships with -- on
+    the 256-row split: fused column sweep + k_rowreg (rows of 512 / 1024 / 2048 points in registers).  Three frames at different
+    launch powers (different step counts in one batch): the strongest against oracle.matrix_ssfm (field 1e-9, ncycle), all
+    three against the LDS-resident k_row (PLX_SSFM_ROWR=0) to 1e-9 with equal step counts."""
+    import torch
+    from polmux_amd import pipeline
+    scale = np.array([0.5, 1.0, 2.0])
+    out = []
+    for env in ({}, {"PLX_SSFM_ROWR": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg = pipeline.HotPathConfig(nsymb=nsymb, nt=nt, length=4e4)
+        hp = pipeline.HotPath(cfg, max_frames=3)
+        for k in env:
+            monkeypatch.delenv(k)
+        info = hp.info()
+        p2 = (nsymb * nt).bit_length() - 1 - 8
+        assert list(info[:3]) == [1, 8, p2] and (info[7] == 2) == (not env)
+        assert hp.row_kernel() == ("k_rowreg" if not env else "k_row")
+        ux, uy = hp.make_batch(3, scale)
+        hp.fibre(ux, uy)
+        _sync()
+        out.append((hp.last_ncycle(3).copy(), ux.cpu().numpy(), uy.cpu().numpy()))
+        if not env:
+            gam, betat, db1 = hp._keep
+            hx, hy = hp.tx_host[0] * math.sqrt(scale[2]), hp.tx_host[1] * math.sqrt(scale[2])
+            rc, fd, nc, ox, oy = oracle.matrix_ssfm(hx, hy, betat, db1, cfg.dzmax, cfg.dphimax, gam, hp.alphalin, cfg.length, 1, 0,
+                                                    hp.fls, [0.0], [0.0], [0.0])
+            assert rc == 0 and nc == out[0][0][2]
+            assert np.abs(out[0][1][2] - ox[:, 0]).max() <= FIELD_RTOL * np.abs(ox).max()
+            assert np.abs(out[0][2][2] - oy[:, 0]).max() <= FIELD_RTOL * np.abs(oy).max()
+        hp.close()
+        del ux, uy
+        torch.cuda.empty_cache()
+    (nc0, x0, y0), (nc1, x1, y1) = out
+    assert nc0.tolist() == nc1.tolist() and nc0[2] > nc0[1] > nc0[0]
+    for a, b in ((x0, x1), (y0, y1)):
+        assert np.abs(a - b).max() <= FIELD_RTOL * np.abs(b).max()
