@@ -1081,9 +1081,12 @@ def test_hot_path_with_reference_front_end_vs_oracle(lib, oracle):
     hp.close()
 
 
-def test_run_my_pdm_qpsk_script_vs_oracle(lib, oracle):
-    """examples/run_my_pdm_qpsk.py = Run_my_PDM_QPSK.m:100-199 on the device path (shipped parameters at a quarter of
-    the shipped length), against the oracle chain fed with the same Tx field: decoded bits identical, symbols 1e-7."""
+@pytest.mark.parametrize("nsymb", [1024, 4096])
+def test_run_my_pdm_qpsk_script_vs_oracle(lib, oracle, nsymb):
+    """examples/run_my_pdm_qpsk.py = Run_my_PDM_QPSK.m:100-199 on the device path -- the shipped parameters at a quarter of
+    the shipped pattern length and as shipped (4096 symbols x 64 samples = 2^18: fused sweep + 1024-point rows of k_rowreg in
+    the fibre and in the front end's optical filter) -- against the oracle chain fed with the same Tx field: decoded bits
+    identical, symbols 1e-11."""
     import importlib.util
     import os
     from oracle import front
@@ -1094,7 +1097,7 @@ def test_run_my_pdm_qpsk_script_vs_oracle(lib, oracle):
                                                                                     "run_my_pdm_qpsk.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    nsymb, nt = 1024, 64
+    nt = 64
     res = mod.main(nsymb, nt, quiet=True)
     assert len(res["lines"]) == 2 and res["lines"][0].startswith("Ch 1 Pol X Match: ")
     fib, rp = res["fib"], res["RxParams"]
