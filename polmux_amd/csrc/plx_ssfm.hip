@@ -983,6 +983,73 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
 // tpass[tid + 256 k] = tpass[tid] * tpass[256 k]: a thread reads ONE entry and the workgroup shares sixteen (bk, in LDS)
 // instead of 16 entries per thread at either end of the kernel -- 128 KiB less through the L2 per 64-KiB row, for two more
 // complex products per point.
+// The multiplier of a row pass that holds BOTH polarisations of a row in one wave (k_row4k<true>, k_rowreg<., true>): lane i
+// (X) and lane i + 32 (Y) hold the same sixteen bins; they trade halves (half_trade) so that each holds ux and uy of eight bins
+// -- x[k] = ux, x[k + 8] = uy of bin ib + k -- apply the waveplate trunks of matrix_step (fiber.m:907-933; phasor tables of
+// k_pmd_tab, or one exponential per bin and trunk) or inverse_pmd's matrix tables (inverse_pmd.m:130-141), and trade back.
+// LOGM: log2 of the row length (the stride of the column phasors); btv: betat (turns) of the lane's eight bins; row: the row's
+// index in the frame (the row phasors); ib: the first of the lane's eight bins within the row.
+template <int LOGM> __device__ __forceinline__ void pair_multiplier(const SsfmArgs &a, cplx *x, const double *btv, const cplx *ct, const FrameCtl *ctl,
+                                                                    int f, int c, int row, size_t rowbase, int ib)
+{
+    const size_t N = (size_t)1 << (a.p1 + a.p2);
+    if (a.umat) {
+        // Uinv = conj(Hgvd) [conj(U11) -U12; conj(U12) U11] applied to [x; y]  (inverse_pmd.m:130-141; k_row's form, bin by bin)
+        const cplx *um = a.umat + 3 * ((size_t)f * N + rowbase + ib);
+#pragma unroll
+        for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const cplx u11 = um[3 * k], u12 = um[3 * k + 1], hg = um[3 * k + 2], p = x[k], q = x[k + 8];
+            x[k] = cmulc(csub(cmulc(p, u11), cmul(u12, q)), hg);
+            x[k + 8] = cmulc(cadd(cmulc(p, u12), cmul(u11, q)), hg);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
+        return;
+    }
+    const double cur = a.force ? a.f_cur : ctl->cur;
+    const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * BRF_STRIDE : 0);
+    const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem;
+#pragma unroll
+    for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
+    if (a.e1tab && ntrunk <= a.tmax) {
+        const int N1 = 1 << a.p1;
+        const cplx *e1 = a.e1tab + (size_t)f * a.tmax * N1 + row, *e2 = a.e2tab + ((size_t)f * a.tmax << LOGM) + ib;
+        // (pmd_trunks_tab with the trunk loop outside the bins: a trunk's plate and row phasor are fetched once)
+        for (int t = 0; t < ntrunk; t++) {
+            int plate = n0 + t;
+            plate = plate < 0 ? 0 : (plate >= a.nplates ? a.nplates - 1 : plate);
+            const double *m = brf + (size_t)plate * BRF_STRIDE;
+            const double s11 = m[0];
+            const cplx s12 = make_double2(m[1], m[2]);
+            const cplx e1v = e1[(size_t)t * N1];
+            const cplx *e2t = e2 + ((size_t)t << LOGM);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const cplx e = cmul(e1v, e2t[k]);
+                const cplx u = x[k], v = x[k + 8];
+                const cplx sx = cadd(cscale(u, s11), cmul(s12, v));
+                const cplx sy = csub(cmulc(u, s12), cscale(v, s11));
+                x[k] = make_double2(e.x * u.x - e.y * sx.y, e.x * u.y + e.y * sx.x);
+                x[k + 8] = make_double2(e.x * v.x - e.y * sy.y, e.x * v.y + e.y * sy.x);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const cplx h = cexp_neg_turns_tab(btv[k] * cur, ct);
+            x[k] = cmul(h, x[k]);
+            x[k + 8] = cmul(h, x[k + 8]);
+        }
+    } else {
+        const double *d1 = a.db1_p + (size_t)c * N + rowbase + ib;
+        const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last;
+        for (int k = 0; k < 8; k++) pmd_trunks(x[k], x[k + 8], btv[k], d1[k], brf, a.nplates, n0, ntrunk, dzb_first, dzb_last, a.lcorr, cur);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
+}
+
 // The two MIDDLE exchanges (level 2 <-> level 3) stay inside a block of 256 points = 16 consecutive threads = one wave: they
 // wait for the wave's own LDS operations only (ROWR_SYNC), the workgroup meets at the two outer exchanges.  Level 2's twiddles
 // W_256^e come from a copy of their own, t8[e + (e >> 2)] (e < 128): its lanes ask for e = 4 j2, 8 j2, 12 j2 (+ 16 r1 ...),
@@ -1100,61 +1167,7 @@ template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2
     for (int k = 0; k < 16; k++) x[k] = s[17 * tid + k];             // row_phys(16 tid + k)
     r16_dif(x);
     if (PAIR && !a.hmul) {
-        if (a.umat) {
-            // Uinv = conj(Hgvd) [conj(U11) -U12; conj(U12) U11] applied to [x; y]  (inverse_pmd.m:130-141; k_row's form, bin by bin)
-            const cplx *um = a.umat + 3 * ((size_t)f * N + rowbase + ib);
-#pragma unroll
-            for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);   // x[k] = ux, x[k + 8] = uy of bin ib + k
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const cplx u11 = um[3 * k], u12 = um[3 * k + 1], hg = um[3 * k + 2], p = x[k], q = x[k + 8];
-                x[k] = cmulc(csub(cmulc(p, u11), cmul(u12, q)), hg);
-                x[k + 8] = cmulc(cadd(cmulc(p, u12), cmul(u11, q)), hg);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
-        } else {
-            const double cur = a.force ? a.f_cur : ctl->cur;
-            const double *brf = a.brf + (a.brf_per_frame ? (size_t)f * a.nplates * BRF_STRIDE : 0);
-            const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem;
-#pragma unroll
-            for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
-            if (a.e1tab && ntrunk <= a.tmax) {
-                const int N1 = 1 << a.p1;
-                const cplx *e1 = a.e1tab + (size_t)f * a.tmax * N1 + brow, *e2 = a.e2tab + ((size_t)f * a.tmax << 12) + ib;
-                // (pmd_trunks_tab with the trunk loop outside the bins: a trunk's plate and row phasor are fetched once)
-                for (int t = 0; t < ntrunk; t++) {
-                    int plate = n0 + t;
-                    plate = plate < 0 ? 0 : (plate >= a.nplates ? a.nplates - 1 : plate);
-                    const double *m = brf + (size_t)plate * BRF_STRIDE;
-                    const double s11 = m[0];
-                    const cplx s12 = make_double2(m[1], m[2]);
-                    const cplx e1v = e1[(size_t)t * N1];
-                    const cplx *e2t = e2 + ((size_t)t << 12);
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const cplx e = cmul(e1v, e2t[k]);
-                        const cplx u = x[k], v = x[k + 8];
-                        const cplx sx = cadd(cscale(u, s11), cmul(s12, v));
-                        const cplx sy = csub(cmulc(u, s12), cscale(v, s11));
-                        x[k] = make_double2(e.x * u.x - e.y * sx.y, e.x * u.y + e.y * sx.x);
-                        x[k + 8] = make_double2(e.x * v.x - e.y * sy.y, e.x * v.y + e.y * sy.x);
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const cplx h = cexp_neg_turns_tab(btv[k] * cur, ct);
-                    x[k] = cmul(h, x[k]);
-                    x[k + 8] = cmul(h, x[k + 8]);
-                }
-            } else {
-                const double *d1 = a.db1_p + (size_t)c * N + rowbase + ib;
-                const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last;
-                for (int k = 0; k < 8; k++) pmd_trunks(x[k], x[k + 8], btv[k], d1[k], brf, a.nplates, n0, ntrunk, dzb_first, dzb_last, a.lcorr, cur);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
-        }
+        pair_multiplier<12>(a, x, btv, ct, ctl, f, c, brow, rowbase, ib);
     } else {
         if (a.hmul) {
             int o16 = 16 * tid;
@@ -1199,8 +1212,11 @@ template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2
 // one row x 2 (two waves per polarisation: one barrier per outer exchange).  The LDS-resident k_row makes 9 - 11
 // barrier-separated passes over the same rows (0.48 / 0.41 / 0.29 of 8 TB/s at 2^17 / 2^18 / 2^19 samples).
 // Twiddles: the compact table of W_M (TwCompact); the middle level's lane twiddles from a 7 x 16 table of the plan (twmid).
+// PAIR (PMD plans, inverse_pmd's matrix tables): the same workgroup with the threads dealt so that lanes i and i + 32 of every
+// wave hold the same thread index of the X and the Y row (a row-polarisation is then half of 1, 2 or 4 waves: the outer
+// exchanges of 1024- and 2048-point rows meet at a workgroup barrier) and pair_multiplier in the place of the scalar phase.
 #define ROWG_THREADS 256
-template <int LOGM> __global__ __launch_bounds__(ROWG_THREADS, 2) void k_rowreg(SsfmArgs a)
+template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) void k_rowreg(SsfmArgs a)
 {
     constexpr int M = 1 << LOGM, S = M / 16, R = M / 256, RP = ROWG_THREADS / S, PITCH = M + M / 16, NTW = M / 8 + 4;
     PLX_DYN_LDS(lds);
@@ -1214,7 +1230,12 @@ template <int LOGM> __global__ __launch_bounds__(ROWG_THREADS, 2) void k_rowreg(
     const int fc = f * a.nfc + c;
     const FrameCtl *ctl = a.ctl + f;
     if (ctl->done) return;
-    const int rp = tid / S, t = tid - rp * S, rl = rp >> 1, pol = rp & 1;      // row-polarisation, thread within it, row within the workgroup
+    // row within the workgroup, polarisation, thread within the row-polarisation
+    constexpr int WPR = S / 32 > 0 ? S / 32 : 1;         // PAIR: waves per row (both polarisations)
+    const int rl = PAIR ? (tid >> 6) / WPR : (tid / S) >> 1, pol = PAIR ? (tid >> 5) & 1 : (tid / S) & 1;
+    const int t = PAIR ? ((tid >> 6) % WPR) * 32 + (tid & 31) : tid % S;
+    const int rp = 2 * rl + pol;
+    constexpr bool WAVE_LOCAL = PAIR ? S <= 32 : S <= 64;    // a row-polarisation's threads are lanes of one wave
     cplx *const s = (cplx *)lds + rp * PITCH;            // this row-polarisation's padded row: physical(p) = p + (p >> 4)
     cplx *const tw = (cplx *)lds + RP * PITCH;           // compact W_M
     cplx *const tm = tw + NTW;                           // [7][16]: the middle level's twiddles, lane-fastest
@@ -1242,7 +1263,7 @@ template <int LOGM> __global__ __launch_bounds__(ROWG_THREADS, 2) void k_rowreg(
     lvl2_dif<S>(x, t, wm);
 #pragma unroll
     for (int k = 0; k < 16; k++) s[row_phys(t + S * k)] = x[k];
-    if (S > 64) __syncthreads(); else ROWR_SYNC();       // (S <= 64: the row-polarisation's threads are lanes of one wave)
+    if (!WAVE_LOCAL) __syncthreads(); else ROWR_SYNC();
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
     cplx wl[7];
@@ -1252,16 +1273,19 @@ template <int LOGM> __global__ __launch_bounds__(ROWG_THREADS, 2) void k_rowreg(
 #pragma unroll
     for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
     ROWR_SYNC();                                         // (a chunk's sixteen threads are lanes of one wave)
-    double btv[16];
-    if (!a.hmul) {
-        const double *bt = a.betat_p + (size_t)c * N + rowbase + 16 * t;
+    const int ib = 16 * t + (PAIR && pol ? 8 : 0);       // (PAIR: the eight bins whose two polarisations the lane holds after the trade)
+    double btv[PAIR ? 8 : 16];
+    if (!a.hmul && !(PAIR && a.umat)) {
+        const double *bt = a.betat_p + (size_t)c * N + rowbase + ib;
 #pragma unroll
-        for (int k = 0; k < 16; k++) btv[k] = bt[k];
+        for (int k = 0; k < (PAIR ? 8 : 16); k++) btv[k] = bt[k];
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[17 * t + k];               // row_phys(16 t + k)
     r16_dif(x);
-    if (a.hmul) {
+    if (PAIR && !a.hmul) {
+        pair_multiplier<LOGM>(a, x, btv, ct, ctl, f, c, (int)blockIdx.x * (RP / 2) + rl, rowbase, ib);
+    } else if (a.hmul) {
         int o16 = 16 * t;
         pin(o16);
         const cplx *h = a.hmul + rowbase + o16;
@@ -1270,7 +1294,7 @@ template <int LOGM> __global__ __launch_bounds__(ROWG_THREADS, 2) void k_rowreg(
     } else {
         const double cur = a.force ? a.f_cur : ctl->cur;
 #pragma unroll
-        for (int k = 0; k < 16; k++) x[k] = cmul(cexp_neg_turns_tab(btv[k] * cur, ct), x[k]);
+        for (int k = 0; k < (PAIR ? 8 : 16); k++) x[k] = cmul(cexp_neg_turns_tab(btv[k] * cur, ct), x[k]);      // (PAIR comes here with hmul only)
     }
     r16_dit(x);
 #pragma unroll
@@ -1278,16 +1302,23 @@ template <int LOGM> __global__ __launch_bounds__(ROWG_THREADS, 2) void k_rowreg(
     ROWR_SYNC();
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+    {
+        // (the lane's twiddles are fetched again rather than held across the multiplier: up to 28 registers)
+        int jq = j2;
+        pin(jq);
+#pragma unroll
+        for (int q = 0; q < (R == 8 ? 7 : (R == 4 ? 3 : 1)); q++) wl[q] = tm[16 * q + jq];
+    }
     lvlmid_dit<R>(x, wl);
 #pragma unroll
     for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
-    if (S > 64) __syncthreads(); else ROWR_SYNC();
+    if (!WAVE_LOCAL) __syncthreads(); else ROWR_SYNC();
     int jo = t;
     pin(jo);
     const cplx tb = tp[jo];                              // (asked for ahead of the last register level)
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[row_phys(t + S * k)];
-    lvl2_dit<S>(x, t, wm);
+    lvl2_dit<S>(x, PAIR ? jo : t, wm);                   // (PAIR, jo: the lane's three second-stage twiddles are formed again, not held across the trunk loop)
 #pragma unroll
     for (int k = 0; k < 16; k++) u[jo + S * k] = cmulc(x[k], cmul(tb, bk[k]));
 }
@@ -2098,7 +2129,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
         UP(P->d_ctab, ctv, cplx);
     }
     // k_rowreg: register-form row pass for dual-polarisation plans without PMD whose rows have 512, 1024 or 2048 points
-    if (tune.rowr && a.dual && !desc->fls[1] && P->p2 >= 9 && P->p2 <= 11 && N1 >= (ROWG_THREADS / (N2 / 16)) / 2) {
+    if (tune.rowr && a.dual && P->p2 >= 9 && P->p2 <= 11 && N1 >= (ROWG_THREADS / (N2 / 16)) / 2) {
         const long double tau = -2.0L * 3.14159265358979323846264338327950288L;
         std::vector<cplx> tc(N2 / 8 + 4), tm(7 * 16, make_double2(1.0, 0.0));
         for (int k = 0; k < N2 / 8 + 4; k++) {
@@ -2115,7 +2146,8 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
         }
         UP(P->d_tw2c, tc, cplx);
         UP(P->d_twmid, tm, cplx);
-        const hipError_t e = P->p2 == 9 ? allow_lds(k_rowreg<9>, ROWG_LDS(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10>, ROWG_LDS(1024)) : allow_lds(k_rowreg<11>, ROWG_LDS(2048));
+        hipError_t e = P->p2 == 9 ? allow_lds(k_rowreg<9, false>, ROWG_LDS(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10, false>, ROWG_LDS(1024)) : allow_lds(k_rowreg<11, false>, ROWG_LDS(2048));
+        if (e == hipSuccess) e = P->p2 == 9 ? allow_lds(k_rowreg<9, true>, ROWG_LDS(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10, true>, ROWG_LDS(1024)) : allow_lds(k_rowreg<11, true>, ROWG_LDS(2048));
         if (e == hipSuccess) P->rowreg = 1;
     }
     UP(P->d_gam, gam, double);
@@ -2283,11 +2315,18 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         PLX_LAUNCH(k_row4k<true>, dim3((unsigned)N1 * FC), dim3(512), P->rs_lds_pair, st, a);
         return;
     }
-    if (P->rowreg && a.dual && !a.pmd && !a.umat) {
+    if (P->rowreg && a.dual) {
         const unsigned gx = (unsigned)(N1 / ((ROWG_THREADS / ((1 << a.p2) / 16)) / 2));
-        if (a.p2 == 9) PLX_LAUNCH(k_rowreg<9>, dim3(gx, FC), dim3(ROWG_THREADS), ROWG_LDS(512), st, a);
-        else if (a.p2 == 10) PLX_LAUNCH(k_rowreg<10>, dim3(gx, FC), dim3(ROWG_THREADS), ROWG_LDS(1024), st, a);
-        else PLX_LAUNCH(k_rowreg<11>, dim3(gx, FC), dim3(ROWG_THREADS), ROWG_LDS(2048), st, a);
+        const dim3 g(gx, FC), bs(ROWG_THREADS);
+        if (a.pmd || a.umat) {                   // the multiplier couples the polarisations: lanes i and i + 32 hold X and Y
+            if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, true>), g, bs, ROWG_LDS(512), st, a);
+            else if (a.p2 == 10) PLX_LAUNCH((k_rowreg<10, true>), g, bs, ROWG_LDS(1024), st, a);
+            else PLX_LAUNCH((k_rowreg<11, true>), g, bs, ROWG_LDS(2048), st, a);
+        } else {
+            if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, false>), g, bs, ROWG_LDS(512), st, a);
+            else if (a.p2 == 10) PLX_LAUNCH((k_rowreg<10, false>), g, bs, ROWG_LDS(1024), st, a);
+            else PLX_LAUNCH((k_rowreg<11, false>), g, bs, ROWG_LDS(2048), st, a);
+        }
         return;
     }
     if (P->row_split && a.dual && !a.pmd) {
@@ -2613,7 +2652,7 @@ int plx_ssfm_filter_dev(plx_ssfm *P, cplx *d_ux, cplx *d_uy, const cplx *d_hmul,
     PLX_HIP(hipMemsetAsync(P->d_ndone, 0, 64, st));
     const dim3 gcol((unsigned)(N2 / b.W), FC), grow((unsigned)(N1 / b.R), FC);
     PLX_LAUNCH(k_col_fwd, gcol, dim3((unsigned)P->col_threads), P->lds_col, st, b);
-    if (d_umat && !P->tw_compact) PLX_LAUNCH(k_row, grow, dim3((unsigned)P->row_threads), P->lds_row, st, b);   // matrix tables couple the polarisations
+    if (d_umat && !P->tw_compact && !P->rowreg) PLX_LAUNCH(k_row, grow, dim3((unsigned)P->row_threads), P->lds_row, st, b);   // matrix tables couple the polarisations
     else launch_row(P, b, FC, st);
     PLX_LAUNCH(k_col_inv, gcol, dim3((unsigned)P->col_threads), P->lds_col, st, b);
     PLX_HIP(hipGetLastError());

@@ -521,11 +521,13 @@ def test_emu_long_rows_both_polarisations_pmd(emu, oracle, monkeypatch, tables):
     assert np.abs(got[True][0] - got[False][0]).max() < 1e-12 * np.abs(got[False][0]).max()
 
 
-def test_emu_inverse_pmd_long_rows(emu, oracle, monkeypatch):
-    """inverse_pmd's matrix tables (inverse_pmd.m:130-141) through the 4096-point row pass: the plan of plx_pmdinv is a PMD-type
-    plan, so k_row4k<true> applies (Hgvd U)^H bin by bin after the halves' trade.  4 x 4096 split against oracle/pmdinv.py."""
+@pytest.mark.parametrize("nsymb,nt", [(256, 64), (64, 64), (256, 8)])
+def test_emu_inverse_pmd_long_rows(emu, oracle, monkeypatch, nsymb, nt):
+    """inverse_pmd's matrix tables (inverse_pmd.m:130-141) through the register-form row passes: the plan of plx_pmdinv is a
+    PMD-type plan, so k_row4k<true> (4 x 4096 split) / k_rowreg<., true> (4 x 1024, 4 x 512) apply (Hgvd U)^H bin by bin after
+    the halves' trade.  Against oracle/pmdinv.py."""
     from oracle import pmdinv
-    nsymb, nt, n = 256, 64, 16384
+    n = nsymb * nt
     fn = synth.fn_grid(nsymb, nt)
     omega = 2 * np.pi * 10.0 * fn
     betat = 0.5 * omega ** 2 * -2.17e-8 + omega ** 3 * 1.3e-10 / 6
@@ -595,6 +597,51 @@ def test_emu_register_form_rows_512_to_2048(emu, oracle, monkeypatch, logm):
         got[mode] = (gx.copy(), gy.copy())
     assert np.abs(got["1"][0] - got["0"][0]).max() < 1e-12 * np.abs(got["0"][0]).max()
     assert not np.array_equal(got["1"][0], got["0"][0])      # (the switch really selects another kernel)
+
+
+@pytest.mark.parametrize("logm,tables", [(9, True), (10, True), (10, False), (11, True)])
+def test_emu_register_form_rows_both_polarisations_pmd(emu, oracle, monkeypatch, logm, tables):
+    """k_rowreg<., true>: rows of 512 / 1024 / 2048 points of a PMD plan -- lanes i and i + 32 of every wave hold the same thread
+    of the X and the Y row and trade halves around the waveplate trunks (pair_multiplier, shared with k_row4k<true>).  4 x M
+    split with its own waveplates against the oracle and against k_row's PMD branch (PLX_SSFM_ROWR=0)."""
+    if not tables:
+        monkeypatch.setenv("PLX_SSFM_NO_PMD_TAB", "1")
+    M = 1 << logm
+    n, nt, nplates, L = 4 * M, (16 if logm == 10 else 32), 4, 9e2
+    fls = [1, 1, 1, 0]
+    betat, db1 = _tables(n, nt, fls, nplates)
+    r = np.random.default_rng(29)
+    brf = (r.random(nplates) * 2 * np.pi - np.pi, r.random(nplates) * np.pi - np.pi / 2, 0.5 * np.arcsin(r.random(nplates) * 2 - 1))
+    fx, fy = _qpsk_field(n, nt, 6.0)[:2]
+    rc, ofd, onc, ox, oy = oracle.matrix_ssfm(fx, fy, betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, nplates, 0, fls, *brf)
+    assert rc == 0 and onc >= 3
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PLX_SSFM_ROWR", mode)
+        monkeypatch.setenv("PLX_SSFM_P1", "2")
+        monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
+        monkeypatch.setenv("PLX_SSFM_LOGW", "6")
+        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, nplates=nplates, frames=1)
+        plan = C.c_void_p()
+        emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+        for k in ("PLX_SSFM_ROWR", "PLX_SSFM_P1", "PLX_SSFM_COL_THREADS", "PLX_SSFM_LOGW"):
+            monkeypatch.delenv(k)
+        info = (C.c_int32 * 8)()
+        emu.call("plx_ssfm_info", plan, info)
+        assert list(info)[:3] == [0, 2, logm] and (info[7] == 2) == (mode == "1")
+        emu.call("plx_ssfm_set_birefringence", plan, _vp(brf[0]), _vp(brf[1]), _vp(brf[2]), 1)
+        ux = _il(fx[None]); uy = _il(fy[None])
+        emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 1, None)
+        ncyc = np.zeros(1, np.int32)
+        emu.call("plx_ssfm_results", plan, 1, None, _vp(ncyc))
+        emu.call("plx_ssfm_destroy", plan)
+        gx = ux.view(np.complex128).reshape(n); gy = uy.view(np.complex128).reshape(n)
+        assert ncyc[0] == onc
+        assert np.abs(gx - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
+        assert np.abs(gy - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
+        got[mode] = (gx.copy(), gy.copy())
+    assert np.abs(got["1"][1] - got["0"][1]).max() < 1e-12 * np.abs(got["0"][1]).max()
+    assert not np.array_equal(got["1"][0], got["0"][0])
 
 
 def test_emu_frame_barrier_timeout_aborts_cleanly(emu, monkeypatch):

@@ -692,3 +692,44 @@ def test_frames_of_2pow17_to_2pow19_register_form_rows_vs_oracle(lib, oracle, mo
     assert nc0.tolist() == nc1.tolist() and nc0[2] > nc0[1] > nc0[0]
     for a, b in ((x0, x1), (y0, y1)):
         assert np.abs(a - b).max() <= FIELD_RTOL * np.abs(b).max()
+
+
+@pytest.mark.parametrize("nsymb,nt", [(4096, 64), (4096, 128)])
+def test_pmd_frames_of_2pow18_and_2pow19_register_form_rows_vs_oracle(lib, oracle, monkeypatch, nsymb, nt):
+    """fiber('gps-') on frames of 2^18 and 2^19 samples: fused column sweep + k_rowreg<., true> (lanes i and i + 32 of a wave
+    hold X and Y of the same bins and trade halves around the trunk loop).  Two frames with their own waveplate draws and
+    launch powers: the stronger against oracle.matrix_ssfm (1e-9, ncycle), both against k_row's PMD branch (PLX_SSFM_ROWR=0)."""
+    import torch
+    from polmux_amd import pipeline
+    out = []
+    scale = np.array([1.0, 2.0])
+    for env in ({}, {"PLX_SSFM_ROWR": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cfg = pipeline.HotPathConfig(nsymb=nsymb, nt=nt, flag="gps-", nplates=50, dgd=0.1, length=4e4, dphimax=2e-2)
+        hp = pipeline.HotPath(cfg, max_frames=2)
+        for k in env:
+            monkeypatch.delenv(k)
+        info = hp.info()
+        assert info[0] == 1 and info[1] == 8 and (info[7] == 2) == (not env)
+        brf = hp.set_random_pmd([41, 42])
+        ux, uy = hp.make_batch(2, scale)
+        hp.fibre(ux, uy)
+        _sync()
+        out.append((hp.last_ncycle(2).copy(), ux.cpu().numpy(), uy.cpu().numpy()))
+        if not env:
+            gam, betat, db1 = hp._keep
+            hx, hy = hp.tx_host[0] * math.sqrt(scale[1]), hp.tx_host[1] * math.sqrt(scale[1])
+            rc, fd, nc, ox, oy = oracle.matrix_ssfm(hx, hy, betat, db1, cfg.dzmax, cfg.dphimax, gam, hp.alphalin, cfg.length, cfg.nplates,
+                                                    0, hp.fls, brf[0][1], brf[1][1], brf[2][1])
+            assert rc == 0 and nc == out[0][0][1] and nc > 4
+            sc = max(np.abs(ox).max(), np.abs(oy).max())
+            assert np.abs(out[0][1][1] - ox[:, 0]).max() <= FIELD_RTOL * sc
+            assert np.abs(out[0][2][1] - oy[:, 0]).max() <= FIELD_RTOL * sc
+        hp.close()
+        del ux, uy
+        torch.cuda.empty_cache()
+    (nc0, x0, y0), (nc1, x1, y1) = out
+    assert nc0.tolist() == nc1.tolist() and nc0[1] > nc0[0]
+    for a, b in ((x0, x1), (y0, y1)):
+        assert np.abs(a - b).max() <= FIELD_RTOL * np.abs(b).max()
