@@ -12,13 +12,14 @@ lib = _abi.get()
 vp = lambda a: C.c_void_p(a.ctypes.data)
 r = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+LG0, LG1 = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (8, 13)     # log2 of the frame sizes drawn (large: 16 19)
 worst = 0.0
 bad = 0
 ran = 0
 illc = 0
 for case in range(ncase):
-    lg = int(r.integers(8, 14))
-    ntl = int(r.choice([3, 4, 5]))
+    lg = int(r.integers(LG0, LG1 + 1))
+    ntl = int(r.choice([3, 4, 5] if lg < 16 else [5, 6, 7]))
     nsl = lg - ntl
     if nsl % 2: nsl -= 1; lg = nsl + ntl
     if nsl < 6: continue
@@ -30,7 +31,7 @@ for case in range(ncase):
     if flag == "----": flag = "g---"
     nplates = int(r.choice([1, 3, 10, 37])) if flag[1] == "p" else 1
     manakov = bool(r.integers(0, 2)) and flag[1] == "p"
-    L = float(r.choice([5e3, 2e4, 8e4]))
+    L = float(r.choice([5e3, 2e4, 8e4] if LG1 < 16 else [2e3, 5e3, 1e4]))
     pavg = float(r.choice([0.5, 2.0, 8.0]))
     px.reset_all(nsymb, nt, nfc); GSTATE.SYMBOLRATE = 28.0
     GSTATE.NCH = nfc; GSTATE.LAMBDA = 1550.0 + 0.4 * (np.arange(nfc) - (nfc - 1) / 2) if nfc > 1 else np.array([1550.0])

@@ -494,7 +494,7 @@ def test_emu_long_rows_both_polarisations_pmd(emu, oracle, monkeypatch, tables):
     rc, ofd, onc, ox, oy = oracle.matrix_ssfm(fx, fy, betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, nplates, 0, fls, *brf)
     assert rc == 0 and onc >= 3
     got = {}
-    for short in (False, True):
+    for short in ((False, True) if tables else (False,)):      # (the 8 x 2048 comparison once: it doubles the emulated work)
         monkeypatch.setenv("PLX_SSFM_P1", "3" if short else "2")
         monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
         monkeypatch.setenv("PLX_SSFM_LOGW", "6")
@@ -518,7 +518,8 @@ def test_emu_long_rows_both_polarisations_pmd(emu, oracle, monkeypatch, tables):
         assert np.abs(gx - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
         assert np.abs(gy - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
         got[short] = (gx.copy(), gy.copy())
-    assert np.abs(got[True][0] - got[False][0]).max() < 1e-12 * np.abs(got[False][0]).max()
+    if tables:
+        assert np.abs(got[True][0] - got[False][0]).max() < 1e-12 * np.abs(got[False][0]).max()
 
 
 @pytest.mark.parametrize("nsymb,nt", [(256, 64), (64, 64), (256, 8)])
@@ -577,7 +578,8 @@ def test_emu_register_form_rows_512_to_2048(emu, oracle, monkeypatch, logm):
         monkeypatch.setenv("PLX_SSFM_P1", "2")
         monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
         monkeypatch.setenv("PLX_SSFM_LOGW", "6")
-        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=2)
+        nf = 2 if logm == 9 else 1                             # (a two-frame batch where the emulated work is small)
+        d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=nf)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
         for k in ("PLX_SSFM_ROWR", "PLX_SSFM_P1", "PLX_SSFM_COL_THREADS", "PLX_SSFM_LOGW"):
@@ -585,11 +587,11 @@ def test_emu_register_form_rows_512_to_2048(emu, oracle, monkeypatch, logm):
         info = (C.c_int32 * 8)()
         emu.call("plx_ssfm_info", plan, info)
         assert list(info)[:3] == [0, 2, logm] and (info[7] == 2) == (mode == "1")
-        ux = _il(np.stack([f[0], 0.5 * f[1]])); uy = _il(np.stack([f[1], f[0]]))
-        emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 2, None)
-        nc = np.zeros(2, np.int32)
-        emu.call("plx_ssfm_results", plan, 2, None, _vp(nc))
-        gx = ux.view(np.complex128).reshape(2, n); gy = uy.view(np.complex128).reshape(2, n)
+        ux = _il(np.stack([f[0], 0.5 * f[1]])[:nf]); uy = _il(np.stack([f[1], f[0]])[:nf])
+        emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), nf, None)
+        nc = np.zeros(nf, np.int32)
+        emu.call("plx_ssfm_results", plan, nf, None, _vp(nc))
+        gx = ux.view(np.complex128).reshape(nf, n); gy = uy.view(np.complex128).reshape(nf, n)
         assert nc[0] == onc
         assert np.abs(gx[0] - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
         assert np.abs(gy[0] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
