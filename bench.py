@@ -412,12 +412,14 @@ def workload_label(a, n):
         return tag + ": " + what
     if a.mc:
         tag = "ex24_pmd-style random-PMD batch (BASELINE config[3] realisations in the timed region: fresh waveplates per frame and step)"
-    elif n == 1 << 20 or a.spans > 1 or a.power_ladder:
+    elif (n == 1 << 20 or a.spans > 1 or a.power_ladder) and a.flag == "g-s-":
         tag = "long-haul launch-power-sweep style (BASELINE config[4]: 2^20-sample frame x 40 spans x 64-point ladder%s)" % (
             "" if (n == 1 << 20 and a.spans == 40 and a.power_ladder) else
             "; this line: 2^%d samples, %d span(s), %s" % (int(np.log2(n)), a.spans, "power ladder" if a.power_ladder else "one launch power"))
     elif n == 65536 and a.flag == "g-s-" and a.nt == 64:
         tag = "Run_my_PDM_QPSK-style (BASELINE config[1])"
+    elif n == 1 << 18 and a.flag == "g-s-" and a.nt == 64:
+        tag = "custom configuration (no BASELINE config; the frame size Run_my_PDM_QPSK.m:21-24 ships with, 4096 symbols x 64 samples, on config[1]'s link)"
     else:
         tag = "custom configuration (no BASELINE config)"
     return tag + ": " + what
@@ -439,6 +441,8 @@ def offline_traffic(fused, F, n, nch=1, flag="g-s-"):
             return None, None
         elif n == 1 << 20:
             tr = tr.get("frames_2pow20", {})
+        elif n == 1 << 18:
+            tr = tr.get("frames_2pow18", {})
         elif n != 65536:
             return None, None
         if not fused:

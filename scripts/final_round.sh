@@ -16,7 +16,9 @@ if [ $part = lines ]; then
   timeout -k 10 300 python3 bench.py --nsymb 16384 --frames 16 --steps 4 --warmup 1 --variants 1 --share-device no --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_c4_frame_fused.json 2>/dev/null || exit 1
   timeout -k 10 600 python3 bench.py --nsymb 16384 --frames 8 --spans 40 --power-ladder --steps 2 --warmup 1 --variants 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_c4_40spans.json 2>/dev/null || exit 1
   timeout -k 10 600 python3 bench.py --nch 16 --spans 10 --nf 5 --frames 32 --steps 3 --warmup 1 --mc-rounds 0 --no-gateway > $O/bench_c2.json 2>/dev/null || exit 1
-  cat $O/bench_default.json $O/bench_no_overlap.json $O/bench_cohmix.json $O/bench_ladder.json $O/bench_mc.json $O/bench_c4_frame.json $O/bench_c4_frame_fused.json $O/bench_c4_40spans.json $O/bench_c2.json > $O/bench.jsonl
+  timeout -k 10 300 python3 bench.py --nsymb 4096 --frames 256 --steps 4 --warmup 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_2pow18.json 2>/dev/null || exit 1
+  timeout -k 10 300 python3 bench.py --nsymb 16384 --flag gps- --frames 16 --steps 3 --warmup 1 --variants 1 --share-device no --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_2pow20_pmd.json 2>/dev/null || exit 1
+  cat $O/bench_default.json $O/bench_no_overlap.json $O/bench_cohmix.json $O/bench_ladder.json $O/bench_mc.json $O/bench_c4_frame.json $O/bench_c4_frame_fused.json $O/bench_c4_40spans.json $O/bench_c2.json $O/bench_2pow18.json $O/bench_2pow20_pmd.json > $O/bench.jsonl
   python3 - <<PY
 import json
 for l in open("$O/bench.jsonl"):

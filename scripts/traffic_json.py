@@ -54,4 +54,11 @@ if os.path.exists(os.path.join(d, "wdm_FETCH_SIZE.txt")):      # BASELINE config
     res["wdm_16ch"] = {"samples_per_launch": sw, "kernels": list(per), "fetch_kb": [fe.get(k) for k in per], "write_kb": [wr.get(k) for k in per],
                        "bytes_per_sample_by_kernel": per, "bytes_per_sample_step": sum(per.values()),
                        "note": "a frame = 16 channels x 2^16 samples = one team of the fused sweep (512 tiles); row pass = k_row256r<PMD> (100 waveplates)"}
+if os.path.exists(os.path.join(d, "mid_FETCH_SIZE.txt")):      # 2^18-sample frames, 64 per launch: k_colx16 + k_rowreg
+    fe, wr = read("mid", "FETCH_SIZE"), read("mid", "WRITE_SIZE")
+    sm = 64 * (1 << 18)
+    per = {k: (2 * fe[k] + wr[k]) * 1024 / sm for k in ("k_colx16", "k_rowreg") if k in fe and k in wr}
+    res["frames_2pow18"] = {"samples_per_launch": sm, "kernels": list(per), "fetch_kb": [fe.get(k) for k in per], "write_kb": [wr.get(k) for k in per],
+                            "bytes_per_sample_by_kernel": per, "bytes_per_sample_step": sum(per.values()),
+                            "note": "4096 symbols x 64 samples (Run_my_PDM_QPSK.m:21-24): 256 x 1024 split, row pass = k_rowreg<10> (one wave per row and polarisation)"}
 print(json.dumps(res, indent=1))

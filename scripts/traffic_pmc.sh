@@ -37,4 +37,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   grep -E "k_colx16|k_row" gpurun_out/traffic/wdm_$c.txt
   rm -rf gpurun_out/traffic/pmc_$c
 done
+# 2^18-sample frames (the size Run_my_PDM_QPSK.m ships with), fused step: k_colx16 + k_rowreg<10>, 64 frames per launch
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf gpurun_out/traffic/pmc_$c
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/traffic/pmc_$c -- python3 bench.py --nsymb 4096 --frames 64 --steps 1 --warmup 0 --variants 1 --mc-rounds 0 --no-cpu-baseline --no-overlap --no-single-frame --no-gateway > /dev/null 2>&1 || exit 1
+  f=$(find gpurun_out/traffic/pmc_$c -name "*counter_collection.csv" | head -1)
+  python scripts/pmc_summary.py $f > gpurun_out/traffic/mid_$c.txt
+  grep -E "k_colx16|k_row" gpurun_out/traffic/mid_$c.txt
+  rm -rf gpurun_out/traffic/pmc_$c
+done
 python scripts/traffic_json.py gpurun_out/traffic $F > gpurun_out/traffic/traffic.json && cat gpurun_out/traffic/traffic.json
