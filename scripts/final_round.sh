@@ -53,6 +53,11 @@ if [ $part = trace ]; then
   python3 scripts/prof_summary.py $f > $O/kernel_trace_wdm16_summary.md
   head -6 $O/kernel_trace_wdm16_summary.md
   rm -rf $O/prof4
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof5 -- python3 bench.py --nsymb 4096 --frames 256 --steps 2 --warmup 1 --variants 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-overlap --no-gateway > /dev/null 2>&1 || exit 1
+  f=$(find $O/prof5 -name "*kernel_trace.csv" | head -1)
+  python3 scripts/prof_summary.py $f > $O/kernel_trace_2pow18_summary.md
+  head -6 $O/kernel_trace_2pow18_summary.md
+  rm -rf $O/prof5
 fi
 if [ $part = traffic ]; then
   scripts/traffic_pmc.sh 256 > $O/traffic.log 2>&1 && cp gpurun_out/traffic/traffic.json $O/traffic.json

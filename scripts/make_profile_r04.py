@@ -1,10 +1,11 @@
-"""dev tool: turn gpurun_out/r04final/* (scripts/final_round.sh lines|trace|traffic r04final) into the files of record under profiles/."""
+"""dev tool: turn gpurun_out/<tag>/* (scripts/final_round.sh lines|trace|traffic <tag>; default tag r04final) into the files of record under profiles/."""
 import json
 import os
 import shutil
+import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(R, "gpurun_out", "r04final")
+F = os.path.join(R, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r04final")
 P = os.path.join(R, "profiles")
 
 
@@ -27,6 +28,8 @@ out = ["# Round 4: rocprofv3 --kernel-trace --stats of the bench (F = 1024 C1 fr
        "\n## Per-kernel summary, `--no-overlap` run\n", rd("kernel_trace_no_overlap_summary.md"),
        "\n## Per-kernel summary, 2^20-sample frames (16 per launch; `k_row4k` is the row pass; `--no-overlap` keeps the fused step)\n", rd("kernel_trace_2pow20_summary.md"),
        "\n## Per-kernel summary, 16-channel WDM frames (BASELINE config[2]'s frame, 'gps-' with 100 waveplates; 32 frames per launch)\n", rd("kernel_trace_wdm16_summary.md"),
+       "\n## Per-kernel summary, 2^18-sample frames (4096 symbols x 64 samples, the size Run_my_PDM_QPSK.m ships with; 256 per launch; `k_rowreg` is the row pass)\n",
+       rd("kernel_trace_2pow18_summary.md") if os.path.exists(os.path.join(F, "kernel_trace_2pow18_summary.md")) else "(not traced)",
        "\n## rocprofv3 --stats (kernel_stats.csv, top rows, default run)\n\n```", rd("kernel_stats_head.csv").rstrip(), "```\n"]
 d = json.loads(rd("bench_default.json").strip().splitlines()[-1])
 r = d["roofline"]
