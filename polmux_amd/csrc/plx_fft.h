@@ -370,6 +370,17 @@ template <int M> struct TwCompact {
     }
 };
 
+// W_M^e (e < M) over the half table t[k] = W_M^k, k < M/2
+template <int M> struct TwHalf {
+    const cplx *t;
+    __device__ __forceinline__ cplx operator()(int e) const
+    {
+        const cplx w = t[e & (M / 2 - 1)];
+        const bool neg = (e & (M - 1)) >= M / 2;
+        return make_double2(neg ? -w.x : w.x, neg ? -w.y : w.y);
+    }
+};
+
 // The MIDDLE register level of a row of M = 16 * R * 16 points (R = 2, 4, 8: rows of 512, 1024 and 2048 points, k_rowreg):
 // after the first level (lvl2_dif<M/16>) the row is sixteen independent blocks of M/16 = 16 R points; a thread holds, of a
 // 256-point chunk of the row, the points j + 16 kk (kk < 16) = point j + 16 k of block h, kk = R h + k: 16 / R radix-R

@@ -1216,9 +1216,13 @@ template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2
 // wave hold the same thread index of the X and the Y row (a row-polarisation is then half of 1, 2 or 4 waves: the outer
 // exchanges of 1024- and 2048-point rows meet at a workgroup barrier) and pair_multiplier in the place of the scalar phase.
 #define ROWG_THREADS 256
+#define ROWG_NTW(M) ((M) <= 1024 ? (M) / 2 : (M) / 8 + 4)
 template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) void k_rowreg(SsfmArgs a)
 {
-    constexpr int M = 1 << LOGM, S = M / 16, R = M / 256, RP = ROWG_THREADS / S, PITCH = M + M / 16, NTW = M / 8 + 4;
+    // (twiddles of the outer level: the half table W_M^k where it fits beside two workgroups' rows -- 512 and 1024 points: 4 / 8
+    //  KiB -- and the compact table, one more complex product per twiddle, for 2048 points)
+    constexpr bool HALF_TW = LOGM <= 10;
+    constexpr int M = 1 << LOGM, S = M / 16, R = M / 256, RP = ROWG_THREADS / S, PITCH = M + M / 16, NTW = ROWG_NTW(M);
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x;
@@ -1245,14 +1249,14 @@ template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) voi
     const size_t rowbase = ((size_t)blockIdx.x * (RP / 2) + rl) << LOGM;
     cplx *const u = (pol ? a.uy : a.ux) + (size_t)fc * N + rowbase;
     const cplx *const tp = a.tpass + rowbase;
-    const TwCompact<M> wm{tw};
+    typename std::conditional<HALF_TW, TwHalf<M>, TwCompact<M>>::type wm{tw};
     const int b = t >> 4, j2 = t & 15;                   // middle level: chunk b of 256 points, point j2 + 16 kk of it
     cplx x[16];
     {
         const cplx ta = tp[t];
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = u[t + S * k];
-        for (int i = tid; i < NTW; i += ROWG_THREADS) tw[i] = a.tw2c[i];
+        for (int i = tid; i < NTW; i += ROWG_THREADS) tw[i] = HALF_TW ? a.tw2[i] : a.tw2c[i];
         if (tid < 7 * 16) tm[tid] = a.twmid[tid];
         if (tid < PLX_CTAB) ct[tid] = a.ctab[tid];
         if (pol == 0 && t < 16) bk[t] = tp[S * t];
@@ -1273,12 +1277,16 @@ template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) voi
 #pragma unroll
     for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
     ROWR_SYNC();                                         // (a chunk's sixteen threads are lanes of one wave)
-    const int ib = 16 * t + (PAIR && pol ? 8 : 0);       // (PAIR: the eight bins whose two polarisations the lane holds after the trade)
-    double btv[PAIR ? 8 : 16];
+    // SHARE (512-point rows: a wave = the two polarisations of one row, as in k_row256r): the multiplier is the same for the two
+    // polarisations of a bin, which sit in lanes i and i + 32 -- the lower half of the wave forms it for the thread's bins 0-7,
+    // the upper half for bins 8-15, and they swap (half_share)
+    constexpr bool SHARE = !PAIR && LOGM == 9, HALF_BINS = PAIR || SHARE;
+    const int ib = 16 * t + (HALF_BINS && pol ? 8 : 0);  // (PAIR: the eight bins whose two polarisations the lane holds after the trade)
+    double btv[HALF_BINS ? 8 : 16];
     if (!a.hmul && !(PAIR && a.umat)) {
         const double *bt = a.betat_p + (size_t)c * N + rowbase + ib;
 #pragma unroll
-        for (int k = 0; k < (PAIR ? 8 : 16); k++) btv[k] = bt[k];
+        for (int k = 0; k < (HALF_BINS ? 8 : 16); k++) btv[k] = bt[k];
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[17 * t + k];               // row_phys(16 t + k)
@@ -1293,8 +1301,19 @@ template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) voi
         for (int k = 0; k < 16; k++) x[k] = cmul(h[k], x[k]);
     } else {
         const double cur = a.force ? a.f_cur : ctl->cur;
+        if (SHARE) {
 #pragma unroll
-        for (int k = 0; k < (PAIR ? 8 : 16); k++) x[k] = cmul(cexp_neg_turns_tab(btv[k] * cur, ct), x[k]);      // (PAIR comes here with hmul only)
+            for (int k = 0; k < 8; k++) {
+                const cplx h = cexp_neg_turns_tab(btv[k] * cur, ct);
+                cplx ha, hb;
+                half_share(h, ha, hb);
+                x[k] = cmul(ha, x[k]);
+                x[k + 8] = cmul(hb, x[k + 8]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < (HALF_BINS ? 8 : 16); k++) x[k] = cmul(cexp_neg_turns_tab(btv[k] * cur, ct), x[k]);      // (PAIR comes here with hmul only)
+        }
     }
     r16_dit(x);
 #pragma unroll
@@ -1322,7 +1341,7 @@ template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) voi
 #pragma unroll
     for (int k = 0; k < 16; k++) u[jo + S * k] = cmulc(x[k], cmul(tb, bk[k]));
 }
-#define ROWG_LDS(M) ((size_t)((ROWG_THREADS / ((M) / 16)) * ((M) + (M) / 16) + (M) / 8 + 4 + 7 * 16 + PLX_CTAB + 17 * (ROWG_THREADS / ((M) / 16) / 2)) * sizeof(cplx))
+#define ROWG_LDS(M) ((size_t)((ROWG_THREADS / ((M) / 16)) * ((M) + (M) / 16) + ROWG_NTW(M) + 7 * 16 + PLX_CTAB + 17 * (ROWG_THREADS / ((M) / 16) / 2)) * sizeof(cplx))
 
 // ------------------------------------------------------ pass 3: inverse columns ---
 // Completes ifft (1/N), applies the attenuation of the step (:531-532) and feeds
