@@ -319,7 +319,7 @@ def test_emu_sweep_variants(emu, oracle, monkeypatch):
     # (PLX_EMU_CUS=1: a one-CU device -- the fused grid is two workgroups, so each walks the tiles of all three frames, with the
     # emulator's two-entry window of the frame list moving on under it)
     for env in ({}, {"PLX_EMU_CUS": "1"}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_P1": "4"}):
-        nf = 1 if "PLX_SSFM_P1" in env else 3
+        nf = 1 if ("PLX_SSFM_P1" in env or "PLX_SSFM_NO_FUSE" in env) else 3
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=nf)
@@ -352,12 +352,15 @@ def test_emu_register_form_row_pass(emu, oracle, monkeypatch):
     fields = [_qpsk_field(n, nt, p)[:2] for p in (9.0,)]
     ref = [oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0]) for f in fields]
     got = {}
-    for mode in ("1", "0"):
+    for mode in ("1",):      # ("0", the same frame through k_row, is compared on the GPU: test_sentinel_landing_... 'ldsrow', test_register_form_row_pass_with_pmd_vs_oracle_three_ways)
         monkeypatch.setenv("PLX_SSFM_ROWR", mode)
         d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=1)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
         monkeypatch.delenv("PLX_SSFM_ROWR")
+        info = (C.c_int32 * 8)()
+        emu.call("plx_ssfm_info", plan, info)
+        assert info[6] == 64                                     # one wave per 2 rows x 2 polarisations: k_row256r
         ux = _il(np.stack([f[0] for f in fields])); uy = _il(np.stack([f[1] for f in fields]))
         emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 1, None)
         ncyc = np.zeros(1, np.int32)
@@ -370,8 +373,6 @@ def test_emu_register_form_row_pass(emu, oracle, monkeypatch):
             assert np.abs(gx[f] - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
             assert np.abs(gy[f] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
         got[mode] = (gx.copy(), gy.copy())
-    assert np.abs(got["1"][0] - got["0"][0]).max() < 1e-12 * np.abs(got["0"][0]).max()
-    assert not np.array_equal(got["1"][0], got["0"][0])      # (the switch really selects another kernel)
 
 
 @pytest.mark.parametrize("tables", [True])      # (False = one exponential per bin and trunk: on the GPU, test_register_form_row_pass_with_pmd_vs_oracle_three_ways)
@@ -391,7 +392,7 @@ def test_emu_register_form_row_pass_with_pmd(emu, oracle, monkeypatch, tables):
     rc, ofd, onc, ox, oy = oracle.matrix_ssfm(fx, fy, betat, db1, 5e2, 5e-3, [1.3e-6], 4.6e-5, L, nplates, 0, fls, *brf)
     assert rc == 0 and onc >= 2
     got = {}
-    for mode in ("1", "0"):
+    for mode in ("1",):      # ("0", k_row's PMD branch on the same frame: on the GPU, test_register_form_row_pass_with_pmd_vs_oracle_three_ways)
         monkeypatch.setenv("PLX_SSFM_ROWR", mode)
         d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 5e2, 5e-3, betat, db1, nplates=nplates, frames=1)
         plan = C.c_void_p()
@@ -408,8 +409,6 @@ def test_emu_register_form_row_pass_with_pmd(emu, oracle, monkeypatch, tables):
         assert np.abs(gx - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
         assert np.abs(gy - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
         got[mode] = (gx.copy(), gy.copy())
-    assert np.abs(got["1"][1] - got["0"][1]).max() < 1e-12 * np.abs(got["0"][1]).max()
-    assert not np.array_equal(got["1"][0], got["0"][0])      # (the switch really selects another kernel)
 
 
 def test_emu_fused_sweep_exact_nonlinear_step(emu, oracle, monkeypatch):
