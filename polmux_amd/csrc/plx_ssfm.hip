@@ -1279,7 +1279,9 @@ template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) voi
     ROWR_SYNC();                                         // (a chunk's sixteen threads are lanes of one wave)
     // SHARE (512-point rows: a wave = the two polarisations of one row, as in k_row256r): the multiplier is the same for the two
     // polarisations of a bin, which sit in lanes i and i + 32 -- the lower half of the wave forms it for the thread's bins 0-7,
-    // the upper half for bins 8-15, and they swap (half_share)
+    // the upper half for bins 8-15, and they swap (half_share).  (For 1024-point rows the same sharing needs the PAIR dealing of
+    // the threads and with it a workgroup barrier at the outer exchanges: measured 939.3 / 941.1 us against 938.4 / 949.9 per
+    // 256-frame launch -- nothing, so those rows keep one wave per row-polarisation.)
     constexpr bool SHARE = !PAIR && LOGM == 9, HALF_BINS = PAIR || SHARE;
     const int ib = 16 * t + (HALF_BINS && pol ? 8 : 0);  // (PAIR: the eight bins whose two polarisations the lane holds after the trade)
     double btv[HALF_BINS ? 8 : 16];
