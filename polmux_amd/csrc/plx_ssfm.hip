@@ -833,7 +833,7 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 // the butterflies are k_row's, stage by stage.  Inter-pass twiddles as in k_row4k: tpass[j + 16 k] = tpass[j] * tpass[16 k],
 // a lane reads one entry and the row's sixteen lanes share sixteen (bk).
 #define ROWR_THREADS 64
-#define ROWR_LDS ((4 * 272 + 128 + 48) * sizeof(cplx))
+#define ROWR_LDS ((4 * 272 + 128 + 80) * sizeof(cplx))
 #ifdef PLX_EMU
 #define ROWR_SYNC() __syncthreads()
 #else
@@ -842,8 +842,10 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 // PMD: the waveplate trunks of matrix_step (fiber.m:907-933) need both polarisations of a bin in one lane: the halves of the
 // wave trade (half_trade) so that every lane holds ux and uy of eight bins, run pmd_trunks / pmd_trunks_tab on them -- the
 // arithmetic of k_row's PMD branch, bin by bin -- and trade back.
-template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r(SsfmArgs a)
+// SC (scalar plans, 2^16-sample frames of scalar_ssfm): the wave's four lane groups are four rows of the one field.
+template <bool PMD, bool SC = false> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r(SsfmArgs a)
 {
+    static_assert(!(PMD && SC), "PMD needs two polarisations");
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x;
@@ -857,12 +859,12 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
     if (ctl->done) return;
     cplx *const s = (cplx *)lds + (tid >> 4) * 272;      // this lane group's padded row: physical(p) = p + (p >> 4)
     cplx *const tw = (cplx *)lds + 4 * 272;              // W_256^k, k < 128
-    cplx *const bk = tw + 128 + 17 * ((tid >> 4) & 1);   // tpass[row][16 k], k < 16 (the two rows' entries on different banks)
+    cplx *const bk = tw + 128 + 17 * (SC ? tid >> 4 : (tid >> 4) & 1);   // tpass[row][16 k], k < 16 (the rows' entries on different banks)
     const Tw256half w8{tw};
-    const int j = tid & 15, r = (tid >> 4) & 1;
+    const int j = tid & 15, r = SC ? tid >> 4 : (tid >> 4) & 1;
     const size_t N = (size_t)1 << 16;
-    const size_t rowbase = ((size_t)blockIdx.x * 2 + r) << 8;
-    cplx *const u = (tid >= 32 ? a.uy : a.ux) + (size_t)fc * N + rowbase;
+    const size_t rowbase = ((size_t)blockIdx.x * (SC ? 4 : 2) + r) << 8;
+    cplx *const u = (!SC && tid >= 32 ? a.uy : a.ux) + (size_t)fc * N + rowbase;
     const cplx *const tp = a.tpass + rowbase;
     cplx x[16];
     // the second register stage's twiddles W_256^{4j}, W^{8j}, W^{12j}: from the table in memory into registers, once -- out of
@@ -876,7 +878,7 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
         {
             const cplx t0 = a.tw2[tid], t1 = a.tw2[tid + 64], t3 = tp[16 * j];
             tw[tid] = t0; tw[tid + 64] = t1;
-            if (tid < 32) bk[j] = t3;
+            if (SC || tid < 32) bk[j] = t3;
         }
         ROWR_SYNC();
 #pragma unroll
@@ -890,11 +892,11 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
     ROWR_SYNC();
     // the multiplier is the same for the two polarisations of a bin, which sit in lanes i and i + 32: the lower half of the
     // wave forms it for the lane's bins 0-7, the upper half for bins 8-15, and they swap (half_share)
-    double btv[8];
+    double btv[SC ? 16 : 8];
     {
-        const double *bt = a.betat_p + (size_t)c * N + rowbase + 16 * j + (tid >= 32 ? 8 : 0);
+        const double *bt = a.betat_p + (size_t)c * N + rowbase + 16 * j + (!SC && tid >= 32 ? 8 : 0);
 #pragma unroll
-        for (int k = 0; k < 8; k++) btv[k] = bt[k];
+        for (int k = 0; k < (SC ? 16 : 8); k++) btv[k] = bt[k];
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) x[k] = s[17 * j + k];               // row_phys(16 j + k)
@@ -943,6 +945,13 @@ template <bool PMD> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
+    } else if (SC) {
+        const double cur = ctl->cur;
+#pragma unroll
+        for (int k = 0; k < (SC ? 16 : 8); k++) {
+            x[k] = cmul(cexp_neg_turns(btv[k] * cur), x[k]);
+            sched_fence();
+        }
     } else {
         const double cur = ctl->cur;
 #pragma unroll
@@ -1217,8 +1226,10 @@ template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2
 // exchanges of 1024- and 2048-point rows meet at a workgroup barrier) and pair_multiplier in the place of the scalar phase.
 #define ROWG_THREADS 256
 #define ROWG_NTW(M) ((M) <= 1024 ? (M) / 2 : (M) / 8 + 4)
-template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) void k_rowreg(SsfmArgs a)
+// SC (scalar plans: scalar_ssfm, and the electrical filter of the front end): every row-polarisation is a row of the one field.
+template <int LOGM, bool PAIR, bool SC = false> __global__ __launch_bounds__(ROWG_THREADS, 2) void k_rowreg(SsfmArgs a)
 {
+    static_assert(!(PAIR && SC), "a scalar plan has no second polarisation to pair with");
     // (twiddles of the outer level: the half table W_M^k where it fits beside two workgroups' rows -- 512 and 1024 points: 4 / 8
     //  KiB -- and the compact table, one more complex product per twiddle, for 2048 points)
     constexpr bool HALF_TW = LOGM <= 10;
@@ -1236,9 +1247,10 @@ template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) voi
     if (ctl->done) return;
     // row within the workgroup, polarisation, thread within the row-polarisation
     constexpr int WPR = S / 32 > 0 ? S / 32 : 1;         // PAIR: waves per row (both polarisations)
-    const int rl = PAIR ? (tid >> 6) / WPR : (tid / S) >> 1, pol = PAIR ? (tid >> 5) & 1 : (tid / S) & 1;
+    const int rl = PAIR ? (tid >> 6) / WPR : (SC ? tid / S : (tid / S) >> 1), pol = PAIR ? (tid >> 5) & 1 : (SC ? 0 : (tid / S) & 1);
     const int t = PAIR ? ((tid >> 6) % WPR) * 32 + (tid & 31) : tid % S;
-    const int rp = 2 * rl + pol;
+    const int rp = SC ? rl : 2 * rl + pol;
+    constexpr int ROWS = SC ? RP : RP / 2;               // rows per workgroup
     constexpr bool WAVE_LOCAL = PAIR ? S <= 32 : S <= 64;    // a row-polarisation's threads are lanes of one wave
     cplx *const s = (cplx *)lds + rp * PITCH;            // this row-polarisation's padded row: physical(p) = p + (p >> 4)
     cplx *const tw = (cplx *)lds + RP * PITCH;           // compact W_M
@@ -1246,7 +1258,7 @@ template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) voi
     cplx *const ct = tm + 7 * 16;                        // the unit circle in 64 steps (cexp_neg_turns_tab)
     cplx *const bk = ct + PLX_CTAB + 17 * rl;            // tpass[row][S k], k < 16 (the rows' entries on different banks)
     const size_t N = (size_t)M << a.p1;
-    const size_t rowbase = ((size_t)blockIdx.x * (RP / 2) + rl) << LOGM;
+    const size_t rowbase = ((size_t)blockIdx.x * ROWS + rl) << LOGM;
     cplx *const u = (pol ? a.uy : a.ux) + (size_t)fc * N + rowbase;
     const cplx *const tp = a.tpass + rowbase;
     typename std::conditional<HALF_TW, TwHalf<M>, TwCompact<M>>::type wm{tw};
@@ -1282,7 +1294,7 @@ template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) voi
     // the upper half for bins 8-15, and they swap (half_share).  (For 1024-point rows the same sharing needs the PAIR dealing of
     // the threads and with it a workgroup barrier at the outer exchanges: measured 939.3 / 941.1 us against 938.4 / 949.9 per
     // 256-frame launch -- nothing, so those rows keep one wave per row-polarisation.)
-    constexpr bool SHARE = !PAIR && LOGM == 9, HALF_BINS = PAIR || SHARE;
+    constexpr bool SHARE = !PAIR && !SC && LOGM == 9, HALF_BINS = PAIR || SHARE;
     const int ib = 16 * t + (HALF_BINS && pol ? 8 : 0);  // (PAIR: the eight bins whose two polarisations the lane holds after the trade)
     double btv[HALF_BINS ? 8 : 16];
     if (!a.hmul && !(PAIR && a.umat)) {
@@ -1294,7 +1306,7 @@ template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) voi
     for (int k = 0; k < 16; k++) x[k] = s[17 * t + k];               // row_phys(16 t + k)
     r16_dif(x);
     if (PAIR && !a.hmul) {
-        pair_multiplier<LOGM>(a, x, btv, ct, ctl, f, c, (int)blockIdx.x * (RP / 2) + rl, rowbase, ib);
+        pair_multiplier<LOGM>(a, x, btv, ct, ctl, f, c, (int)blockIdx.x * ROWS + rl, rowbase, ib);
     } else if (a.hmul) {
         int o16 = 16 * t;
         pin(o16);
@@ -1343,7 +1355,7 @@ template <int LOGM, bool PAIR> __global__ __launch_bounds__(ROWG_THREADS, 2) voi
 #pragma unroll
     for (int k = 0; k < 16; k++) u[jo + S * k] = cmulc(x[k], cmul(tb, bk[k]));
 }
-#define ROWG_LDS(M) ((size_t)((ROWG_THREADS / ((M) / 16)) * ((M) + (M) / 16) + ROWG_NTW(M) + 7 * 16 + PLX_CTAB + 17 * (ROWG_THREADS / ((M) / 16) / 2)) * sizeof(cplx))
+#define ROWG_LDS(M) ((size_t)((ROWG_THREADS / ((M) / 16)) * ((M) + (M) / 16) + ROWG_NTW(M) + 7 * 16 + PLX_CTAB + 17 * (ROWG_THREADS / ((M) / 16))) * sizeof(cplx))
 
 // ------------------------------------------------------ pass 3: inverse columns ---
 // Completes ifft (1/N), applies the attenuation of the step (:531-532) and feeds
@@ -2150,7 +2162,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
         UP(P->d_ctab, ctv, cplx);
     }
     // k_rowreg: register-form row pass for dual-polarisation plans without PMD whose rows have 512, 1024 or 2048 points
-    if (tune.rowr && a.dual && P->p2 >= 9 && P->p2 <= 11 && N1 >= (ROWG_THREADS / (N2 / 16)) / 2) {
+    if (tune.rowr && P->p2 >= 9 && P->p2 <= 11 && N1 >= (ROWG_THREADS / (N2 / 16)) / (a.dual ? 2 : 1)) {
         const long double tau = -2.0L * 3.14159265358979323846264338327950288L;
         std::vector<cplx> tc(N2 / 8 + 4), tm(7 * 16, make_double2(1.0, 0.0));
         for (int k = 0; k < N2 / 8 + 4; k++) {
@@ -2169,6 +2181,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
         UP(P->d_twmid, tm, cplx);
         hipError_t e = P->p2 == 9 ? allow_lds(k_rowreg<9, false>, ROWG_LDS(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10, false>, ROWG_LDS(1024)) : allow_lds(k_rowreg<11, false>, ROWG_LDS(2048));
         if (e == hipSuccess) e = P->p2 == 9 ? allow_lds(k_rowreg<9, true>, ROWG_LDS(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10, true>, ROWG_LDS(1024)) : allow_lds(k_rowreg<11, true>, ROWG_LDS(2048));
+        if (e == hipSuccess) e = P->p2 == 9 ? allow_lds(k_rowreg<9, false, true>, ROWG_LDS(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10, false, true>, ROWG_LDS(1024)) : allow_lds(k_rowreg<11, false, true>, ROWG_LDS(2048));
         if (e == hipSuccess) P->rowreg = 1;
     }
     UP(P->d_gam, gam, double);
@@ -2200,6 +2213,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
     }
     if (tune.rowr && a.dual && a.p1 == 8 && a.p2 == 8 && !P->row_split &&
         (a.pmd ? allow_lds(k_row256r<true>, ROWR_LDS) : allow_lds(k_row256r<false>, ROWR_LDS)) == hipSuccess) P->rowr = 1;
+    if (tune.rowr && !a.dual && a.p1 == 8 && a.p2 == 8 && allow_lds(k_row256r<false, true>, ROWR_LDS) == hipSuccess) P->rowr = 1;
     // Fused column sweep (k_colx16): the inverse column pass of step s, the step controller and the forward column
     // pass of step s+1 in ONE launch on a register/LDS-resident tile (2 sweeps over HBM per step instead of 3), for
     // dual-polarisation plans with 256 x (8+8) column tiles.  The tiles of a frame meet at a barrier inside the
@@ -2336,6 +2350,13 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         PLX_LAUNCH(k_row4k<true>, dim3((unsigned)N1 * FC), dim3(512), P->rs_lds_pair, st, a);
         return;
     }
+    if (P->rowreg && !a.dual) {                  // scalar plan: every row-polarisation of the workgroup is a row
+        const dim3 g((unsigned)(N1 / (ROWG_THREADS / ((1 << a.p2) / 16))), FC), bs(ROWG_THREADS);
+        if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, false, true>), g, bs, ROWG_LDS(512), st, a);
+        else if (a.p2 == 10) PLX_LAUNCH((k_rowreg<10, false, true>), g, bs, ROWG_LDS(1024), st, a);
+        else PLX_LAUNCH((k_rowreg<11, false, true>), g, bs, ROWG_LDS(2048), st, a);
+        return;
+    }
     if (P->rowreg && a.dual) {
         const unsigned gx = (unsigned)(N1 / ((ROWG_THREADS / ((1 << a.p2) / 16)) / 2));
         const dim3 g(gx, FC), bs(ROWG_THREADS);
@@ -2364,7 +2385,11 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         }
         return;
     }
-    if (P->rowr && !a.force && !a.hmul && !a.umat) {
+    if (P->rowr && !a.dual && !a.force && !a.hmul) {
+        PLX_LAUNCH((k_row256r<false, true>), dim3(64u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
+        return;
+    }
+    if (P->rowr && a.dual && !a.force && !a.hmul && !a.umat) {
         if (a.pmd) PLX_LAUNCH(k_row256r<true>, dim3(128u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
         else PLX_LAUNCH(k_row256r<false>, dim3(128u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
         return;

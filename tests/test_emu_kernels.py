@@ -600,6 +600,42 @@ def test_emu_register_form_rows_512_to_2048(emu, oracle, monkeypatch, logm):
     assert not np.array_equal(got["1"][0], got["0"][0])      # (the switch really selects another kernel)
 
 
+@pytest.mark.parametrize("logm", [9, 11])
+def test_emu_register_form_rows_scalar_plan(emu, oracle, monkeypatch, logm):
+    """k_rowreg<., false, true>: the scalar plan's rows of 512 / 2048 points (every row-polarisation of the workgroup is a row of
+    the one field), two 'sepfields' channels with XPM, 4 x M split (8 x M for 512 points: eight rows to a workgroup) against
+    oracle.scalar_ssfm."""
+    M = 1 << logm
+    p1 = 3 if logm == 9 else 2
+    n, nt, L = (1 << p1) * M, (64 if logm == 9 else 32), 9e2
+    fls = [1, 0, 1, 1]
+    betat, db1 = _tables(n, nt, fls, 1, nfc=2)
+    cols = [_qpsk_field(n, nt, p)[0] for p in (6.0, 8.0)]
+    u = np.asfortranarray(np.stack(cols, 1))
+    gam = [1.3e-6, 1.25e-6]
+    ofd, onc, ou = oracle.scalar_ssfm(u, betat, 4e2, 5e-3, gam, 4.6e-5, L, fls)
+    assert onc >= 3
+    monkeypatch.setenv("PLX_SSFM_P1", str(p1))
+    monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
+    monkeypatch.setenv("PLX_SSFM_LOGW", "6")
+    d = _desc(n, 2, 0, fls, L, 4.6e-5, gam, 4e2, 5e-3, betat, db1, frames=1)
+    plan = C.c_void_p()
+    emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+    for k in ("PLX_SSFM_P1", "PLX_SSFM_COL_THREADS", "PLX_SSFM_LOGW"):
+        monkeypatch.delenv(k)
+    info = (C.c_int32 * 8)()
+    emu.call("plx_ssfm_info", plan, info)
+    assert list(info)[:3] == [0, p1, logm] and info[7] == 2
+    g = _il(np.ascontiguousarray(u.T)[None])                     # [frame][channel][nfft]
+    emu.call("plx_ssfm_propagate_dev", plan, _vp(g), None, 1, None)
+    nc = np.zeros(1, np.int32)
+    emu.call("plx_ssfm_results", plan, 1, None, _vp(nc))
+    emu.call("plx_ssfm_destroy", plan)
+    assert nc[0] == onc
+    got = g.view(np.complex128).reshape(2, n).T
+    assert np.abs(got - ou).max() < 1e-11 * np.abs(ou).max()
+
+
 @pytest.mark.parametrize("logm,tables", [(9, True), (10, True), (10, False), (11, True)])
 def test_emu_register_form_rows_both_polarisations_pmd(emu, oracle, monkeypatch, logm, tables):
     """k_rowreg<., true>: rows of 512 / 1024 / 2048 points of a PMD plan -- lanes i and i + 32 of every wave hold the same thread

@@ -139,6 +139,35 @@ def test_scalar_ssfm_gateway_vs_oracle(lib, oracle, flag, nfc):
         np.testing.assert_allclose(ur + 1j * ui, ref, rtol=1e-11, atol=1e-13)
 
 
+@pytest.mark.parametrize("nsymb,nt,flag,nfc", [(1024, 64, "g-s-", 1), (1024, 64, "g-sx", 2), (1024, 128, "g-sx", 3), (4096, 64, "g-s-", 1),
+                                               (4096, 128, "g-s-", 1)])
+def test_scalar_ssfm_register_form_rows_vs_oracle(lib, oracle, monkeypatch, nsymb, nt, flag, nfc):
+    """scalar_ssfm (fiber.m:557-636) on frames of 2^16 ... 2^19 samples, one field or a 'sepfields' comb with XPM (the row
+    sums of nl_step :795): the row pass of the scalar plan is the register form too (k_row256r<false, true>: four rows to a
+    wave; k_rowreg<., false, true>: every row-polarisation of the workgroup a row).  Against oracle.scalar_ssfm (1e-9, ncycle,
+    first step) and against the LDS-resident k_row (PLX_SSFM_ROWR=0) on the same frame."""
+    c = _fibre_case(nsymb, nt, flag, 4.0, nfc=nfc, scalar=True, length=3e4)
+    ofd, onc, ou = oracle.scalar_ssfm(c["ux"], c["t"]["betat"], c["dzm"], c["dph"], c["t"]["gam"], c["t"]["alphalin"], c["length"], c["fls"])
+    got = []
+    for env in ({}, {"PLX_SSFM_ROWR": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        lib.call("plx_release_all")                    # (the gateway's cached plan was built under the other setting)
+        d = _desc(c)
+        ur, ui = np.asfortranarray(c["ux"].real.copy()), np.asfortranarray(c["ux"].imag.copy())
+        fd, nc = C.c_double(), C.c_int32()
+        lib.call("plx_scalar_ssfm", _vp(ur), _vp(ui), C.byref(d), C.byref(fd), C.byref(nc))
+        for k in env:
+            monkeypatch.delenv(k)
+        assert nc.value == onc and onc > 5 and fd.value == pytest.approx(ofd, rel=1e-12)
+        g = ur + 1j * ui
+        assert np.abs(g - ou).max() <= FIELD_RTOL * np.abs(ou).max()
+        got.append(g)
+    lib.call("plx_release_all")
+    assert np.abs(got[0] - got[1]).max() <= FIELD_RTOL * np.abs(got[1]).max()
+    assert not np.array_equal(got[0], got[1])                                       # (the switch really selects another kernel)
+
+
 def test_register_form_row_pass_with_pmd_vs_oracle_three_ways(lib, oracle, monkeypatch):
     """A 256 x 256 'gps-' frame (10 waveplates) takes the register form of the row pass with the waveplate trunks on traded
     wave halves (k_row256r<PMD>): with the trunk phasor tables (default), with one exponential per bin and trunk
