@@ -1448,6 +1448,18 @@ __device__ __noinline__ void kerr_full_range(int j, int t, double gamleff, int m
     }
 }
 
+// ... and of the scalar form of the sweep: nl_step (:792-804, SPM only) on the lane's column of the parked tile.
+__device__ __noinline__ void kerr_full_range_scalar(int j, int t, double gam, double leff)
+{
+    PLX_DYN_LDS(lds);
+    cplx *s = (cplx *)lds;
+    for (int k = 0; k < 16; k++) {
+        const cplx X = s[((j + 16 * k) << 4) + t];
+        const double pw = X.x * X.x + X.y * X.y;
+        s[((j + 16 * k) << 4) + t] = cmul(X, cexpi(-gam * pw * leff));
+    }
+}
+
 // ----------------------------------------------------------------------------------------------
 // k_colx16: the fused column sweep for the 256 x (8+8) tile with both column transforms held in
 // REGISTERS (16 points per thread, r16_* + lvl2_*256): per tile one LDS exchange per transform instead
@@ -1511,8 +1523,13 @@ __device__ __forceinline__ void emu_lockstep() {}
 #endif
 
 
-__global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf)
+// D = false: the same sweep for SCALAR plans (scalar_ssfm, fiber.m:557-636, without XPM -- its row sums across channels would
+// need the other channels' tiles): a tile is sixteen columns of the one field, lane t its column t; the frame maximum is
+// max |u|^2 (nextstep :694-698 with ~isy), the Kerr step nl_step's u .*= fastexp(-gam |u|^2 leff) (:792-804) on the lane's own
+// sixteen points -- no lane pairs, no swapped halves.
+template <bool D> __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int tiles_pf)
 {
+    constexpr int CW = D ? 8 : 16;         // columns of one polarisation in a tile
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x, t = tid & 15, j = tid >> 4;
@@ -1523,10 +1540,10 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     double *red = (double *)(tw + 128);
     FrameCtl *lctl = (FrameCtl *)(red + 32);
     lds_load_twiddles(tw, a.tw1, 128, tid, 256);
-    cplx *const fld = (t < 8) ? a.ux : a.uy;
+    cplx *const fld = (D && t >= 8) ? a.uy : a.ux;
     const int round = a.round;
-    const int colt = t & 7;
-    const bool isx = t < 8;
+    const int colt = D ? t & 7 : t;
+    const bool isx = !D || t < 8;
     const int lane = tid & 63, row0 = (tid >> 6) * 64;     // this wave stages rows row0 .. row0+63
     // Teams.  The grid is a whole number of TEAMS of tiles_pf workgroups; a team takes a frame at a time, workgroup ti of the
     // team its tile ti (channel c, column block bx: the same every time round).  A team's first frame is slot `team` of the
@@ -1561,7 +1578,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
         // (lane & 15 == t: the lane stages a piece of the same column of the same polarisation it later works on)
         int lq = lane >> 4;
         pin(lq);                           // (addresses are formed where they are used: hoisted out of the tile loop they end up in scratch)
-        const cplx *src = fld + ((size_t)fc << LOGN) + (size_t)bx * 8 + colt + (size_t)(row0 + lq) * N2;
+        const cplx *src = fld + ((size_t)fc << LOGN) + (size_t)bx * CW + colt + (size_t)(row0 + lq) * N2;
         FrameCtl *const rec = lctl + 4 * par + (tid >> 6);
         if (lane == (int)(offsetof(FrameCtl, done) / 16)) rec->done = PLX_REC_SENTINEL;   // (the lane whose piece of the record holds the word)
         lds_settle();                      // (the sentinel is in place before the copy that replaces it can land)
@@ -1580,11 +1597,11 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
     // is the two polarisations of ONE sample -- for k < 8 the X lane's sample k and the Y lane's sample k + 8 -- and the
     // frame maximum and the Kerr step need no per-lane selects (130 v_cndmask per tile before).  Exact: negations only.
     cplx *const twn = (cplx *)(gaml + COLX_NFC);
-    if (tid < 128) { const cplx w = a.tw1[tid]; twn[tid] = make_double2(-w.x, -w.y); }
+    if (D && tid < 128) { const cplx w = a.tw1[tid]; twn[tid] = make_double2(-w.x, -w.y); }
     // (the per-lane table pointer and the LDS distance between the halves of a column, 2048 elements for the lanes that swap
     //  them, are re-derived from t where they are used: held across the tile loop they cost the two registers that spill)
-#define COLX_TWA(tp) (((tp) >= 8) ? (const cplx *)twn : (const cplx *)tw)
-#define COLX_HSW(tp) (((tp) >= 8) ? 2048 : 0)
+#define COLX_TWA(tp) ((D && (tp) >= 8) ? (const cplx *)twn : (const cplx *)tw)
+#define COLX_HSW(tp) ((D && (tp) >= 8) ? 2048 : 0)
     int f = team < nact ? a.active[team] : -1;
     if (f < 0) return;                     // (more teams than frames)
     stage(f, 0);
@@ -1643,7 +1660,7 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
             stage(f, (it & 1) ^ 1);        // (s is free here: every path below ends past its last read of s, and so far
             continue;                      //  each wave has only touched its own rows)
         }
-        const size_t cbase = ((size_t)fc << LOGN) + (size_t)bx * 8 + colt;   // in the caller's arrays
+        const size_t cbase = ((size_t)fc << LOGN) + (size_t)bx * CW + colt;   // in the caller's arrays
         const bool started = wrec->started != 0;
         {
             cplx x[16];
@@ -1677,6 +1694,10 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
 #pragma unroll
         for (int k = 0; k < 16; k++) y[k] = cscale(y[k], sc);
         double m = 0;
+        if (!D) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) m = fmax(fma(y[k].y, y[k].y, y[k].x * y[k].x), m);
+        } else
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             // |ux|^2 + |uy|^2 of ONE sample: this lane's y[k] and the partner lane's y[k + 8] (lane t ^ 8).  The X lane forms
@@ -1762,14 +1783,36 @@ __global__ __launch_bounds__(256, 2) void k_colx16(SsfmArgs a, int tiles_x, int 
                 int tq = t, jq = j;        // (opaque here: the sixteen row offsets of this once-per-frame store are not loop invariants
                 pin(tq);                   //  worth thirty-two registers of the tile loop)
                 pin(jq);
-                const int rsw = tq >= 8 ? 128 : 0;         // (the second polarisation's lanes hold the halves swapped)
+                const int rsw = (D && tq >= 8) ? 128 : 0;  // (the second polarisation's lanes hold the halves swapped)
 #pragma unroll
                 for (int k = 0; k < 8; k++) fld[cbase + (size_t)(jq + 16 * k + rsw) * N2] = y[k];
 #pragma unroll
                 for (int k = 8; k < 16; k++) fld[cbase + (size_t)(jq + 16 * k - rsw) * N2] = y[k];
             }
         } else {
-            if (a.spm) {                   // Kerr step of step s+1 (:832-852) on registers
+            if (!D) {
+                if (a.spm) {               // nl_step (:792-804, SPM only) on the lane's own sixteen points
+                    const double gam = gaml[c];
+                    if (fabs(gam * leff) * red[18] < 0.0625) {
+#pragma unroll
+                        for (int k = 0; k < 16; k++) {
+                            const double pw = y[k].x * y[k].x + y[k].y * y[k].y;
+                            double sn, cs;
+                            sincos_taylor(-gam * pw * leff, &sn, &cs);
+                            y[k] = cmul(y[k], make_double2(cs, sn));
+                        }
+                    } else {               // ('--s-': the exact single step, radians of phase) through the exchange buffer
+#pragma unroll
+                        for (int k = 0; k < 16; k++) s[((j + 16 * k) << 4) + t] = y[k];
+                        lds_barrier();
+                        kerr_full_range_scalar(j, t, gam, leff);
+                        lds_barrier();
+#pragma unroll
+                        for (int k = 0; k < 16; k++) y[k] = s[((j + 16 * k) << 4) + t];
+                        lds_barrier();
+                    }
+                }
+            } else if (a.spm) {            // Kerr step of step s+1 (:832-852) on registers
                 const double gamleff = gaml[c] * leff;
                 // |gamleff*P| <= gamleff * (tile maximum): a few mrad under the step controller, so the
                 // Taylor form applies to the whole tile; otherwise ('--s-' exact single step) the rare
@@ -2204,7 +2247,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
     P->col_threads = P->lds_col > 80 * 1024 ? 1024 : 512;   // measured: 512-thread column workgroups (2 per CU, 16 waves) beat
                                                             // 256 by 3-12 %; tall tiles of large frames: one workgroup per CU, 16 waves
     if (tune.col_threads == 128 || tune.col_threads == 256 || tune.col_threads == 512 || tune.col_threads == 1024) P->col_threads = tune.col_threads;
-    if (allow_lds(k_colx16, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
+    if (allow_lds(k_colx16<true>, P->lds_col) != hipSuccess || allow_lds(k_colx16<false>, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
         allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
         (!P->tw_compact && allow_lds(k_row, P->lds_row > P->rs_lds ? P->lds_row : P->rs_lds) != hipSuccess) ||
         (P->tw_compact && (allow_lds(k_row4k<false>, P->rs_lds) != hipSuccess || allow_lds(k_row4k<true>, P->rs_lds_pair) != hipSuccess))) {
@@ -2220,7 +2263,9 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
     // launch, so all of them must be resident together: the grid is sized from the runtime's own occupancy answer
     // for this kernel (block size and dynamic LDS as launched), a multiple of the tiles per frame; a plan whose
     // frame does not fit the chip that way takes the barrier-free three-sweep step.
-    if (a.dual && !tune.no_fuse && a.p1 == 8 && a.W == 8 && nfc <= COLX_NFC) {
+    // (scalar plans: the same sweep on sixteen columns of the one field -- not with XPM, whose Kerr step needs the other
+    //  channels' powers at the same sample, i.e. other workgroups' tiles)
+    if (((a.dual && a.W == 8) || (!a.dual && a.W == 16 && !desc->fls[3])) && !tune.no_fuse && a.p1 == 8 && nfc <= COLX_NFC) {
         int ncu = 256;
         {
             int dev = 0, v = 0;
@@ -2228,7 +2273,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
                 ncu = v;
         }
         const int tiles_pf = nfc * (N2 / a.W);
-        const int per_cu = blocks_per_cu(k_colx16, 256, P->lds_col);
+        const int per_cu = a.dual ? blocks_per_cu(k_colx16<true>, 256, P->lds_col) : blocks_per_cu(k_colx16<false>, 256, P->lds_col);
         const int cap = ncu * per_cu;
         if (tiles_pf <= cap) {
             P->fused = 1;
@@ -2492,7 +2537,8 @@ static int propagate_frames(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int nframes, hi
 #endif
                 a.round = steps + sidx;
                 PLX_MARK(0, steps + sidx);
-                PLX_LAUNCH(k_colx16, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
+                if (a.dual) PLX_LAUNCH(k_colx16<true>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
+                else PLX_LAUNCH(k_colx16<false>, gx, blk, P->lds_col, st, a, tcx, P->tiles_pf);
 #ifdef PLX_EMU
                 emu::g_concurrency = 1;
 #endif

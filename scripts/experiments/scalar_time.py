@@ -35,5 +35,10 @@ T = min(ts[1:]); ss = steps.value
 print("scalar N=2^%d x %d frames '%s': %.2f ms, %.1f steps/frame, info %s" % (int(math.log2(n)), F, flag, T * 1e3, ss / n / F, list(info)))
 per = [(ms[i] / max(k[i], 1) * 1e3) for i in range(4)]
 act = F * n * 32.0   # bytes per sweep (16 read + 16 written per sample)
-print("  kernels us: col_fwd %.1f (%.3f of 8 TB/s)  row %.1f (%.3f)  col_inv %.1f (%.3f)  control %.1f; step group (96 B per sample-step) %.3f" % (
-      per[0], act / per[0] / 8e6, per[1], act / per[1] / 8e6, per[2], act / per[2] / 8e6, per[3], 96.0 * ss / T / 8e12))
+fr = lambda us: act / us / 8e6 if us > 0 else 0.0
+if info[0]:
+    print("  fused: k_colx16<false> %.1f us (%.3f of 8 TB/s)  row %.1f (%.3f)  control %.1f; step group (64 B per sample-step) %.3f" % (
+          per[0], fr(per[0]), per[1], fr(per[1]), per[3], 64.0 * ss / T / 8e12))
+else:
+    print("  kernels us: col_fwd %.1f (%.3f of 8 TB/s)  row %.1f (%.3f)  col_inv %.1f (%.3f)  control %.1f; step group (96 B per sample-step) %.3f" % (
+          per[0], fr(per[0]), per[1], fr(per[1]), per[2], fr(per[2]), per[3], 96.0 * ss / T / 8e12))

@@ -446,6 +446,47 @@ def test_emu_fused_sweep_exact_nonlinear_step(emu, oracle, monkeypatch):
         assert np.abs(gy[f] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
 
 
+@pytest.mark.parametrize("flag", ["g-s-", "--s-"])
+def test_emu_fused_sweep_scalar_plan(emu, oracle, monkeypatch, flag):
+    """k_colx16<false>: scalar_ssfm (fiber.m:557-636) without XPM on the fused column sweep -- sixteen columns of the one field
+    to a tile, max |u|^2 at the frame barrier, nl_step on the lane's own points; two 'sepfields' channels, three frames at
+    different powers claimed by the teams of a one-CU device.  'g-s-': against oracle.scalar_ssfm and the three-sweep step;
+    '--s-': the exact single step (radians of phase: the full-range path through the exchange buffer)."""
+    n, nt, nfc = 4096, 64, 2
+    fls = [1, 0, 1, 0] if flag == "g-s-" else [0, 0, 1, 0]
+    L = 1.2e3 if flag == "g-s-" else 2e4
+    gam = [1.3e-6, 1.2e-6] if flag == "g-s-" else [1.3e-3, 1.1e-3]
+    dzmax, dph = (4e2, 5e-3) if flag == "g-s-" else (L, np.inf)
+    betat, db1 = _tables(n, nt, fls, 1, nfc)
+    frames = [np.asfortranarray(np.stack([_qpsk_field(n, nt, p * (1 + 0.3 * k), (2 + k, 5 + k))[0] for k in range(nfc)], 1)) for p in (6.0, 9.0, 14.0)]
+    ref = [oracle.scalar_ssfm(u, betat, dzmax, dph, gam, 4.6e-5, L, fls) for u in frames]
+    got = []
+    for env in ({"PLX_EMU_CUS": "1"}, {"PLX_SSFM_NO_FUSE": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = _desc(n, nfc, 0, fls, L, 4.6e-5, gam, dzmax, dph, betat, db1, frames=3)
+        plan = C.c_void_p()
+        emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+        for k in env:
+            monkeypatch.delenv(k)
+        info = (C.c_int32 * 8)()
+        emu.call("plx_ssfm_info", plan, info)
+        assert info[0] == (0 if "PLX_SSFM_NO_FUSE" in env else 1) and info[1] == 8 and info[4] == (0 if "PLX_SSFM_NO_FUSE" in env else nfc)
+        g = _il(np.stack([np.ascontiguousarray(u.T) for u in frames]))          # [frame][channel][nfft]
+        emu.call("plx_ssfm_propagate_dev", plan, _vp(g), None, 3, None)
+        nc = np.zeros(3, np.int32)
+        emu.call("plx_ssfm_results", plan, 3, None, _vp(nc))
+        emu.call("plx_ssfm_destroy", plan)
+        got.append((g.view(np.complex128).reshape(3, nfc, n).copy(), nc.copy()))
+    for f in range(3):
+        ofd, onc, ou = ref[f]
+        for gg, nc in got:
+            assert nc[f] == onc and (onc >= 3 if flag == "g-s-" else onc == 1)
+            assert np.abs(gg[f].T - ou).max() < 1e-11 * np.abs(ou).max()
+    if flag == "--s-":
+        assert np.abs(np.angle(got[0][0][2][0] * np.conj(frames[2][:, 0]))).max() > 0.5      # radians of nonlinear phase
+
+
 def test_emu_long_rows_compact_twiddles(emu, oracle, monkeypatch):
     """4096-point rows (the row pass of 2^20-sample frames: one polarisation per workgroup, compact twiddle table W^{4k} +
     four fine factors, plx_fft.h row_tw) on a 4 x 4096 split of a 2^14 frame: field and step count against the oracle."""
