@@ -1097,11 +1097,13 @@ template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2
     // (row fastest, then frame-channel, then polarisation).
     // (PAIR: k = the frame-channel, both polarisations in the workgroup)
     const int K = (int)(gridDim.x >> a.p1), lg = a.p1 < 3 ? a.p1 : 3, G = 1 << lg;     // (G = 8 rows to a group; fewer rows: all of them)
+    // (a scalar plan -- no second field -- launches one workgroup per row and frame-channel as well)
+    const bool unit_fc = PAIR || a.uy == nullptr;
     int brow, by, bpol;
-    if (K >= (PAIR ? 16 : 32)) {
+    if (K >= (unit_fc ? 16 : 32)) {
         const int g8 = (int)blockIdx.x / (G * K), rem = (int)blockIdx.x - g8 * G * K, bk2 = rem >> lg;
-        brow = g8 * G + (rem & (G - 1)); by = PAIR ? bk2 : bk2 >> 1; bpol = bk2 & 1;
-    } else if (PAIR) {
+        brow = g8 * G + (rem & (G - 1)); by = unit_fc ? bk2 : bk2 >> 1; bpol = unit_fc ? 0 : bk2 & 1;
+    } else if (unit_fc) {
         const int N1 = 1 << a.p1;
         brow = (int)blockIdx.x & (N1 - 1); by = (int)blockIdx.x >> a.p1; bpol = 0;
     } else {
@@ -2088,7 +2090,8 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
         // without PMD -- keep the 256-row column tile and take 4096-point rows instead (k_row4k, compact twiddle table: one
         // polarisation per row workgroup and two workgroups per CU, or with PMD both polarisations in one workgroup of twice
         // the size); everything else stops at 2048-point rows and gets taller column tiles
-        const bool long_rows = desc->dual_pol && !tune.no_row_split && !tune.short_rows;
+        // (scalar plans take the same split: k_row4k on the rows of the one field)
+        const bool long_rows = !tune.no_row_split && !tune.short_rows;
         const int p2max = long_rows ? 12 : 11;
         if (p - p1 > p2max) p1 = p - p2max;                  // large frames: taller tiles instead
         if (p1 > p - 4) p1 = p - 4;                          // keep N2 >= 16
@@ -2129,9 +2132,10 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
         P->rs_threads = N2 / 8 < ROW_THREADS ? ROW_THREADS : (N2 / 8 > 1024 ? 1024 : N2 / 8);
         P->rs_lds = ((size_t)(N2 + N2 / 16) + (P->tw_compact ? N2 / 8 + 4 + 16 + 160 + PLX_CTAB : N2 / 2)) * sizeof(cplx);   // (+16: k_row4k's bk, +160: its padded W_256 table, + the unit-circle table)
     }
-    if (P->tw_compact && !P->row_split) {
+    if (P->tw_compact && !a.dual && !tune.no_row_split) P->rs_lds = ((size_t)(N2 + N2 / 16) + N2 / 8 + 4 + 16 + 160 + PLX_CTAB) * sizeof(cplx);
+    if (P->tw_compact && !P->row_split && a.dual) {
         free_plan(P);
-        PLX_FAIL(PLX_ERR_UNSUPPORTED, "plx_ssfm_create: 4096-point rows need a dual-polarisation plan");
+        PLX_FAIL(PLX_ERR_UNSUPPORTED, "plx_ssfm_create: 4096-point rows need the one-polarisation row pass (PLX_SSFM_NO_ROW_SPLIT is set)");
     }
     if (P->tw_compact) {
         P->row_pair4k = desc->fls[1] ? 1 : 0;
@@ -2391,6 +2395,10 @@ extern "C" int plx_ssfm_set_birefringence_dev(plx_ssfm *P, const double *db0, co
 static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t st)
 {
     const int N1 = 1 << a.p1;
+    if (P->tw_compact && !a.dual) {              // scalar plan, 4096-point rows: one workgroup per row and frame-channel
+        PLX_LAUNCH(k_row4k<false>, dim3((unsigned)N1 * FC), dim3(256), P->rs_lds, st, a);
+        return;
+    }
     if (P->tw_compact && a.dual && (a.pmd || a.umat)) {      // the multiplier couples the polarisations: both rows in one workgroup
         PLX_LAUNCH(k_row4k<true>, dim3((unsigned)N1 * FC), dim3(512), P->rs_lds_pair, st, a);
         return;
@@ -2683,7 +2691,7 @@ extern "C" int plx_ssfm_info(plx_ssfm *P, int32_t *info)
 {
     if (!P || !info) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_info: null argument");
     info[0] = P->fused; info[1] = P->p1; info[2] = P->p2; info[3] = P->fused_grid; info[4] = P->tiles_pf;
-    info[5] = P->col_threads; info[6] = P->rowr ? ROWR_THREADS : P->rowreg ? ROWG_THREADS : (P->tw_compact ? (P->row_pair4k ? 512 : 256) : (P->row_split ? P->rs_threads : P->row_threads)); info[7] = P->rowreg ? 2 : (P->row_pair4k ? 0 : P->row_split);
+    info[5] = P->col_threads; info[6] = P->rowr ? ROWR_THREADS : P->rowreg ? ROWG_THREADS : (P->tw_compact ? (P->row_pair4k ? 512 : 256) : (P->row_split ? P->rs_threads : P->row_threads)); info[7] = P->rowreg ? 2 : (P->row_pair4k ? 0 : ((P->tw_compact && !P->a.dual) ? 1 : P->row_split));
     return PLX_OK;
 }
 

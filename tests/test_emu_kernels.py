@@ -641,14 +641,14 @@ def test_emu_register_form_rows_512_to_2048(emu, oracle, monkeypatch, logm):
     assert not np.array_equal(got["1"][0], got["0"][0])      # (the switch really selects another kernel)
 
 
-@pytest.mark.parametrize("logm", [9, 11])
+@pytest.mark.parametrize("logm", [9, 11, 12])
 def test_emu_register_form_rows_scalar_plan(emu, oracle, monkeypatch, logm):
     """k_rowreg<., false, true>: the scalar plan's rows of 512 / 2048 points (every row-polarisation of the workgroup is a row of
     the one field), two 'sepfields' channels with XPM, 4 x M split (8 x M for 512 points: eight rows to a workgroup) against
-    oracle.scalar_ssfm."""
+    oracle.scalar_ssfm.  4096 points: k_row4k<false> with one workgroup per row and frame-channel."""
     M = 1 << logm
     p1 = 3 if logm == 9 else 2
-    n, nt, L = (1 << p1) * M, (64 if logm == 9 else 32), 9e2
+    n, nt, L = (1 << p1) * M, (32 if logm == 11 else 64), 9e2
     fls = [1, 0, 1, 1]
     betat, db1 = _tables(n, nt, fls, 1, nfc=2)
     cols = [_qpsk_field(n, nt, p)[0] for p in (6.0, 8.0)]
@@ -666,7 +666,7 @@ def test_emu_register_form_rows_scalar_plan(emu, oracle, monkeypatch, logm):
         monkeypatch.delenv(k)
     info = (C.c_int32 * 8)()
     emu.call("plx_ssfm_info", plan, info)
-    assert list(info)[:3] == [0, p1, logm] and info[7] == 2
+    assert list(info)[:3] == [0, p1, logm] and info[7] == (2 if logm < 12 else 1)
     g = _il(np.ascontiguousarray(u.T)[None])                     # [frame][channel][nfft]
     emu.call("plx_ssfm_propagate_dev", plan, _vp(g), None, 1, None)
     nc = np.zeros(1, np.int32)
