@@ -146,11 +146,13 @@ def test_scalar_ssfm_register_form_rows_vs_oracle(lib, oracle, monkeypatch, nsym
     sums of nl_step :795): the row pass of the scalar plan is the register form too (k_row256r<false, true>: four rows to a
     wave; k_rowreg<., false, true>: every row-polarisation of the workgroup a row; 2^20 samples: the 256 x 4096 split with
     k_row4k, against the 512 x 2048 split of PLX_SSFM_SHORT_ROWS=1).  Against oracle.scalar_ssfm (1e-9, ncycle, first step) and
-    against the LDS-resident k_row (PLX_SSFM_ROWR=0) on the same frame."""
+    against the round-1 structure (three sweeps, the LDS-resident k_row, k_rowsum for XPM: PLX_SSFM_NO_FUSE=1, PLX_SSFM_ROWR=0)
+    on the same frame.  The default takes the fused sweep k_colx16<false>; the XPM combs keep k_rowsum and three sweeps, with the
+    register-form rows."""
     c = _fibre_case(nsymb, nt, flag, 4.0, nfc=nfc, scalar=True, length=3e4)
     ofd, onc, ou = oracle.scalar_ssfm(c["ux"], c["t"]["betat"], c["dzm"], c["dph"], c["t"]["gam"], c["t"]["alphalin"], c["length"], c["fls"])
     got = []
-    for env in ({}, {"PLX_SSFM_ROWR": "0", "PLX_SSFM_SHORT_ROWS": "1"}):
+    for env in ({}, {"PLX_SSFM_ROWR": "0", "PLX_SSFM_SHORT_ROWS": "1", "PLX_SSFM_NO_FUSE": "1"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         lib.call("plx_release_all")                    # (the gateway's cached plan was built under the other setting)
