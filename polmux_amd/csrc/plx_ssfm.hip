@@ -1229,9 +1229,13 @@ template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2
 #define ROWG_THREADS 256
 #define ROWG_NTW(M) ((M) <= 1024 ? (M) / 2 : (M) / 8 + 4)
 // SC (scalar plans: scalar_ssfm, and the electrical filter of the front end): every row-polarisation is a row of the one field.
-template <int LOGM, bool PAIR, bool SC = false> __global__ __launch_bounds__(ROWG_THREADS, 2) void k_rowreg(SsfmArgs a)
+// SPLIT (rows of 512 / 1024 points, whose row-polarisations are lanes of one wave): the exchanges go through LDS in two halves,
+// real parts then imaginary parts, so a row-polarisation's padded row is 8.5 KiB instead of 17 and THREE workgroups share a CU
+// (twelve waves instead of eight: the kernel then has to fit 168 registers).
+template <int LOGM, bool PAIR, bool SC = false, bool SPLIT = false> __global__ __launch_bounds__(ROWG_THREADS, SPLIT ? 3 : 2) void k_rowreg(SsfmArgs a)
 {
     static_assert(!(PAIR && SC), "a scalar plan has no second polarisation to pair with");
+    static_assert(!SPLIT || (!PAIR && LOGM <= 10), "the split exchange is wave-local");
     // (twiddles of the outer level: the half table W_M^k where it fits beside two workgroups' rows -- 512 and 1024 points: 4 / 8
     //  KiB -- and the compact table, one more complex product per twiddle, for 2048 points)
     constexpr bool HALF_TW = LOGM <= 10;
@@ -1255,7 +1259,8 @@ template <int LOGM, bool PAIR, bool SC = false> __global__ __launch_bounds__(ROW
     constexpr int ROWS = SC ? RP : RP / 2;               // rows per workgroup
     constexpr bool WAVE_LOCAL = PAIR ? S <= 32 : S <= 64;    // a row-polarisation's threads are lanes of one wave
     cplx *const s = (cplx *)lds + rp * PITCH;            // this row-polarisation's padded row: physical(p) = p + (p >> 4)
-    cplx *const tw = (cplx *)lds + RP * PITCH;           // compact W_M
+    double *const sd = (double *)lds + rp * PITCH;       // SPLIT: the same row, one component at a time
+    cplx *const tw = SPLIT ? (cplx *)((double *)lds + RP * PITCH) : (cplx *)lds + RP * PITCH;           // W_M (half or compact table)
     cplx *const tm = tw + NTW;                           // [7][16]: the middle level's twiddles, lane-fastest
     cplx *const ct = tm + 7 * 16;                        // the unit circle in 64 steps (cexp_neg_turns_tab)
     cplx *const bk = ct + PLX_CTAB + 17 * rl;            // tpass[row][S k], k < 16 (the rows' entries on different banks)
@@ -1266,6 +1271,28 @@ template <int LOGM, bool PAIR, bool SC = false> __global__ __launch_bounds__(ROW
     typename std::conditional<HALF_TW, TwHalf<M>, TwCompact<M>>::type wm{tw};
     const int b = t >> 4, j2 = t & 15;                   // middle level: chunk b of 256 points, point j2 + 16 kk of it
     cplx x[16];
+    // SPLIT: one exchange in two halves -- x[k] goes to slot wi(k), the thread's next sixteen values come from slot ri(k)
+    auto exchange_split = [&](auto wi, auto ri) {
+        // (the real parts travel first and land in x[k].x while x[k].y still holds the OLD imaginary parts: no spare registers)
+#pragma unroll
+        for (int k = 0; k < 16; k++) sd[wi(k)] = x[k].x;
+        ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k].x = sd[ri(k)];
+        ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) sd[wi(k)] = x[k].y;
+        ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k].y = sd[ri(k)];
+        ROWR_SYNC();
+    };
+    // (the padded slots in closed form -- S and 256 are multiples of 16, j2 < 16 -- so that every access is ONE base register + an
+    //  immediate: row_phys(t + S k) = t + (t >> 4) + (S + S / 16) k, row_phys(256 b + j2 + 16 k) = 272 b + j2 + 17 k)
+    const int obase = t + (t >> 4), cbase = 272 * b + j2, tbase = 17 * t;
+    const auto outer = [&](int k) { return obase + (S + S / 16) * k; };
+    const auto chunk = [&](int k) { return cbase + 17 * k; };
+    const auto own16 = [&](int k) { return tbase + k; };                     // row_phys(16 t + k)
     {
         const cplx ta = tp[t];
 #pragma unroll
@@ -1279,18 +1306,24 @@ template <int LOGM, bool PAIR, bool SC = false> __global__ __launch_bounds__(ROW
         for (int k = 0; k < 16; k++) x[k] = cmul(x[k], cmul(ta, bk[k]));
     }
     lvl2_dif<S>(x, t, wm);
+    if (SPLIT) exchange_split(outer, chunk);
+    else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) s[row_phys(t + S * k)] = x[k];
-    if (!WAVE_LOCAL) __syncthreads(); else ROWR_SYNC();
+        for (int k = 0; k < 16; k++) s[row_phys(t + S * k)] = x[k];
+        if (!WAVE_LOCAL) __syncthreads(); else ROWR_SYNC();
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+        for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+    }
     cplx wl[7];
 #pragma unroll
     for (int q = 0; q < (R == 8 ? 7 : (R == 4 ? 3 : 1)); q++) wl[q] = tm[16 * q + j2];     // (the plan lists this R's twiddles first)
     lvlmid_dif<R>(x, wl);                                // (written back where this thread read it: no barrier in between)
+    if (SPLIT) exchange_split(chunk, own16);
+    else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
-    ROWR_SYNC();                                         // (a chunk's sixteen threads are lanes of one wave)
+        for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
+        ROWR_SYNC();                                     // (a chunk's sixteen threads are lanes of one wave)
+    }
     // SHARE (512-point rows: a wave = the two polarisations of one row, as in k_row256r): the multiplier is the same for the two
     // polarisations of a bin, which sit in lanes i and i + 32 -- the lower half of the wave forms it for the thread's bins 0-7,
     // the upper half for bins 8-15, and they swap (half_share).  (For 1024-point rows the same sharing needs the PAIR dealing of
@@ -1304,8 +1337,10 @@ template <int LOGM, bool PAIR, bool SC = false> __global__ __launch_bounds__(ROW
 #pragma unroll
         for (int k = 0; k < (HALF_BINS ? 8 : 16); k++) btv[k] = bt[k];
     }
+    if (!SPLIT) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = s[17 * t + k];               // row_phys(16 t + k)
+        for (int k = 0; k < 16; k++) x[k] = s[17 * t + k];           // row_phys(16 t + k)
+    }
     r16_dif(x);
     if (PAIR && !a.hmul) {
         pair_multiplier<LOGM>(a, x, btv, ct, ctl, f, c, (int)blockIdx.x * ROWS + rl, rowbase, ib);
@@ -1332,11 +1367,14 @@ template <int LOGM, bool PAIR, bool SC = false> __global__ __launch_bounds__(ROW
         }
     }
     r16_dit(x);
+    if (SPLIT) exchange_split(own16, chunk);
+    else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) s[17 * t + k] = x[k];
-    ROWR_SYNC();
+        for (int k = 0; k < 16; k++) s[17 * t + k] = x[k];
+        ROWR_SYNC();
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+        for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+    }
     {
         // (the lane's twiddles are fetched again rather than held across the multiplier: up to 28 registers)
         int jq = j2;
@@ -1345,19 +1383,30 @@ template <int LOGM, bool PAIR, bool SC = false> __global__ __launch_bounds__(ROW
         for (int q = 0; q < (R == 8 ? 7 : (R == 4 ? 3 : 1)); q++) wl[q] = tm[16 * q + jq];
     }
     lvlmid_dit<R>(x, wl);
+    if (!SPLIT) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
-    if (!WAVE_LOCAL) __syncthreads(); else ROWR_SYNC();
+        for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
+        if (!WAVE_LOCAL) __syncthreads(); else ROWR_SYNC();
+    }
     int jo = t;
     pin(jo);
-    const cplx tb = tp[jo];                              // (asked for ahead of the last register level)
+    // (SPLIT: the row's two pointers are formed again here instead of being held -- or spilled -- since the top of the kernel)
+    int rq = rl, pq = pol, fq = fc;
+    if (SPLIT) { pin(rq); pin(pq); pin(fq); }
+    const size_t rowbase2 = SPLIT ? ((size_t)blockIdx.x * ROWS + rq) << LOGM : rowbase;
+    cplx *const u2 = SPLIT ? (pq ? a.uy : a.ux) + ((size_t)fq << (LOGM + a.p1)) + rowbase2 : u;
+    const cplx tb = (SPLIT ? a.tpass + rowbase2 : tp)[jo];                              // (asked for ahead of the last register level)
+    if (SPLIT) exchange_split(chunk, outer);
+    else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = s[row_phys(t + S * k)];
-    lvl2_dit<S>(x, PAIR ? jo : t, wm);                   // (PAIR, jo: the lane's three second-stage twiddles are formed again, not held across the trunk loop)
+        for (int k = 0; k < 16; k++) x[k] = s[row_phys(t + S * k)];
+    }
+    lvl2_dit<S>(x, (PAIR || SPLIT) ? jo : t, wm);                   // (PAIR, jo: the lane's three second-stage twiddles are formed again, not held across the trunk loop)
 #pragma unroll
-    for (int k = 0; k < 16; k++) u[jo + S * k] = cmulc(x[k], cmul(tb, bk[k]));
+    for (int k = 0; k < 16; k++) u2[jo + S * k] = cmulc(x[k], cmul(tb, bk[k]));
 }
 #define ROWG_LDS(M) ((size_t)((ROWG_THREADS / ((M) / 16)) * ((M) + (M) / 16) + ROWG_NTW(M) + 7 * 16 + PLX_CTAB + 17 * (ROWG_THREADS / ((M) / 16))) * sizeof(cplx))
+#define ROWG_LDS_SPLIT(M) (ROWG_LDS(M) - (size_t)((ROWG_THREADS / ((M) / 16)) * ((M) + (M) / 16)) * sizeof(double))
 
 // ------------------------------------------------------ pass 3: inverse columns ---
 // Completes ifft (1/N), applies the attenuation of the step (:531-532) and feeds
@@ -1948,6 +1997,7 @@ struct plx_ssfm {
     int col_threads = 512;         // workgroup size of k_col_fwd / k_col_inv
     int row_threads = ROW_THREADS; // workgroup size of k_row
     int rowr = 0;                  // k_row256r serves the step's row pass
+    int rowg_split = 0;            // ... with the exchanges split into real and imaginary halves (three workgroups per CU)
     int rowreg = 0;                // k_rowreg<p2> serves it (dual polarisation, no PMD, rows of 512 / 1024 / 2048 points)
     cplx *d_tw2c = nullptr, *d_twmid = nullptr;
     int row_split = 0, rs_threads = 0; // long rows without PMD: one polarisation per workgroup (scalar row pass twice)
@@ -2031,7 +2081,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // not adopted (working copy, frame groups, grid sizing: profiles/r03_notes.md) are gone with their code.
 namespace {
 struct Tune {
-    int short_rows = 0, no_fuse = 0, p1 = -1, logW = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, no_pmd_tab = 0, rowr = 0, store_late = -1, row_rev = 0;
+    int short_rows = 0, no_fuse = 0, p1 = -1, logW = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, no_pmd_tab = 0, rowr = 0, store_late = -1, row_rev = 0, rowg_split = 1;
     double barrier_timeout_ms = 500.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -2045,6 +2095,7 @@ struct Tune {
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
         store_late = geti("PLX_SSFM_STORE_LATE", -1);  // fused sweep: stores after the next tile's landing; -1: where a launch has more than one team
         row_rev = geti("PLX_SSFM_ROW_REV", 1);         // 0: the row pass takes the listed frames in ascending order as well (A/B)
+        rowg_split = geti("PLX_SSFM_ROWG_SPLIT", 1);   // 0: k_rowreg's whole-sample exchanges also for rows of 512 / 1024 points (A/B, tests)
         rowr = geti("PLX_SSFM_ROWR", 1);               // 0: the LDS-resident k_row also where the register form k_row256r applies (A/B, tests)
         no_pmd_tab = geti("PLX_SSFM_NO_PMD_TAB", 0);   // PMD plans: one exponential per bin and trunk instead of the phasor tables (A/B, tests)
         if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
@@ -2230,6 +2281,13 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
         if (e == hipSuccess) e = P->p2 == 9 ? allow_lds(k_rowreg<9, true>, ROWG_LDS(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10, true>, ROWG_LDS(1024)) : allow_lds(k_rowreg<11, true>, ROWG_LDS(2048));
         if (e == hipSuccess) e = P->p2 == 9 ? allow_lds(k_rowreg<9, false, true>, ROWG_LDS(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10, false, true>, ROWG_LDS(1024)) : allow_lds(k_rowreg<11, false, true>, ROWG_LDS(2048));
         if (e == hipSuccess) P->rowreg = 1;
+        // rows of 512 / 1024 points without PMD: the exchanges in real / imaginary halves, three workgroups per CU
+        // (PLX_SSFM_ROWG_SPLIT=0: the whole-sample exchange, A/B and tests)
+        if (P->rowreg && P->p2 <= 10 && tune.rowg_split) {
+            const hipError_t e2 = a.dual ? (P->p2 == 9 ? allow_lds(k_rowreg<9, false, false, true>, ROWG_LDS_SPLIT(512)) : allow_lds(k_rowreg<10, false, false, true>, ROWG_LDS_SPLIT(1024)))
+                                         : (P->p2 == 9 ? allow_lds(k_rowreg<9, false, true, true>, ROWG_LDS_SPLIT(512)) : allow_lds(k_rowreg<10, false, true, true>, ROWG_LDS_SPLIT(1024)));
+            if (e2 == hipSuccess) P->rowg_split = 1;
+        }
     }
     UP(P->d_gam, gam, double);
 #undef UP
@@ -2405,7 +2463,9 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
     }
     if (P->rowreg && !a.dual) {                  // scalar plan: every row-polarisation of the workgroup is a row
         const dim3 g((unsigned)(N1 / (ROWG_THREADS / ((1 << a.p2) / 16))), FC), bs(ROWG_THREADS);
-        if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, false, true>), g, bs, ROWG_LDS(512), st, a);
+        if (P->rowg_split && a.p2 == 9) PLX_LAUNCH((k_rowreg<9, false, true, true>), g, bs, ROWG_LDS_SPLIT(512), st, a);
+        else if (P->rowg_split && a.p2 == 10) PLX_LAUNCH((k_rowreg<10, false, true, true>), g, bs, ROWG_LDS_SPLIT(1024), st, a);
+        else if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, false, true>), g, bs, ROWG_LDS(512), st, a);
         else if (a.p2 == 10) PLX_LAUNCH((k_rowreg<10, false, true>), g, bs, ROWG_LDS(1024), st, a);
         else PLX_LAUNCH((k_rowreg<11, false, true>), g, bs, ROWG_LDS(2048), st, a);
         return;
@@ -2417,6 +2477,9 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
             if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, true>), g, bs, ROWG_LDS(512), st, a);
             else if (a.p2 == 10) PLX_LAUNCH((k_rowreg<10, true>), g, bs, ROWG_LDS(1024), st, a);
             else PLX_LAUNCH((k_rowreg<11, true>), g, bs, ROWG_LDS(2048), st, a);
+        } else if (P->rowg_split && a.p2 <= 10) {
+            if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, false, false, true>), g, bs, ROWG_LDS_SPLIT(512), st, a);
+            else PLX_LAUNCH((k_rowreg<10, false, false, true>), g, bs, ROWG_LDS_SPLIT(1024), st, a);
         } else {
             if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, false>), g, bs, ROWG_LDS(512), st, a);
             else if (a.p2 == 10) PLX_LAUNCH((k_rowreg<10, false>), g, bs, ROWG_LDS(1024), st, a);

@@ -665,7 +665,7 @@ def test_frames_of_2pow17_to_2pow19_register_form_rows_vs_oracle(lib, oracle, mo
     from polmux_amd import pipeline
     scale = np.array([0.5, 1.0, 2.0])
     out = []
-    for env in ({}, {"PLX_SSFM_ROWR": "0"}):
+    for env in ({}, {"PLX_SSFM_ROWR": "0"}, {"PLX_SSFM_ROWG_SPLIT": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         cfg = pipeline.HotPathConfig(nsymb=nsymb, nt=nt, length=4e4)
@@ -674,8 +674,8 @@ def test_frames_of_2pow17_to_2pow19_register_form_rows_vs_oracle(lib, oracle, mo
             monkeypatch.delenv(k)
         info = hp.info()
         p2 = (nsymb * nt).bit_length() - 1 - 8
-        assert list(info[:3]) == [1, 8, p2] and (info[7] == 2) == (not env)
-        assert hp.row_kernel() == ("k_rowreg" if not env else "k_row")
+        assert list(info[:3]) == [1, 8, p2] and (info[7] == 2) == ("PLX_SSFM_ROWR" not in env)
+        assert hp.row_kernel() == ("k_rowreg" if "PLX_SSFM_ROWR" not in env else "k_row")
         ux, uy = hp.make_batch(3, scale)
         hp.fibre(ux, uy)
         _sync()
@@ -691,10 +691,12 @@ def test_frames_of_2pow17_to_2pow19_register_form_rows_vs_oracle(lib, oracle, mo
         hp.close()
         del ux, uy
         torch.cuda.empty_cache()
-    (nc0, x0, y0), (nc1, x1, y1) = out
-    assert nc0.tolist() == nc1.tolist() and nc0[2] > nc0[1] > nc0[0]
-    for a, b in ((x0, x1), (y0, y1)):
-        assert np.abs(a - b).max() <= FIELD_RTOL * np.abs(b).max()
+    nc0, x0, y0 = out[0]
+    assert nc0[2] > nc0[1] > nc0[0]
+    for nc1, x1, y1 in out[1:]:          # the LDS-resident k_row; k_rowreg with whole-sample exchanges (rows of 512 / 1024 points split them by default)
+        assert nc0.tolist() == nc1.tolist()
+        for a, b in ((x0, x1), (y0, y1)):
+            assert np.abs(a - b).max() <= FIELD_RTOL * np.abs(b).max()
 
 
 @pytest.mark.parametrize("nsymb,nt", [(4096, 64), (4096, 128)])
