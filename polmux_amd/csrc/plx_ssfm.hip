@@ -833,7 +833,8 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 // the butterflies are k_row's, stage by stage.  Inter-pass twiddles as in k_row4k: tpass[j + 16 k] = tpass[j] * tpass[16 k],
 // a lane reads one entry and the row's sixteen lanes share sixteen (bk).
 #define ROWR_THREADS 64
-#define ROWR_LDS ((4 * 272 + 128 + 80) * sizeof(cplx))
+#define ROWR_LDS ((4 * 272 + 128 + 48) * sizeof(cplx))        // 20224 B: eight one-wave workgroups per CU
+#define ROWR_LDS_SC ((4 * 272 + 128 + 80) * sizeof(cplx))     // scalar plans: four rows' bk entries (seven workgroups per CU)
 #ifdef PLX_EMU
 #define ROWR_SYNC() __syncthreads()
 #else
@@ -2318,7 +2319,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
     }
     if (tune.rowr && a.dual && a.p1 == 8 && a.p2 == 8 && !P->row_split &&
         (a.pmd ? allow_lds(k_row256r<true>, ROWR_LDS) : allow_lds(k_row256r<false>, ROWR_LDS)) == hipSuccess) P->rowr = 1;
-    if (tune.rowr && !a.dual && a.p1 == 8 && a.p2 == 8 && allow_lds(k_row256r<false, true>, ROWR_LDS) == hipSuccess) P->rowr = 1;
+    if (tune.rowr && !a.dual && a.p1 == 8 && a.p2 == 8 && allow_lds(k_row256r<false, true>, ROWR_LDS_SC) == hipSuccess) P->rowr = 1;
     // Fused column sweep (k_colx16): the inverse column pass of step s, the step controller and the forward column
     // pass of step s+1 in ONE launch on a register/LDS-resident tile (2 sweeps over HBM per step instead of 3), for
     // dual-polarisation plans with 256 x (8+8) column tiles.  The tiles of a frame meet at a barrier inside the
@@ -2502,7 +2503,7 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         return;
     }
     if (P->rowr && !a.dual && !a.force && !a.hmul) {
-        PLX_LAUNCH((k_row256r<false, true>), dim3(64u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
+        PLX_LAUNCH((k_row256r<false, true>), dim3(64u, FC), dim3(ROWR_THREADS), ROWR_LDS_SC, st, a);
         return;
     }
     if (P->rowr && a.dual && !a.force && !a.hmul && !a.umat) {
