@@ -1333,7 +1333,10 @@ template <int LOGM, bool PAIR, bool SC = false, bool SPLIT = false> __global__ _
     constexpr bool SHARE = !PAIR && !SC && LOGM == 9, HALF_BINS = PAIR || SHARE;
     const int ib = 16 * t + (HALF_BINS && pol ? 8 : 0);  // (PAIR: the eight bins whose two polarisations the lane holds after the trade)
     double btv[HALF_BINS ? 8 : 16];
-    if (!a.hmul && !(PAIR && a.umat)) {
+    // (SPLIT without sharing: the sixteen phases are asked for in two halves AT the multiplier -- sixteen registers less across r16_dif,
+    //  what the 168-register form of the 1024-point rows is short of)
+    constexpr bool LATE_BT = SPLIT && !HALF_BINS;
+    if (!LATE_BT && !a.hmul && !(PAIR && a.umat)) {
         const double *bt = a.betat_p + (size_t)c * N + rowbase + ib;
 #pragma unroll
         for (int k = 0; k < (HALF_BINS ? 8 : 16); k++) btv[k] = bt[k];
@@ -1361,6 +1364,18 @@ template <int LOGM, bool PAIR, bool SC = false, bool SPLIT = false> __global__ _
                 half_share(h, ha, hb);
                 x[k] = cmul(ha, x[k]);
                 x[k + 8] = cmul(hb, x[k + 8]);
+            }
+        } else if (LATE_BT) {
+#pragma unroll
+            for (int h = 0; h < 16; h += 8) {
+                int o = ib + h;
+                pin(o);
+                const double *bt = a.betat_p + (size_t)c * N + rowbase + o;
+                double bh[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) bh[k] = bt[k];
+#pragma unroll
+                for (int k = 0; k < 8; k++) x[h + k] = cmul(cexp_neg_turns_tab(bh[k] * cur, ct), x[h + k]);
             }
         } else {
 #pragma unroll
