@@ -1082,8 +1082,11 @@ struct Tw256pad {
 // halves (half_trade: v_permlane32_swap, no LDS, no barrier) around the multiplier exactly as k_row256r<PMD> does.  Everything
 // else -- the three register levels, the four exchanges, the blocks of sixteen threads that stay inside a wave -- is the
 // one-polarisation kernel with the thread's index within its row (tj) in the place of tid.
-template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2) void k_row4k(SsfmArgs a)
+// SPLIT (the one-polarisation form): the four exchanges in real / imaginary halves, as in k_rowreg -- a 34 KiB padded row, three
+// workgroups per CU (twelve waves) at <= 168 registers; the two outer exchanges then meet at three workgroup barriers each.
+template <bool PAIR, bool SPLIT = false> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : (SPLIT ? 3 : 2)) void k_row4k(SsfmArgs a)
 {
+    static_assert(!(PAIR && SPLIT), "the split exchange belongs to the one-polarisation form");
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = PAIR ? (int)((threadIdx.x >> 6) * 32u + (threadIdx.x & 31u)) : (int)threadIdx.x;   // the thread's index within its row
@@ -1121,7 +1124,8 @@ template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2
     const FrameCtl *ctl = a.ctl + f;
     if (ctl->done) return;
     cplx *s = (cplx *)lds + (PAIR ? bpol * 4352 : 0);    // [4352] padded row: physical(p) = p + (p >> 4)
-    cplx *tw = (cplx *)lds + (PAIR ? 2 : 1) * 4352;      // W_4096^{4k}, k < 512, then W_4096^0..3
+    double *const sd = (double *)lds;            // SPLIT: the padded row, one component at a time
+    cplx *tw = SPLIT ? (cplx *)((double *)lds + 4352) : (cplx *)lds + (PAIR ? 2 : 1) * 4352;      // W_4096^{4k}, k < 512, then W_4096^0..3
     cplx *bk = tw + 516;                         // tpass[256 k], k < 16
     cplx *t8 = bk + 16;                          // W_256^e at e + (e >> 2), e < 128
     cplx *ct = t8 + 160;                         // the unit circle in 64 steps (cexp_neg_turns_tab)
@@ -1134,6 +1138,29 @@ template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2
     const Tw256pad w2{t8};
     const int b = tid >> 4, j2 = tid & 15;       // level 2: block b of 256 points, point j2 + 16 k of it
     cplx x[16];
+    // SPLIT: one exchange in two halves (x[k] to slot wi(k), the thread's next sixteen values from slot ri(k); the real parts land
+    // in x[k].x while x[k].y still holds the old imaginary parts).  The padded slots in closed form: row_phys(tid + 256 k) =
+    // tid + (tid >> 4) + 272 k, row_phys(256 b + j2 + 16 k) = 272 b + j2 + 17 k, row_phys(16 tid + k) = 17 tid + k.
+    // outer: the partners are the whole workgroup (barriers); else lanes of this wave.  No barrier behind the last read: a slot a
+    // thread reads in one exchange is written next by that thread itself, or after a later barrier.
+    auto exchange_split = [&](auto wi, auto ri, bool outer) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) sd[wi(k)] = x[k].x;
+        if (outer) __syncthreads(); else ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k].x = sd[ri(k)];
+        if (outer) __syncthreads(); else ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) sd[wi(k)] = x[k].y;
+        if (outer) __syncthreads(); else ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k].y = sd[ri(k)];
+        if (!outer) ROWR_SYNC();
+    };
+    const int obase = tid + (tid >> 4), cbase = 272 * b + j2, tbase = 17 * tid;
+    const auto outerp = [&](int k) { return obase + 272 * k; };
+    const auto chunkp = [&](int k) { return cbase + 17 * k; };
+    const auto own16p = [&](int k) { return tbase + k; };
     {
         cplx ta = tp[tid];
 #pragma unroll
@@ -1155,28 +1182,36 @@ template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2
         for (int k = 0; k < 16; k++) x[k] = cmul(x[k], cmul(ta, bk[k]));
     }
     lvl2_dif<256>(x, tid, w1);
+    if (SPLIT) exchange_split(outerp, chunkp, true);
+    else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) s[row_phys(tid + 256 * k)] = x[k];
-    __syncthreads();
+        for (int k = 0; k < 16; k++) s[row_phys(tid + 256 * k)] = x[k];
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+        for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+    }
     lvl2_dif<16>(x, j2, w2);                     // (written back where this thread read it: no barrier in between)
+    if (SPLIT) exchange_split(chunkp, own16p, false);
+    else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
-    ROWR_SYNC();                                 // (the block's sixteen threads are lanes of one wave)
+        for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
+        ROWR_SYNC();                             // (the block's sixteen threads are lanes of one wave)
+    }
     // the step's multiplier at the 16 bins this thread holds (lin_step :771-773 / matrix_step with matR = I): the phases are
     // asked for HERE, one exchange and one register level ahead of their use (16 more registers fit beside r16_dif)
     // (PAIR: the eight bins whose two polarisations the lane holds after the trade -- the lower half of the wave the thread's
     //  bins 0-7, the upper half bins 8-15)
     const int ib = 16 * tid + (PAIR && bpol ? 8 : 0);
     double btv[PAIR ? 8 : 16];
-    if (!a.hmul && !(PAIR && a.umat)) {
+    if (!SPLIT && !a.hmul && !(PAIR && a.umat)) {      // (SPLIT: asked for in two halves at the multiplier, see k_rowreg)
         const double *bt = a.betat_p + (size_t)c * N + rowbase + ib;
 #pragma unroll
         for (int k = 0; k < (PAIR ? 8 : 16); k++) btv[k] = bt[k];
     }
+    if (!SPLIT) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = s[17 * tid + k];             // row_phys(16 tid + k)
+        for (int k = 0; k < 16; k++) x[k] = s[17 * tid + k];         // row_phys(16 tid + k)
+    }
     r16_dif(x);
     if (PAIR && !a.hmul) {
         pair_multiplier<12>(a, x, btv, ct, ctl, f, c, brow, rowbase, ib);
@@ -1189,28 +1224,54 @@ template <bool PAIR> __global__ __launch_bounds__(PAIR ? 512 : 256, PAIR ? 1 : 2
             for (int k = 0; k < 16; k++) x[k] = cmul(h[k], x[k]);
         } else {
             const double cur = a.force ? a.f_cur : ctl->cur;
+            if (SPLIT) {
+#pragma unroll
+                for (int h = 0; h < 16; h += 8) {
+                    int o = ib + h;
+                    pin(o);
+                    const double *bt = a.betat_p + (size_t)c * N + rowbase + o;
+                    double bh[8];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) bh[k] = bt[k];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) x[h + k] = cmul(cexp_neg_turns_tab(bh[k] * cur, ct), x[h + k]);
+                }
+            } else
 #pragma unroll
             for (int k = 0; k < (PAIR ? 8 : 16); k++) x[k] = cmul(cexp_neg_turns_tab(btv[k] * cur, ct), x[k]);    // (PAIR comes here with hmul only)
         }
     }
     r16_dit(x);
+    if (SPLIT) exchange_split(own16p, chunkp, false);
+    else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) s[17 * tid + k] = x[k];
-    ROWR_SYNC();
+        for (int k = 0; k < 16; k++) s[17 * tid + k] = x[k];
+        ROWR_SYNC();
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+        for (int k = 0; k < 16; k++) x[k] = s[row_phys(256 * b + j2 + 16 * k)];
+    }
     lvl2_dit<16>(x, j2, w2);
+    if (!SPLIT) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
-    __syncthreads();
+        for (int k = 0; k < 16; k++) s[row_phys(256 * b + j2 + 16 * k)] = x[k];
+        __syncthreads();
+    }
     int jo = tid;
     pin(jo);
-    const cplx tb = tp[jo];                      // (asked for ahead of the last register level)
+    // (SPLIT: the row's pointers are formed again here instead of being held since the top of the kernel)
+    int rq = brow, pq = bpol, fq = fc;
+    if (SPLIT) { pin(rq); pin(pq); pin(fq); }
+    const size_t rowbase2 = SPLIT ? (size_t)rq << 12 : rowbase;
+    cplx *const u2 = SPLIT ? (pq ? a.uy : a.ux) + ((size_t)fq << (a.p1 + 12)) + rowbase2 : u;
+    const cplx tb = (SPLIT ? a.tpass + rowbase2 : tp)[jo];                      // (asked for ahead of the last register level)
+    if (SPLIT) exchange_split(chunkp, outerp, true);
+    else {
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = s[row_phys(tid + 256 * k)];
-    lvl2_dit<256>(x, tid, w1);
+        for (int k = 0; k < 16; k++) x[k] = s[row_phys(tid + 256 * k)];
+    }
+    lvl2_dit<256>(x, SPLIT ? jo : tid, w1);
 #pragma unroll
-    for (int k = 0; k < 16; k++) u[jo + 256 * k] = cmulc(x[k], cmul(tb, bk[k]));
+    for (int k = 0; k < 16; k++) u2[jo + 256 * k] = cmulc(x[k], cmul(tb, bk[k]));
 }
 
 // ------------------------------------------------- pass 2 for rows of 512, 1024 and 2048 points, register form ---
@@ -2013,6 +2074,7 @@ struct plx_ssfm {
     int col_threads = 512;         // workgroup size of k_col_fwd / k_col_inv
     int row_threads = ROW_THREADS; // workgroup size of k_row
     int rowr = 0;                  // k_row256r serves the step's row pass
+    int row4k_split = 0;           // k_row4k<false, true>: the same for 4096-point rows
     int rowg_split = 0;            // ... with the exchanges split into real and imaginary halves (three workgroups per CU)
     int rowreg = 0;                // k_rowreg<p2> serves it (dual polarisation, no PMD, rows of 512 / 1024 / 2048 points)
     cplx *d_tw2c = nullptr, *d_twmid = nullptr;
@@ -2097,7 +2159,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // not adopted (working copy, frame groups, grid sizing: profiles/r03_notes.md) are gone with their code.
 namespace {
 struct Tune {
-    int short_rows = 0, no_fuse = 0, p1 = -1, logW = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, no_pmd_tab = 0, rowr = 0, store_late = -1, row_rev = 0, rowg_split = 1;
+    int short_rows = 0, no_fuse = 0, p1 = -1, logW = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, no_pmd_tab = 0, rowr = 0, store_late = -1, row_rev = 0, rowg_split = 1, row4k_split = 1;
     double barrier_timeout_ms = 500.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -2111,6 +2173,7 @@ struct Tune {
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
         store_late = geti("PLX_SSFM_STORE_LATE", -1);  // fused sweep: stores after the next tile's landing; -1: where a launch has more than one team
         row_rev = geti("PLX_SSFM_ROW_REV", 1);         // 0: the row pass takes the listed frames in ascending order as well (A/B)
+        row4k_split = geti("PLX_SSFM_ROW4K_SPLIT", 1);  // 0: k_row4k's whole-sample exchanges (two workgroups per CU; A/B, tests)
         rowg_split = geti("PLX_SSFM_ROWG_SPLIT", 1);   // 0: k_rowreg's whole-sample exchanges also for rows of 512 / 1024 points (A/B, tests)
         rowr = geti("PLX_SSFM_ROWR", 1);               // 0: the LDS-resident k_row also where the register form k_row256r applies (A/B, tests)
         no_pmd_tab = geti("PLX_SSFM_NO_PMD_TAB", 0);   // PMD plans: one exponential per bin and trunk instead of the phasor tables (A/B, tests)
@@ -2328,10 +2391,12 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
     if (allow_lds(k_colx16<true>, P->lds_col) != hipSuccess || allow_lds(k_colx16<false>, P->lds_col) != hipSuccess || allow_lds(k_col_fwd, P->lds_col) != hipSuccess ||
         allow_lds(k_col_inv, P->lds_col) != hipSuccess ||
         (!P->tw_compact && allow_lds(k_row, P->lds_row > P->rs_lds ? P->lds_row : P->rs_lds) != hipSuccess) ||
-        (P->tw_compact && (allow_lds(k_row4k<false>, P->rs_lds) != hipSuccess || allow_lds(k_row4k<true>, P->rs_lds_pair) != hipSuccess))) {
+        (P->tw_compact && (allow_lds(k_row4k<false>, P->rs_lds) != hipSuccess || allow_lds(k_row4k<true>, P->rs_lds_pair) != hipSuccess ||
+                           allow_lds(k_row4k<false, true>, P->rs_lds) != hipSuccess))) {
         free_plan(P);
         PLX_FAIL(PLX_ERR_HIP, "plx_ssfm_create: cannot reserve LDS for the transform kernels");
     }
+    P->row4k_split = (P->tw_compact && tune.row4k_split) ? 1 : 0;
     if (tune.rowr && a.dual && a.p1 == 8 && a.p2 == 8 && !P->row_split &&
         (a.pmd ? allow_lds(k_row256r<true>, ROWR_LDS) : allow_lds(k_row256r<false>, ROWR_LDS)) == hipSuccess) P->rowr = 1;
     if (tune.rowr && !a.dual && a.p1 == 8 && a.p2 == 8 && allow_lds(k_row256r<false, true>, ROWR_LDS_SC) == hipSuccess) P->rowr = 1;
@@ -2470,7 +2535,8 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
 {
     const int N1 = 1 << a.p1;
     if (P->tw_compact && !a.dual) {              // scalar plan, 4096-point rows: one workgroup per row and frame-channel
-        PLX_LAUNCH(k_row4k<false>, dim3((unsigned)N1 * FC), dim3(256), P->rs_lds, st, a);
+        if (P->row4k_split) PLX_LAUNCH((k_row4k<false, true>), dim3((unsigned)N1 * FC), dim3(256), P->rs_lds - 4352 * sizeof(double), st, a);
+        else PLX_LAUNCH(k_row4k<false>, dim3((unsigned)N1 * FC), dim3(256), P->rs_lds, st, a);
         return;
     }
     if (P->tw_compact && a.dual && (a.pmd || a.umat)) {      // the multiplier couples the polarisations: both rows in one workgroup
@@ -2508,7 +2574,8 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         b.dual = 0; b.R = 1; b.logR = 0;
         const dim3 gs((unsigned)N1, FC), bs((unsigned)P->rs_threads);
         if (P->tw_compact) {                     // (both polarisations in one launch: one tail instead of two)
-            PLX_LAUNCH(k_row4k<false>, dim3(gs.x * gs.y * 2u), dim3(256), P->rs_lds, st, b);   // (rows x frame-channels x polarisations: decoded in the kernel)
+            if (P->row4k_split) PLX_LAUNCH((k_row4k<false, true>), dim3(gs.x * gs.y * 2u), dim3(256), P->rs_lds - 4352 * sizeof(double), st, b);
+            else PLX_LAUNCH(k_row4k<false>, dim3(gs.x * gs.y * 2u), dim3(256), P->rs_lds, st, b);   // (rows x frame-channels x polarisations: decoded in the kernel)
             return;
         }
         for (int pol = 0; pol < 2; pol++) {

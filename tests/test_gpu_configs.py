@@ -304,7 +304,8 @@ def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monk
     F = 8
     dbm = -4.0 + 12.0 * np.arange(F) / (F - 1)
     out = []
-    for env in ({}, {"PLX_SSFM_NO_FUSE": "1"}):
+    # (the second plan also keeps k_row4k's whole-sample exchanges: the default splits them into real / imaginary halves)
+    for env in ({}, {"PLX_SSFM_NO_FUSE": "1", "PLX_SSFM_ROW4K_SPLIT": "0"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, nspans=nspans)
