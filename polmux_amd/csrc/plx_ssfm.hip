@@ -1297,7 +1297,7 @@ template <bool PAIR, bool SPLIT = false> __global__ __launch_bounds__(PAIR ? 512
 template <int LOGM, bool PAIR, bool SC = false, bool SPLIT = false> __global__ __launch_bounds__(ROWG_THREADS, SPLIT ? 3 : 2) void k_rowreg(SsfmArgs a)
 {
     static_assert(!(PAIR && SC), "a scalar plan has no second polarisation to pair with");
-    static_assert(!SPLIT || (!PAIR && LOGM <= 10), "the split exchange is wave-local");
+    static_assert(!SPLIT || !PAIR, "the split exchange belongs to the one-polarisation forms");
     // (twiddles of the outer level: the half table W_M^k where it fits beside two workgroups' rows -- 512 and 1024 points: 4 / 8
     //  KiB -- and the compact table, one more complex product per twiddle, for 2048 points)
     constexpr bool HALF_TW = LOGM <= 10;
@@ -1334,20 +1334,22 @@ template <int LOGM, bool PAIR, bool SC = false, bool SPLIT = false> __global__ _
     const int b = t >> 4, j2 = t & 15;                   // middle level: chunk b of 256 points, point j2 + 16 kk of it
     cplx x[16];
     // SPLIT: one exchange in two halves -- x[k] goes to slot wi(k), the thread's next sixteen values come from slot ri(k)
-    auto exchange_split = [&](auto wi, auto ri) {
+    // (block: the partners of an OUTER exchange of a 2048-point row are two waves -- workgroup barriers, and none behind the last
+    //  read: a slot a thread reads in one exchange is written next by that thread itself, or behind a later barrier)
+    auto exchange_split = [&](auto wi, auto ri, bool block = false) {
         // (the real parts travel first and land in x[k].x while x[k].y still holds the OLD imaginary parts: no spare registers)
 #pragma unroll
         for (int k = 0; k < 16; k++) sd[wi(k)] = x[k].x;
-        ROWR_SYNC();
+        if (block) __syncthreads(); else ROWR_SYNC();
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k].x = sd[ri(k)];
-        ROWR_SYNC();
+        if (block) __syncthreads(); else ROWR_SYNC();
 #pragma unroll
         for (int k = 0; k < 16; k++) sd[wi(k)] = x[k].y;
-        ROWR_SYNC();
+        if (block) __syncthreads(); else ROWR_SYNC();
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k].y = sd[ri(k)];
-        ROWR_SYNC();
+        if (!block) ROWR_SYNC();
     };
     // (the padded slots in closed form -- S and 256 are multiples of 16, j2 < 16 -- so that every access is ONE base register + an
     //  immediate: row_phys(t + S k) = t + (t >> 4) + (S + S / 16) k, row_phys(256 b + j2 + 16 k) = 272 b + j2 + 17 k)
@@ -1368,7 +1370,7 @@ template <int LOGM, bool PAIR, bool SC = false, bool SPLIT = false> __global__ _
         for (int k = 0; k < 16; k++) x[k] = cmul(x[k], cmul(ta, bk[k]));
     }
     lvl2_dif<S>(x, t, wm);
-    if (SPLIT) exchange_split(outer, chunk);
+    if (SPLIT) exchange_split(outer, chunk, !WAVE_LOCAL);
     else {
 #pragma unroll
         for (int k = 0; k < 16; k++) s[row_phys(t + S * k)] = x[k];
@@ -1473,7 +1475,7 @@ template <int LOGM, bool PAIR, bool SC = false, bool SPLIT = false> __global__ _
     const size_t rowbase2 = SPLIT ? ((size_t)blockIdx.x * ROWS + rq) << LOGM : rowbase;
     cplx *const u2 = SPLIT ? (pq ? a.uy : a.ux) + ((size_t)fq << (LOGM + a.p1)) + rowbase2 : u;
     const cplx tb = (SPLIT ? a.tpass + rowbase2 : tp)[jo];                              // (asked for ahead of the last register level)
-    if (SPLIT) exchange_split(chunk, outer);
+    if (SPLIT) exchange_split(chunk, outer, !WAVE_LOCAL);
     else {
 #pragma unroll
         for (int k = 0; k < 16; k++) x[k] = s[row_phys(t + S * k)];
@@ -2362,9 +2364,11 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
         if (e == hipSuccess) P->rowreg = 1;
         // rows of 512 / 1024 points without PMD: the exchanges in real / imaginary halves, three workgroups per CU
         // (PLX_SSFM_ROWG_SPLIT=0: the whole-sample exchange, A/B and tests)
-        if (P->rowreg && P->p2 <= 10 && tune.rowg_split) {
-            const hipError_t e2 = a.dual ? (P->p2 == 9 ? allow_lds(k_rowreg<9, false, false, true>, ROWG_LDS_SPLIT(512)) : allow_lds(k_rowreg<10, false, false, true>, ROWG_LDS_SPLIT(1024)))
-                                         : (P->p2 == 9 ? allow_lds(k_rowreg<9, false, true, true>, ROWG_LDS_SPLIT(512)) : allow_lds(k_rowreg<10, false, true, true>, ROWG_LDS_SPLIT(1024)));
+        if (P->rowreg && tune.rowg_split) {
+            const hipError_t e2 = a.dual ? (P->p2 == 9 ? allow_lds(k_rowreg<9, false, false, true>, ROWG_LDS_SPLIT(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10, false, false, true>, ROWG_LDS_SPLIT(1024))
+                                                                                                                                        : allow_lds(k_rowreg<11, false, false, true>, ROWG_LDS_SPLIT(2048)))
+                                         : (P->p2 == 9 ? allow_lds(k_rowreg<9, false, true, true>, ROWG_LDS_SPLIT(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10, false, true, true>, ROWG_LDS_SPLIT(1024))
+                                                                                                                                       : allow_lds(k_rowreg<11, false, true, true>, ROWG_LDS_SPLIT(2048)));
             if (e2 == hipSuccess) P->rowg_split = 1;
         }
     }
@@ -2547,6 +2551,7 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         const dim3 g((unsigned)(N1 / (ROWG_THREADS / ((1 << a.p2) / 16))), FC), bs(ROWG_THREADS);
         if (P->rowg_split && a.p2 == 9) PLX_LAUNCH((k_rowreg<9, false, true, true>), g, bs, ROWG_LDS_SPLIT(512), st, a);
         else if (P->rowg_split && a.p2 == 10) PLX_LAUNCH((k_rowreg<10, false, true, true>), g, bs, ROWG_LDS_SPLIT(1024), st, a);
+        else if (P->rowg_split && a.p2 == 11) PLX_LAUNCH((k_rowreg<11, false, true, true>), g, bs, ROWG_LDS_SPLIT(2048), st, a);
         else if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, false, true>), g, bs, ROWG_LDS(512), st, a);
         else if (a.p2 == 10) PLX_LAUNCH((k_rowreg<10, false, true>), g, bs, ROWG_LDS(1024), st, a);
         else PLX_LAUNCH((k_rowreg<11, false, true>), g, bs, ROWG_LDS(2048), st, a);
@@ -2559,9 +2564,10 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
             if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, true>), g, bs, ROWG_LDS(512), st, a);
             else if (a.p2 == 10) PLX_LAUNCH((k_rowreg<10, true>), g, bs, ROWG_LDS(1024), st, a);
             else PLX_LAUNCH((k_rowreg<11, true>), g, bs, ROWG_LDS(2048), st, a);
-        } else if (P->rowg_split && a.p2 <= 10) {
+        } else if (P->rowg_split) {
             if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, false, false, true>), g, bs, ROWG_LDS_SPLIT(512), st, a);
-            else PLX_LAUNCH((k_rowreg<10, false, false, true>), g, bs, ROWG_LDS_SPLIT(1024), st, a);
+            else if (a.p2 == 10) PLX_LAUNCH((k_rowreg<10, false, false, true>), g, bs, ROWG_LDS_SPLIT(1024), st, a);
+            else PLX_LAUNCH((k_rowreg<11, false, false, true>), g, bs, ROWG_LDS_SPLIT(2048), st, a);
         } else {
             if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, false>), g, bs, ROWG_LDS(512), st, a);
             else if (a.p2 == 10) PLX_LAUNCH((k_rowreg<10, false>), g, bs, ROWG_LDS(1024), st, a);
