@@ -2176,8 +2176,8 @@ struct Tune {
         store_late = geti("PLX_SSFM_STORE_LATE", -1);  // fused sweep: stores after the next tile's landing; -1: where a launch has more than one team
         row_rev = geti("PLX_SSFM_ROW_REV", 1);         // 0: the row pass takes the listed frames in ascending order as well (A/B)
         row4k_split = geti("PLX_SSFM_ROW4K_SPLIT", 1);  // 0: k_row4k's whole-sample exchanges (two workgroups per CU; A/B, tests)
-        rowg_split = geti("PLX_SSFM_ROWG_SPLIT", 1);   // 0: k_rowreg's whole-sample exchanges also for rows of 512 / 1024 points (A/B, tests)
-        rowr = geti("PLX_SSFM_ROWR", 1);               // 0: the LDS-resident k_row also where the register form k_row256r applies (A/B, tests)
+        rowg_split = geti("PLX_SSFM_ROWG_SPLIT", 1);   // 0: k_rowreg's whole-sample exchanges (two workgroups per CU; A/B, tests)
+        rowr = geti("PLX_SSFM_ROWR", 1);               // 0: the LDS-resident k_row also where the register forms k_row256r / k_rowreg apply (A/B, tests)
         no_pmd_tab = geti("PLX_SSFM_NO_PMD_TAB", 0);   // PMD plans: one exponential per bin and trunk instead of the phasor tables (A/B, tests)
         if (const char *e = getenv("PLX_SSFM_BARRIER_TIMEOUT_MS")) barrier_timeout_ms = atof(e);
     }
