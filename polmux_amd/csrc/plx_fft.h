@@ -447,6 +447,57 @@ template <int R> __device__ __forceinline__ void lvlmid_dit(cplx *x, const cplx 
     }
 }
 
+// One R-point set of that level on R consecutive registers (rows of 16 R points, k_rowsm: a thread's sixteen registers are
+// 16 / R sets whose lane twiddles differ): x[q] = point i + 16 q, w as in lvlmid_dif for lane index i.
+template <int R> __device__ __forceinline__ void radset_dif(cplx *x, const cplx *w)
+{
+    if (R == 2) {
+        const cplx a = x[0], b = x[1];
+        x[0] = cadd(a, b);
+        x[1] = cmul(csub(a, b), w[0]);
+        return;
+    }
+    if (R == 8) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const cplx a = x[k], b = x[k + 4];
+            x[k] = cadd(a, b);
+            x[k + 4] = cmul(csub(a, b), w[k]);
+        }
+    }
+    const cplx w1 = w[R == 8 ? 4 : 0], w2 = w[R == 8 ? 5 : 1], w3 = w[R == 8 ? 6 : 2];
+#pragma unroll
+    for (int b = 0; b < R; b += 4) {
+        const cplx a0 = x[b], a1 = x[b + 1], a2 = x[b + 2], a3 = x[b + 3];
+        const cplx t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = cmulni(csub(a1, a3));
+        x[b] = cadd(t0, t2); x[b + 1] = cmul(csub(t0, t2), w2); x[b + 2] = cmul(cadd(t1, t3), w1); x[b + 3] = cmul(csub(t1, t3), w3);
+    }
+}
+template <int R> __device__ __forceinline__ void radset_dit(cplx *x, const cplx *w)
+{
+    if (R == 2) {
+        const cplx a = x[0], b = cmulc(x[1], w[0]);
+        x[0] = cadd(a, b);
+        x[1] = csub(a, b);
+        return;
+    }
+    const cplx w1 = w[R == 8 ? 4 : 0], w2 = w[R == 8 ? 5 : 1], w3 = w[R == 8 ? 6 : 2];
+#pragma unroll
+    for (int b = 0; b < R; b += 4) {
+        const cplx c0 = x[b], c2 = cmulc(x[b + 1], w2), c1 = cmulc(x[b + 2], w1), c3 = cmulc(x[b + 3], w3);
+        const cplx s0 = cadd(c0, c2), s1 = csub(c0, c2), s2 = cadd(c1, c3), s3 = cmuli(csub(c1, c3));
+        x[b] = cadd(s0, s2); x[b + 1] = cadd(s1, s3); x[b + 2] = csub(s0, s2); x[b + 3] = csub(s1, s3);
+    }
+    if (R == 8) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const cplx a = x[k], b = cmulc(x[k + 4], w[k]);
+            x[k] = cadd(a, b);
+            x[k + 4] = csub(a, b);
+        }
+    }
+}
+
 // T = 1<<logT padded rows of M = 1<<logM (M >= 16) points each, row t at s + t*row_pitch(M).
 __device__ __forceinline__ void row_fft_dif(cplx *s, int logM, int logT, const cplx *tw, int tid, int nthr)
 {

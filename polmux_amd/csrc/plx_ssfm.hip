@@ -1487,6 +1487,121 @@ template <int LOGM, bool PAIR, bool SC = false, bool SPLIT = false> __global__ _
 #define ROWG_LDS(M) ((size_t)((ROWG_THREADS / ((M) / 16)) * ((M) + (M) / 16) + ROWG_NTW(M) + 7 * 16 + PLX_CTAB + 17 * (ROWG_THREADS / ((M) / 16))) * sizeof(cplx))
 #define ROWG_LDS_SPLIT(M) (ROWG_LDS(M) - (size_t)((ROWG_THREADS / ((M) / 16)) * ((M) + (M) / 16)) * sizeof(double))
 
+// ------------------------------------------------- pass 2 for rows of 32, 64 and 128 points, register form ---
+// Frames of 2^13 ... 2^15 samples on the 256-row split (the sizes of the reference's own examples: ex19 / ex20 run 256 x 64 =
+// 2^14): dual polarisation without PMD, and scalar plans.  M = R x 16 points (R = 2, 4, 8): R threads per row and polarisation
+// with 16 points each, ONE WAVE = 64 / R row-polarisations, no workgroup barrier.  Thread j holds points j + R k; for each
+// i = j + R par (par < 16 / R) the R points i + 16 q sit in R of its registers -- one radix-R set (radset_dif: the middle
+// level of k_rowreg, on a row that is a single block) -- then one exchange through the wave's padded rows (in real /
+// imaginary halves: 8.5 KiB per wave) hands every thread sixteen contiguous points for r16_dif; multiplier on the thread's
+// sixteen bins; the inverse mirrors it.  The inter-pass twiddles are read from tpass directly (16 per thread and direction).
+template <int LOGM, bool SC> __global__ __launch_bounds__(64, 3) void k_rowsm(SsfmArgs a)
+{
+    constexpr int M = 1 << LOGM, R = M / 16, NS = 16 / R, RPW = 64 / R, NQ = R == 8 ? 7 : (R == 4 ? 3 : 1);
+    PLX_DYN_LDS(lds);
+    if (all_done_or_aborted(a)) return;
+    const int tid = threadIdx.x;
+    int slot = blockIdx.y / a.nfc;
+    const int c = blockIdx.y - slot * a.nfc;       // (channels of a frame: 'sepfields' WDM)
+    if (!row_slot(a, slot)) return;
+    int f;
+    if (!slot_frame(a, slot, f)) return;
+    const int fc = f * a.nfc + c;
+    const FrameCtl *ctl = a.ctl + f;
+    if (ctl->done) return;
+    const int g = tid / R, j = tid - g * R;              // row-polarisation of the wave, thread within it
+    const int rp = (int)blockIdx.x * RPW + g, row = SC ? rp : rp >> 1, pol = SC ? 0 : rp & 1;
+    double *const sd = (double *)lds + g * (17 * R);     // this row-polarisation's padded row (one component at a time): physical(p) = p + (p >> 4)
+    cplx *const tm = (cplx *)((double *)lds + 64 * 17);  // [7][16]: the radix-R level's twiddles by i (the plan lists this R's first)
+    cplx *const ct = tm + 7 * 16;                        // the unit circle in 64 steps (cexp_neg_turns_tab)
+    const size_t N = (size_t)M << a.p1;
+    const size_t rowbase = (size_t)row << LOGM;
+    cplx *const u = (pol ? a.uy : a.ux) + (size_t)fc * N + rowbase;
+    const cplx *const tp = a.tpass + rowbase;
+    cplx x[16];                                          // x[R par + q] = point i + 16 q, i = j + R par
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[R * (k % NS) + k / NS] = u[j + R * k];
+    tm[tid] = a.twmid[tid];
+    if (tid < 7 * 16 - 64) tm[64 + tid] = a.twmid[64 + tid];
+    ct[tid] = a.ctab[tid];
+    {
+        cplx tv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) tv[k] = tp[j + R * k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[R * (k % NS) + k / NS] = cmul(x[R * (k % NS) + k / NS], tv[k]);
+    }
+    ROWR_SYNC();                                         // tables staged (one wave)
+#pragma unroll
+    for (int par = 0; par < NS; par++) {
+        cplx w[7];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) w[q] = tm[16 * q + j + R * par];
+        radset_dif<R>(x + R * par, w);
+    }
+    // exchange: register (par, q) = point i + 16 q goes to slot i + 17 q; the thread then takes the sixteen points of block j
+#pragma unroll
+    for (int k = 0; k < 16; k++) sd[j + R * (k / R) + 17 * (k % R)] = x[k].x;
+    ROWR_SYNC();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k].x = sd[17 * j + k];
+    ROWR_SYNC();
+#pragma unroll
+    for (int k = 0; k < 16; k++) sd[j + R * (k / R) + 17 * (k % R)] = x[k].y;
+    ROWR_SYNC();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k].y = sd[17 * j + k];
+    ROWR_SYNC();
+    r16_dif(x);
+    if (a.hmul) {
+        const cplx *h = a.hmul + rowbase + 16 * j;
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = cmul(h[k], x[k]);
+    } else {
+        const double cur = a.force ? a.f_cur : ctl->cur;
+#pragma unroll
+        for (int h = 0; h < 16; h += 8) {
+            int o = 16 * j + h;
+            pin(o);
+            const double *bt = a.betat_p + (size_t)c * N + rowbase + o;
+            double bh[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) bh[k] = bt[k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) x[h + k] = cmul(cexp_neg_turns_tab(bh[k] * cur, ct), x[h + k]);
+        }
+    }
+    r16_dit(x);
+#pragma unroll
+    for (int k = 0; k < 16; k++) sd[17 * j + k] = x[k].x;
+    ROWR_SYNC();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k].x = sd[j + R * (k / R) + 17 * (k % R)];
+    ROWR_SYNC();
+#pragma unroll
+    for (int k = 0; k < 16; k++) sd[17 * j + k] = x[k].y;
+    ROWR_SYNC();
+#pragma unroll
+    for (int k = 0; k < 16; k++) x[k].y = sd[j + R * (k / R) + 17 * (k % R)];
+#pragma unroll
+    for (int par = 0; par < NS; par++) {
+        cplx w[7];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) w[q] = tm[16 * q + j + R * par];
+        radset_dit<R>(x + R * par, w);
+    }
+    {
+        int jo = j;
+        pin(jo);
+        cplx tv[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) tv[k] = tp[jo + R * k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) u[jo + R * k] = cmulc(x[R * (k % NS) + k / NS], tv[k]);
+    }
+}
+#define ROWSM_LDS ((size_t)64 * 17 * sizeof(double) + (7 * 16 + PLX_CTAB) * sizeof(cplx))
+
 // ------------------------------------------------------ pass 3: inverse columns ---
 // Completes ifft (1/N), applies the attenuation of the step (:531-532) and feeds
 // nextstep's global maximum (:694-696) -- no extra pass over the field.
@@ -2077,6 +2192,7 @@ struct plx_ssfm {
     int row_threads = ROW_THREADS; // workgroup size of k_row
     int rowr = 0;                  // k_row256r serves the step's row pass
     int row4k_split = 0;           // k_row4k<false, true>: the same for 4096-point rows
+    int rowsm = 0;                 // k_rowsm<p2> serves it (rows of 32 / 64 / 128 points; dual polarisation without PMD, scalar)
     int rowg_split = 0;            // ... with the exchanges split into real and imaginary halves (three workgroups per CU)
     int rowreg = 0;                // k_rowreg<p2> serves it (dual polarisation, no PMD, rows of 512 / 1024 / 2048 points)
     cplx *d_tw2c = nullptr, *d_twmid = nullptr;
@@ -2161,7 +2277,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // not adopted (working copy, frame groups, grid sizing: profiles/r03_notes.md) are gone with their code.
 namespace {
 struct Tune {
-    int short_rows = 0, no_fuse = 0, p1 = -1, logW = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, no_pmd_tab = 0, rowr = 0, store_late = -1, row_rev = 0, rowg_split = 1, row4k_split = 1;
+    int short_rows = 0, no_fuse = 0, p1 = -1, logW = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, no_pmd_tab = 0, rowr = 0, store_late = -1, row_rev = 0, rowg_split = 1, row4k_split = 1, rowsm = 1;
     double barrier_timeout_ms = 500.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -2175,6 +2291,7 @@ struct Tune {
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
         store_late = geti("PLX_SSFM_STORE_LATE", -1);  // fused sweep: stores after the next tile's landing; -1: where a launch has more than one team
         row_rev = geti("PLX_SSFM_ROW_REV", 1);         // 0: the row pass takes the listed frames in ascending order as well (A/B)
+        rowsm = geti("PLX_SSFM_ROWSM", 1);              // 0: k_row for rows of 32 / 64 / 128 points everywhere; 2: k_rowsm wherever it applies (tests)
         row4k_split = geti("PLX_SSFM_ROW4K_SPLIT", 1);  // 0: k_row4k's whole-sample exchanges (two workgroups per CU; A/B, tests)
         rowg_split = geti("PLX_SSFM_ROWG_SPLIT", 1);   // 0: k_rowreg's whole-sample exchanges (two workgroups per CU; A/B, tests)
         rowr = geti("PLX_SSFM_ROWR", 1);               // 0: the LDS-resident k_row also where the register forms k_row256r / k_rowreg apply (A/B, tests)
@@ -2339,6 +2456,28 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
             ctv[k] = make_double2((double)cosl(ang), (double)-sinl(ang));
         }
         UP(P->d_ctab, ctv, cplx);
+    }
+    // k_rowsm: register-form row pass for rows of 32 / 64 / 128 points (one wave = 64 / R row-polarisations)
+    // (measured, fraction of 8 TB/s: scalar plans 0.55 / 0.67 / 0.68 at 32 / 64 / 128 points against k_row's 0.49 / 0.50 / 0.45;
+    //  dual-polarisation plans 0.64 / 0.69 / 0.70 against 0.70 / 0.70 / 0.60 -- k_row's wider workgroups win the short dual rows,
+    //  so those take it at 128 points only; PLX_SSFM_ROWSM=2 forces it wherever it applies: tests)
+    const int rowsm_min = a.dual ? (tune.rowsm == 2 ? 5 : 7) : 5;
+    if (tune.rowr && tune.rowsm && !desc->fls[1] && P->p2 >= rowsm_min && P->p2 <= 7 && (N1 * (a.dual ? 2 : 1)) % (64 / (N2 / 16)) == 0) {
+        const long double tau = -2.0L * 3.14159265358979323846264338327950288L;
+        std::vector<cplx> tm(7 * 16, make_double2(1.0, 0.0));
+        const int R = N2 / 16;
+        auto put = [&](int q, int j, int e, int m) { tm[16 * q + j] = make_double2((double)cosl(tau * e / m), (double)sinl(tau * e / m)); };
+        for (int j = 0; j < 16; j++) {
+            if (R == 2) put(0, j, j, 32);
+            const int q0 = R == 8 ? 4 : 0;
+            if (R >= 4) for (int q = 0; q < 3; q++) put(q0 + q, j, (q + 1) * j, 64);
+            if (R == 8) for (int q = 0; q < 4; q++) put(q, j, j + 16 * q, 128);
+        }
+        UP(P->d_twmid, tm, cplx);
+        hipError_t e = hipSuccess;
+        if (a.dual) e = P->p2 == 5 ? allow_lds(k_rowsm<5, false>, ROWSM_LDS) : P->p2 == 6 ? allow_lds(k_rowsm<6, false>, ROWSM_LDS) : allow_lds(k_rowsm<7, false>, ROWSM_LDS);
+        else e = P->p2 == 5 ? allow_lds(k_rowsm<5, true>, ROWSM_LDS) : P->p2 == 6 ? allow_lds(k_rowsm<6, true>, ROWSM_LDS) : allow_lds(k_rowsm<7, true>, ROWSM_LDS);
+        if (e == hipSuccess) P->rowsm = 1;
     }
     // k_rowreg: register-form row pass for dual-polarisation plans without PMD whose rows have 512, 1024 or 2048 points
     if (tune.rowr && P->p2 >= 9 && P->p2 <= 11 && N1 >= (ROWG_THREADS / (N2 / 16)) / (a.dual ? 2 : 1)) {
@@ -2545,6 +2684,19 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
     }
     if (P->tw_compact && a.dual && (a.pmd || a.umat)) {      // the multiplier couples the polarisations: both rows in one workgroup
         PLX_LAUNCH(k_row4k<true>, dim3((unsigned)N1 * FC), dim3(512), P->rs_lds_pair, st, a);
+        return;
+    }
+    if (P->rowsm && !a.pmd && !a.umat) {
+        const dim3 g((unsigned)(N1 * (a.dual ? 2 : 1) / (64 / ((1 << a.p2) / 16))), FC), bs(64);
+        if (a.dual) {
+            if (a.p2 == 5) PLX_LAUNCH((k_rowsm<5, false>), g, bs, ROWSM_LDS, st, a);
+            else if (a.p2 == 6) PLX_LAUNCH((k_rowsm<6, false>), g, bs, ROWSM_LDS, st, a);
+            else PLX_LAUNCH((k_rowsm<7, false>), g, bs, ROWSM_LDS, st, a);
+        } else {
+            if (a.p2 == 5) PLX_LAUNCH((k_rowsm<5, true>), g, bs, ROWSM_LDS, st, a);
+            else if (a.p2 == 6) PLX_LAUNCH((k_rowsm<6, true>), g, bs, ROWSM_LDS, st, a);
+            else PLX_LAUNCH((k_rowsm<7, true>), g, bs, ROWSM_LDS, st, a);
+        }
         return;
     }
     if (P->rowreg && !a.dual) {                  // scalar plan: every row-polarisation of the workgroup is a row
@@ -2843,7 +2995,7 @@ extern "C" int plx_ssfm_info(plx_ssfm *P, int32_t *info)
 {
     if (!P || !info) PLX_FAIL(PLX_ERR_ARG, "plx_ssfm_info: null argument");
     info[0] = P->fused; info[1] = P->p1; info[2] = P->p2; info[3] = P->fused_grid; info[4] = P->tiles_pf;
-    info[5] = P->col_threads; info[6] = P->rowr ? ROWR_THREADS : P->rowreg ? ROWG_THREADS : (P->tw_compact ? (P->row_pair4k ? 512 : 256) : (P->row_split ? P->rs_threads : P->row_threads)); info[7] = P->rowreg ? 2 : (P->row_pair4k ? 0 : ((P->tw_compact && !P->a.dual) ? 1 : P->row_split));
+    info[5] = P->col_threads; info[6] = (P->rowr || P->rowsm) ? ROWR_THREADS : P->rowreg ? ROWG_THREADS : (P->tw_compact ? (P->row_pair4k ? 512 : 256) : (P->row_split ? P->rs_threads : P->row_threads)); info[7] = (P->rowreg || P->rowsm) ? 2 : (P->row_pair4k ? 0 : ((P->tw_compact && !P->a.dual) ? 1 : P->row_split));
     return PLX_OK;
 }
 

@@ -416,7 +416,7 @@ class HotPath:
         info = (C.c_int32 * 8)()
         self.lib.call("plx_ssfm_info", self.ssfm, info)
         if info[6] == 64:
-            return "k_row256r"
+            return "k_row256r" if info[2] == 8 else "k_rowsm"    # (rows of 32 / 64 / 128 points)
         if info[7] == 2:
             return "k_rowreg"                                     # rows of 512 / 1024 / 2048 points, register form
         if info[2] == 12:

@@ -641,6 +641,64 @@ def test_emu_register_form_rows_512_to_2048(emu, oracle, monkeypatch, logm):
     assert not np.array_equal(got["1"][0], got["0"][0])      # (the switch really selects another kernel)
 
 
+@pytest.mark.parametrize("logm,scalar", [(5, False), (6, False), (7, False), (5, True), (7, True)])
+def test_emu_register_form_small_rows(emu, oracle, monkeypatch, logm, scalar):
+    """k_rowsm<5 / 6 / 7>: rows of 32, 64 and 128 points (frames of 2^13 ... 2^15 samples on the 256-row split: the sizes of the
+    reference's own examples) -- R = 2 / 4 / 8 threads per row and polarisation, sixteen points each, one radix-R set per
+    i = j + R par, one exchange in real / imaginary halves, r16 -- on a 32 x M split: a dual-polarisation batch of two frames
+    against oracle.matrix_ssfm, a two-channel scalar XPM comb against oracle.scalar_ssfm, and both against k_row (PLX_SSFM_ROWR=0)."""
+    M = 1 << logm
+    n, nt, L = 32 * M, (16 if logm != 6 else 32), 9e2
+    got = {}
+    if scalar:
+        fls = [1, 0, 1, 1]
+        betat, db1 = _tables(n, nt, fls, 1, nfc=2)
+        u = np.asfortranarray(np.stack([_qpsk_field(n, nt, p)[0] for p in (6.0, 8.0)], 1))
+        gam = [1.3e-6, 1.25e-6]
+        ofd, onc, ou = oracle.scalar_ssfm(u, betat, 4e2, 5e-3, gam, 4.6e-5, L, fls)
+    else:
+        fls = [1, 0, 1, 0]
+        betat, db1 = _tables(n, nt, fls, 1)
+        f = _qpsk_field(n, nt, 6.0)
+        rc, fd, onc, ox, oy = oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0])
+    assert onc >= 3
+    monkeypatch.setenv("PLX_SSFM_ROWSM", "2")              # (also for the short dual rows, which take k_row by default)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PLX_SSFM_ROWR", mode)
+        monkeypatch.setenv("PLX_SSFM_P1", "5")
+        monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
+        d = _desc(n, 2, 0, fls, L, 4.6e-5, gam, 4e2, 5e-3, betat, db1, frames=1) if scalar else \
+            _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=2)
+        plan = C.c_void_p()
+        emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
+        for k in ("PLX_SSFM_ROWR", "PLX_SSFM_P1", "PLX_SSFM_COL_THREADS"):
+            monkeypatch.delenv(k)
+        info = (C.c_int32 * 8)()
+        emu.call("plx_ssfm_info", plan, info)
+        assert list(info)[:3] == [0, 5, logm] and (info[7] == 2 and info[6] == 64) == (mode == "1")
+        if scalar:
+            g = _il(np.ascontiguousarray(u.T)[None])
+            emu.call("plx_ssfm_propagate_dev", plan, _vp(g), None, 1, None)
+            nc = np.zeros(1, np.int32)
+            emu.call("plx_ssfm_results", plan, 1, None, _vp(nc))
+            res = g.view(np.complex128).reshape(2, n).T
+            assert nc[0] == onc and np.abs(res - ou).max() < 1e-11 * np.abs(ou).max()
+        else:
+            ux = _il(np.stack([f[0], 0.5 * f[1]])); uy = _il(np.stack([f[1], f[0]]))
+            emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 2, None)
+            nc = np.zeros(2, np.int32)
+            emu.call("plx_ssfm_results", plan, 2, None, _vp(nc))
+            res = ux.view(np.complex128).reshape(2, n)
+            gy = uy.view(np.complex128).reshape(2, n)
+            assert nc[0] == onc
+            assert np.abs(res[0] - ox[:, 0]).max() < 1e-11 * np.abs(ox).max()
+            assert np.abs(gy[0] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
+        emu.call("plx_ssfm_destroy", plan)
+        got[mode] = np.array(res).copy()
+    assert np.abs(got["1"] - got["0"]).max() < 1e-12 * np.abs(got["0"]).max()
+    assert not np.array_equal(got["1"], got["0"])      # (the switch really selects another kernel)
+
+
 @pytest.mark.parametrize("logm", [9, 11, 12])
 def test_emu_register_form_rows_scalar_plan(emu, oracle, monkeypatch, logm):
     """k_rowreg<., false, true>: the scalar plan's rows of 512 / 2048 points (every row-polarisation of the workgroup is a row of

@@ -656,7 +656,7 @@ def test_pmd_2pow20_frames_fused_sweep_and_both_rows_in_one_workgroup_vs_oracle(
     assert np.abs(x0[0] * math.sqrt(2.0) - x0[1]).max() > 0.05 * np.abs(x0[1]).max()
 
 
-@pytest.mark.parametrize("nsymb,nt", [(1024, 128), (4096, 64), (4096, 128)])
+@pytest.mark.parametrize("nsymb,nt", [(1024, 128), (4096, 64), (4096, 128), (256, 128)])
 def test_frames_of_2pow17_to_2pow19_register_form_rows_vs_oracle(lib, oracle, monkeypatch, nsymb, nt):
     """Frames between the BASELINE shapes -- 2^18 = 4096 symbols x 64 samples is what Run_my_PDM_QPSK.m:21-24 ships with -- on
     the 256-row split: fused column sweep + k_rowreg (rows of 512 / 1024 / 2048 points in registers).  Three frames at different
@@ -676,7 +676,7 @@ def test_frames_of_2pow17_to_2pow19_register_form_rows_vs_oracle(lib, oracle, mo
         info = hp.info()
         p2 = (nsymb * nt).bit_length() - 1 - 8
         assert list(info[:3]) == [1, 8, p2] and (info[7] == 2) == ("PLX_SSFM_ROWR" not in env)
-        assert hp.row_kernel() == ("k_rowreg" if "PLX_SSFM_ROWR" not in env else "k_row")
+        assert hp.row_kernel() == (("k_rowreg" if p2 >= 9 else "k_rowsm") if "PLX_SSFM_ROWR" not in env else "k_row")   # (2^15: 128-point rows)
         ux, uy = hp.make_batch(3, scale)
         hp.fibre(ux, uy)
         _sync()

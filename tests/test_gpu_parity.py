@@ -140,12 +140,13 @@ def test_scalar_ssfm_gateway_vs_oracle(lib, oracle, flag, nfc):
 
 
 @pytest.mark.parametrize("nsymb,nt,flag,nfc", [(1024, 64, "g-s-", 1), (1024, 64, "g-sx", 2), (1024, 128, "g-sx", 3), (4096, 64, "g-s-", 1),
-                                               (4096, 128, "g-s-", 1), (16384, 64, "g-s-", 1)])
+                                               (4096, 128, "g-s-", 1), (16384, 64, "g-s-", 1), (256, 32, "g-sx", 2), (256, 64, "g-s-", 1),
+                                               (256, 128, "g-sx", 3)])
 def test_scalar_ssfm_register_form_rows_vs_oracle(lib, oracle, monkeypatch, nsymb, nt, flag, nfc):
     """scalar_ssfm (fiber.m:557-636) on frames of 2^16 ... 2^19 samples, one field or a 'sepfields' comb with XPM (the row
     sums of nl_step :795): the row pass of the scalar plan is the register form too (k_row256r<false, true>: four rows to a
     wave; k_rowreg<., false, true>: every row-polarisation of the workgroup a row; 2^20 samples: the 256 x 4096 split with
-    k_row4k, against the 512 x 2048 split of PLX_SSFM_SHORT_ROWS=1).  Against oracle.scalar_ssfm (1e-9, ncycle, first step) and
+    k_row4k, against the 512 x 2048 split of PLX_SSFM_SHORT_ROWS=1; 2^13 ... 2^15 samples: k_rowsm, 32 / 64 / 128-point rows).  Against oracle.scalar_ssfm (1e-9, ncycle, first step) and
     against the round-1 structure (three sweeps, the LDS-resident k_row, k_rowsum for XPM: PLX_SSFM_NO_FUSE=1, PLX_SSFM_ROWR=0)
     on the same frame.  The default takes the fused sweep k_colx16<false>; the XPM combs keep k_rowsum and three sweeps, with the
     register-form rows."""
