@@ -318,7 +318,8 @@ def test_emu_sweep_variants(emu, oracle, monkeypatch):
     ref = [oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0]) for f in fields]
     # (PLX_EMU_CUS=1: a one-CU device -- the fused grid is two workgroups, so each walks the tiles of all three frames, with the
     # emulator's two-entry window of the frame list moving on under it)
-    for env in ({}, {"PLX_EMU_CUS": "1"}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_P1": "4"}):
+    # (the three-sweep step alone is test_emu_register_form_row_pass's and test_emu_fused_sweep_scalar_plan's second leg)
+    for env in ({}, {"PLX_EMU_CUS": "1"}, {"PLX_SSFM_P1": "4"}):
         nf = 1 if ("PLX_SSFM_P1" in env or "PLX_SSFM_NO_FUSE" in env) else 3
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -819,7 +820,7 @@ def test_emu_frame_barrier_timeout_aborts_cleanly(emu, monkeypatch):
 @pytest.mark.parametrize("tolflag", [2, 1])
 def test_emu_adaptive_ssfm(emu, oracle, tolflag):
     """scalar_a_ssfm / adaptssfm (fiber.m:639-679, 938-1009) and the dphiadapt first step (:588-611)."""
-    n, nt, nfc, L = 512, 8, 2, 0.8e4
+    n, nt, nfc, L = 512, 8, 2, 0.5e4
     fls = [1, 0, 1, 1]
     betat, db1 = _tables(n, nt, fls, 1, nfc)
     u = np.asfortranarray(np.stack([_qpsk_field(n, nt, 6.0, (2 + k, 5 + k))[0] for k in range(nfc)], 1))
