@@ -844,9 +844,14 @@ __global__ __launch_bounds__(1024) void k_row(SsfmArgs a)
 // wave trade (half_trade) so that every lane holds ux and uy of eight bins, run pmd_trunks / pmd_trunks_tab on them -- the
 // arithmetic of k_row's PMD branch, bin by bin -- and trade back.
 // SC (scalar plans, 2^16-sample frames of scalar_ssfm): the wave's four lane groups are four rows of the one field.
-template <bool PMD, bool SC = false> __global__ __launch_bounds__(ROWR_THREADS, 2) void k_row256r(SsfmArgs a)
+// SPLIT (the PMD form with phasor tables, i.e. a linear db1: the plan knows): three waves per SIMD -- the two exchanges through
+// LDS in real / imaginary halves (11.5 KiB per one-wave workgroup instead of 20), the phases asked for behind the trunk loop,
+// the column phasors fetched two bins at a time, and ONLY the table form of the trunk loop in the kernel (the general form, one
+// exponential per bin and trunk, stays in k_row256r<true>): 168 registers.
+template <bool PMD, bool SC = false, bool SPLIT = false> __global__ __launch_bounds__(ROWR_THREADS, SPLIT ? 3 : 2) void k_row256r(SsfmArgs a)
 {
     static_assert(!(PMD && SC), "PMD needs two polarisations");
+    static_assert(!SPLIT || PMD, "the split form is the PMD kernel's");
     PLX_DYN_LDS(lds);
     if (all_done_or_aborted(a)) return;
     const int tid = threadIdx.x;
@@ -859,7 +864,8 @@ template <bool PMD, bool SC = false> __global__ __launch_bounds__(ROWR_THREADS, 
     const FrameCtl *ctl = a.ctl + f;
     if (ctl->done) return;
     cplx *const s = (cplx *)lds + (tid >> 4) * 272;      // this lane group's padded row: physical(p) = p + (p >> 4)
-    cplx *const tw = (cplx *)lds + 4 * 272;              // W_256^k, k < 128
+    double *const sd = (double *)lds + (tid >> 4) * 272; // SPLIT: the same row, one component at a time
+    cplx *const tw = SPLIT ? (cplx *)((double *)lds + 4 * 272) : (cplx *)lds + 4 * 272;              // W_256^k, k < 128
     cplx *const bk = tw + 128 + 17 * (SC ? tid >> 4 : (tid >> 4) & 1);   // tpass[row][16 k], k < 16 (the rows' entries on different banks)
     const Tw256half w8{tw};
     const int j = tid & 15, r = SC ? tid >> 4 : (tid >> 4) & 1;
@@ -888,19 +894,36 @@ template <bool PMD, bool SC = false> __global__ __launch_bounds__(ROWR_THREADS, 
     sched_fence();
     if (PMD) lvl2_dif<16>(x, j, w8); else lvl2_dif<16>(x, j, w8, v1, v2, v3);
     sched_fence();
+    if (SPLIT) {                           // row_phys(j + 16 k) = j + 17 k, row_phys(16 j + k) = 17 j + k
 #pragma unroll
-    for (int k = 0; k < 16; k++) s[row_phys(j + 16 * k)] = x[k];
-    ROWR_SYNC();
+        for (int k = 0; k < 16; k++) sd[j + 17 * k] = x[k].x;
+        ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k].x = sd[17 * j + k];
+        ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) sd[j + 17 * k] = x[k].y;
+        ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k].y = sd[17 * j + k];
+        ROWR_SYNC();
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) s[row_phys(j + 16 * k)] = x[k];
+        ROWR_SYNC();
+    }
     // the multiplier is the same for the two polarisations of a bin, which sit in lanes i and i + 32: the lower half of the
     // wave forms it for the lane's bins 0-7, the upper half for bins 8-15, and they swap (half_share)
     double btv[SC ? 16 : 8];
-    {
+    if (!SPLIT) {
         const double *bt = a.betat_p + (size_t)c * N + rowbase + 16 * j + (!SC && tid >= 32 ? 8 : 0);
 #pragma unroll
         for (int k = 0; k < (SC ? 16 : 8); k++) btv[k] = bt[k];
     }
+    if (!SPLIT) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = s[17 * j + k];               // row_phys(16 j + k)
+        for (int k = 0; k < 16; k++) x[k] = s[17 * j + k];           // row_phys(16 j + k)
+    }
     r16_dif(x);
     sched_fence();
     if (PMD) {
@@ -911,7 +934,7 @@ template <bool PMD, bool SC = false> __global__ __launch_bounds__(ROWR_THREADS, 
         const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem;
 #pragma unroll
         for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);   // x[k] = ux, x[k + 8] = uy of bin ib + k
-        if (a.e1tab && ntrunk <= a.tmax) {
+        if (SPLIT || (a.e1tab && ntrunk <= a.tmax)) {       // (SPLIT: launched for plans with tables only; ntrunk <= tmax by the plan's bound on dz)
             const cplx *e1 = a.e1tab + (size_t)f * a.tmax * 256 + rowf, *e2 = a.e2tab + (size_t)f * a.tmax * 256 + ib;
             // (pmd_trunks_tab with the trunk loop outside the bins: a trunk's plate and row phasor are fetched once)
             for (int t = 0; t < ntrunk; t++) {
@@ -930,7 +953,15 @@ template <bool PMD, bool SC = false> __global__ __launch_bounds__(ROWR_THREADS, 
                     const cplx sy = csub(cmulc(u, s12), cscale(v, s11));
                     x[k] = make_double2(e.x * u.x - e.y * sx.y, e.x * u.y + e.y * sx.x);
                     x[k + 8] = make_double2(e.x * v.x - e.y * sy.y, e.x * v.y + e.y * sy.x);
+                    if (SPLIT && (k & 1)) sched_fence();
                 }
+            }
+            if (SPLIT) {
+                int o = ib;
+                pin(o);
+                const double *bt = a.betat_p + (size_t)c * N + rowbase + o;
+#pragma unroll
+                for (int k = 0; k < 8; k++) btv[k] = bt[k];
             }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -939,7 +970,7 @@ template <bool PMD, bool SC = false> __global__ __launch_bounds__(ROWR_THREADS, 
                 x[k + 8] = cmul(h, x[k + 8]);
                 sched_fence();
             }
-        } else {
+        } else if (!SPLIT) {
             const double *d1 = a.db1_p + (size_t)c * N + rowbase + ib;
             const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last;
             for (int k = 0; k < 8; k++) pmd_trunks(x[k], x[k + 8], btv[k], d1[k], brf, a.nplates, n0, ntrunk, dzb_first, dzb_last, a.lcorr, cur);
@@ -968,12 +999,28 @@ template <bool PMD, bool SC = false> __global__ __launch_bounds__(ROWR_THREADS, 
     sched_fence();
     r16_dit(x);
     sched_fence();
+    if (!SPLIT) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) s[17 * j + k] = x[k];
-    ROWR_SYNC();
+        for (int k = 0; k < 16; k++) s[17 * j + k] = x[k];
+        ROWR_SYNC();
+    }
     const cplx tb = tp[j];
+    if (SPLIT) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) x[k] = s[row_phys(j + 16 * k)];
+        for (int k = 0; k < 16; k++) sd[17 * j + k] = x[k].x;
+        ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k].x = sd[j + 17 * k];
+        ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) sd[17 * j + k] = x[k].y;
+        ROWR_SYNC();
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k].y = sd[j + 17 * k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) x[k] = s[row_phys(j + 16 * k)];
+    }
     sched_fence();
     if (PMD) lvl2_dit<16>(x, j, w8); else lvl2_dit<16>(x, j, w8, v1, v2, v3);
     sched_fence();
@@ -2193,6 +2240,7 @@ struct plx_ssfm {
     int rowr = 0;                  // k_row256r serves the step's row pass
     int row4k_split = 0;           // k_row4k<false, true>: the same for 4096-point rows
     int rowsm = 0;                 // k_rowsm<p2> serves it (rows of 32 / 64 / 128 points; dual polarisation without PMD, scalar)
+    int row256_split = 0;          // k_row256r<true, false, true>: the PMD form with tables at three waves per SIMD
     int rowg_split = 0;            // ... with the exchanges split into real and imaginary halves (three workgroups per CU)
     int rowreg = 0;                // k_rowreg<p2> serves it (dual polarisation, no PMD, rows of 512 / 1024 / 2048 points)
     cplx *d_tw2c = nullptr, *d_twmid = nullptr;
@@ -2277,7 +2325,7 @@ template <class K> static int blocks_per_cu(K, int, size_t) { return 2; }
 // not adopted (working copy, frame groups, grid sizing: profiles/r03_notes.md) are gone with their code.
 namespace {
 struct Tune {
-    int short_rows = 0, no_fuse = 0, p1 = -1, logW = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, no_pmd_tab = 0, rowr = 0, store_late = -1, row_rev = 0, rowg_split = 1, row4k_split = 1, rowsm = 1;
+    int short_rows = 0, no_fuse = 0, p1 = -1, logW = -1, col_threads = -1, no_row_split = 0, safe_landing = 0, no_pmd_tab = 0, rowr = 0, store_late = -1, row_rev = 0, rowg_split = 1, row4k_split = 1, rowsm = 1, row256_split = 1;
     double barrier_timeout_ms = 500.0;
     static int geti(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
     Tune()
@@ -2291,6 +2339,7 @@ struct Tune {
         safe_landing = geti("PLX_SSFM_SAFE_LANDING", 0);
         store_late = geti("PLX_SSFM_STORE_LATE", -1);  // fused sweep: stores after the next tile's landing; -1: where a launch has more than one team
         row_rev = geti("PLX_SSFM_ROW_REV", 1);         // 0: the row pass takes the listed frames in ascending order as well (A/B)
+        row256_split = geti("PLX_SSFM_ROW256_SPLIT", 1);  // 0: k_row256r<PMD> with both trunk forms and whole-sample exchanges also for plans with phasor tables (A/B, tests)
         rowsm = geti("PLX_SSFM_ROWSM", 1);              // 0: k_row for rows of 32 / 64 / 128 points everywhere; 2: k_rowsm wherever it applies (tests)
         row4k_split = geti("PLX_SSFM_ROW4K_SPLIT", 1);  // 0: k_row4k's whole-sample exchanges (two workgroups per CU; A/B, tests)
         rowg_split = geti("PLX_SSFM_ROWG_SPLIT", 1);   // 0: k_rowreg's whole-sample exchanges (two workgroups per CU; A/B, tests)
@@ -2543,6 +2592,7 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
     if (tune.rowr && a.dual && a.p1 == 8 && a.p2 == 8 && !P->row_split &&
         (a.pmd ? allow_lds(k_row256r<true>, ROWR_LDS) : allow_lds(k_row256r<false>, ROWR_LDS)) == hipSuccess) P->rowr = 1;
     if (tune.rowr && !a.dual && a.p1 == 8 && a.p2 == 8 && allow_lds(k_row256r<false, true>, ROWR_LDS_SC) == hipSuccess) P->rowr = 1;
+    if (P->rowr && a.dual && a.pmd && tune.row256_split && allow_lds(k_row256r<true, false, true>, ROWR_LDS) == hipSuccess) P->row256_split = 1;
     // Fused column sweep (k_colx16): the inverse column pass of step s, the step controller and the forward column
     // pass of step s+1 in ONE launch on a register/LDS-resident tile (2 sweeps over HBM per step instead of 3), for
     // dual-polarisation plans with 256 x (8+8) column tiles.  The tiles of a frame meet at a barrier inside the
@@ -2747,7 +2797,8 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
         return;
     }
     if (P->rowr && a.dual && !a.force && !a.hmul && !a.umat) {
-        if (a.pmd) PLX_LAUNCH(k_row256r<true>, dim3(128u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
+        if (a.pmd && P->row256_split && a.e1tab) PLX_LAUNCH((k_row256r<true, false, true>), dim3(128u, FC), dim3(ROWR_THREADS), ROWR_LDS - 4 * 272 * sizeof(double), st, a);
+        else if (a.pmd) PLX_LAUNCH(k_row256r<true>, dim3(128u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
         else PLX_LAUNCH(k_row256r<false>, dim3(128u, FC), dim3(ROWR_THREADS), ROWR_LDS, st, a);
         return;
     }
