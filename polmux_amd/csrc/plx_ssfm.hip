@@ -1046,11 +1046,14 @@ template <bool PMD, bool SC = false, bool SPLIT = false> __global__ __launch_bou
 // k_pmd_tab, or one exponential per bin and trunk) or inverse_pmd's matrix tables (inverse_pmd.m:130-141), and trade back.
 // LOGM: log2 of the row length (the stride of the column phasors); btv: betat (turns) of the lane's eight bins; row: the row's
 // index in the frame (the row phasors); ib: the first of the lane's eight bins within the row.
-template <int LOGM> __device__ __forceinline__ void pair_multiplier(const SsfmArgs &a, cplx *x, const double *btv, const cplx *ct, const FrameCtl *ctl,
+// TABONLY: the caller's plan has phasor tables (a linear db1) and no matrix tables are in play: only that trunk form is compiled
+// in (the general one, an exponential per bin and trunk inlined eight times, is what holds ~90 registers more), and the phases
+// are asked for here, behind the trunk loop (btv unused).
+template <int LOGM, bool TABONLY = false> __device__ __forceinline__ void pair_multiplier(const SsfmArgs &a, cplx *x, const double *btv, const cplx *ct, const FrameCtl *ctl,
                                                                     int f, int c, int row, size_t rowbase, int ib)
 {
     const size_t N = (size_t)1 << (a.p1 + a.p2);
-    if (a.umat) {
+    if (!TABONLY && a.umat) {
         // Uinv = conj(Hgvd) [conj(U11) -U12; conj(U12) U11] applied to [x; y]  (inverse_pmd.m:130-141; k_row's form, bin by bin)
         const cplx *um = a.umat + 3 * ((size_t)f * N + rowbase + ib);
 #pragma unroll
@@ -1070,7 +1073,7 @@ template <int LOGM> __device__ __forceinline__ void pair_multiplier(const SsfmAr
     const int ntrunk = ctl->ntrunk, n0 = ctl->ntot - ctl->nmem;
 #pragma unroll
     for (int k = 0; k < 8; k++) half_trade(x[k], x[k + 8]);
-    if (a.e1tab && ntrunk <= a.tmax) {
+    if (TABONLY || (a.e1tab && ntrunk <= a.tmax)) {
         const int N1 = 1 << a.p1;
         const cplx *e1 = a.e1tab + (size_t)f * a.tmax * N1 + row, *e2 = a.e2tab + ((size_t)f * a.tmax << LOGM) + ib;
         // (pmd_trunks_tab with the trunk loop outside the bins: a trunk's plate and row phasor are fetched once)
@@ -1090,15 +1093,24 @@ template <int LOGM> __device__ __forceinline__ void pair_multiplier(const SsfmAr
                 const cplx sy = csub(cmulc(u, s12), cscale(v, s11));
                 x[k] = make_double2(e.x * u.x - e.y * sx.y, e.x * u.y + e.y * sx.x);
                 x[k + 8] = make_double2(e.x * v.x - e.y * sy.y, e.x * v.y + e.y * sy.x);
+                if (TABONLY && (k & 1)) sched_fence();
             }
+        }
+        double bl[8];
+        if (TABONLY) {
+            int o = ib;
+            pin(o);
+            const double *bt = a.betat_p + (size_t)c * N + rowbase + o;
+#pragma unroll
+            for (int k = 0; k < 8; k++) bl[k] = bt[k];
         }
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            const cplx h = cexp_neg_turns_tab(btv[k] * cur, ct);
+            const cplx h = cexp_neg_turns_tab((TABONLY ? bl[k] : btv[k]) * cur, ct);
             x[k] = cmul(h, x[k]);
             x[k + 8] = cmul(h, x[k + 8]);
         }
-    } else {
+    } else if (!TABONLY) {
         const double *d1 = a.db1_p + (size_t)c * N + rowbase + ib;
         const double dzb_first = ctl->dzb_first, dzb_last = ctl->dzb_last;
         for (int k = 0; k < 8; k++) pmd_trunks(x[k], x[k + 8], btv[k], d1[k], brf, a.nplates, n0, ntrunk, dzb_first, dzb_last, a.lcorr, cur);
@@ -1344,7 +1356,7 @@ template <bool PAIR, bool SPLIT = false> __global__ __launch_bounds__(PAIR ? 512
 template <int LOGM, bool PAIR, bool SC = false, bool SPLIT = false> __global__ __launch_bounds__(ROWG_THREADS, SPLIT ? 3 : 2) void k_rowreg(SsfmArgs a)
 {
     static_assert(!(PAIR && SC), "a scalar plan has no second polarisation to pair with");
-    static_assert(!SPLIT || !PAIR, "the split exchange belongs to the one-polarisation forms");
+    // (PAIR && SPLIT: the PMD form for plans with phasor tables -- pair_multiplier<., true> -- which then fits three waves per SIMD too)
     // (twiddles of the outer level: the half table W_M^k where it fits beside two workgroups' rows -- 512 and 1024 points: 4 / 8
     //  KiB -- and the compact table, one more complex product per twiddle, for 2048 points)
     constexpr bool HALF_TW = LOGM <= 10;
@@ -1446,7 +1458,7 @@ template <int LOGM, bool PAIR, bool SC = false, bool SPLIT = false> __global__ _
     // (SPLIT without sharing: the sixteen phases are asked for in two halves AT the multiplier -- sixteen registers less across r16_dif,
     //  what the 168-register form of the 1024-point rows is short of)
     constexpr bool LATE_BT = SPLIT && !HALF_BINS;
-    if (!LATE_BT && !a.hmul && !(PAIR && a.umat)) {
+    if (!LATE_BT && !(PAIR && SPLIT) && !a.hmul && !(PAIR && a.umat)) {
         const double *bt = a.betat_p + (size_t)c * N + rowbase + ib;
 #pragma unroll
         for (int k = 0; k < (HALF_BINS ? 8 : 16); k++) btv[k] = bt[k];
@@ -1457,7 +1469,7 @@ template <int LOGM, bool PAIR, bool SC = false, bool SPLIT = false> __global__ _
     }
     r16_dif(x);
     if (PAIR && !a.hmul) {
-        pair_multiplier<LOGM>(a, x, btv, ct, ctl, f, c, (int)blockIdx.x * ROWS + rl, rowbase, ib);
+        pair_multiplier<LOGM, SPLIT>(a, x, btv, ct, ctl, f, c, (int)blockIdx.x * ROWS + rl, rowbase, ib);
     } else if (a.hmul) {
         int o16 = 16 * t;
         pin(o16);
@@ -2241,6 +2253,7 @@ struct plx_ssfm {
     int row4k_split = 0;           // k_row4k<false, true>: the same for 4096-point rows
     int rowsm = 0;                 // k_rowsm<p2> serves it (rows of 32 / 64 / 128 points; dual polarisation without PMD, scalar)
     int row256_split = 0;          // k_row256r<true, false, true>: the PMD form with tables at three waves per SIMD
+    int rowg_pair_split = 0;       // ... and the PMD form with phasor tables as well (k_rowreg<., true, false, true>)
     int rowg_split = 0;            // ... with the exchanges split into real and imaginary halves (three workgroups per CU)
     int rowreg = 0;                // k_rowreg<p2> serves it (dual polarisation, no PMD, rows of 512 / 1024 / 2048 points)
     cplx *d_tw2c = nullptr, *d_twmid = nullptr;
@@ -2558,6 +2571,10 @@ extern "C" int plx_ssfm_create_ex(plx_ssfm **out, const plx_ssfm_desc *desc, uin
                                          : (P->p2 == 9 ? allow_lds(k_rowreg<9, false, true, true>, ROWG_LDS_SPLIT(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10, false, true, true>, ROWG_LDS_SPLIT(1024))
                                                                                                                                        : allow_lds(k_rowreg<11, false, true, true>, ROWG_LDS_SPLIT(2048)));
             if (e2 == hipSuccess) P->rowg_split = 1;
+            if (P->rowg_split && a.dual &&
+                (P->p2 == 9 ? allow_lds(k_rowreg<9, true, false, true>, ROWG_LDS_SPLIT(512)) : P->p2 == 10 ? allow_lds(k_rowreg<10, true, false, true>, ROWG_LDS_SPLIT(1024))
+                                                                                                             : allow_lds(k_rowreg<11, true, false, true>, ROWG_LDS_SPLIT(2048))) == hipSuccess)
+                P->rowg_pair_split = 1;
         }
     }
     UP(P->d_gam, gam, double);
@@ -2762,7 +2779,11 @@ static void launch_row(plx_ssfm *P, const SsfmArgs &a, unsigned FC, hipStream_t 
     if (P->rowreg && a.dual) {
         const unsigned gx = (unsigned)(N1 / ((ROWG_THREADS / ((1 << a.p2) / 16)) / 2));
         const dim3 g(gx, FC), bs(ROWG_THREADS);
-        if (a.pmd || a.umat) {                   // the multiplier couples the polarisations: lanes i and i + 32 hold X and Y
+        if (a.pmd && !a.umat && a.e1tab && P->rowg_split && P->rowg_pair_split) {      // ... with phasor tables: the three-waves-per-SIMD form
+            if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, true, false, true>), g, bs, ROWG_LDS_SPLIT(512), st, a);
+            else if (a.p2 == 10) PLX_LAUNCH((k_rowreg<10, true, false, true>), g, bs, ROWG_LDS_SPLIT(1024), st, a);
+            else PLX_LAUNCH((k_rowreg<11, true, false, true>), g, bs, ROWG_LDS_SPLIT(2048), st, a);
+        } else if (a.pmd || a.umat) {            // the multiplier couples the polarisations: lanes i and i + 32 hold X and Y
             if (a.p2 == 9) PLX_LAUNCH((k_rowreg<9, true>), g, bs, ROWG_LDS(512), st, a);
             else if (a.p2 == 10) PLX_LAUNCH((k_rowreg<10, true>), g, bs, ROWG_LDS(1024), st, a);
             else PLX_LAUNCH((k_rowreg<11, true>), g, bs, ROWG_LDS(2048), st, a);
