@@ -99,6 +99,35 @@ int plx_ssfm_create(plx_ssfm **plan, const plx_ssfm_desc *desc);
  * stream (a one-team plan -- plx_ssfm_info: info[4] == info[3] -- whose receiver runs beside the next batch's fibre). */
 #define PLX_SSFM_SHARE_DEVICE 1u
 int plx_ssfm_create_ex(plx_ssfm **plan, const plx_ssfm_desc *desc, uint32_t flags);
+/* Plan-time tuning: which kernels and which split a plan takes where the library has more than one (the tests compare
+ * each kernel with the one it replaced; A/B measurements).  NOT read from the environment: a plan created without a
+ * tuning takes the defaults, which consult exactly two deployment variables -- PLX_SSFM_NO_FUSE=1 (every plan of the
+ * process on the barrier-free three-sweep step: several processes on one GPU) and PLX_SSFM_BARRIER_TIMEOUT_MS (the frame
+ * barrier's patience, default 500).  plx_ssfm_tuning_defaults fills the struct (always call it first: it sets `size`);
+ * plx_ssfm_create_tuned(..., tuning) builds one plan with it (NULL: the process-wide override if one is set, else the
+ * defaults); plx_ssfm_tuning_override(t) makes t the tuning of every plan created WITHOUT one from now on -- including
+ * the plans the gateway tier builds and caches (call plx_release_all() to drop those built earlier) -- NULL ends it.
+ * A test hook: deployments never call it.                                                                           */
+typedef struct plx_ssfm_tuning {
+    uint32_t size;           /* sizeof(plx_ssfm_tuning), set by plx_ssfm_tuning_defaults                              */
+    int32_t no_fuse;         /* 1: three sweeps per step (k_col_fwd, row pass, k_col_inv) instead of the fused sweep   */
+    int32_t short_rows;      /* 1: 2^20-sample frames on the 512 x 2048 split instead of 256 x 4096                    */
+    int32_t no_row_split;    /* 1: long rows keep both polarisations in one workgroup of k_row                         */
+    int32_t p1, logW;        /* forced log2 of the column length / of the tile width (-1: the plan's choice)           */
+    int32_t col_threads;     /* forced workgroup size of k_col_fwd / k_col_inv: 128 ... 1024 (-1: the plan's choice)   */
+    int32_t rowr;            /* 0: the LDS-resident k_row also where a register-form row pass applies                  */
+    int32_t rowsm;           /* 0: k_rowsm nowhere; 2: wherever it applies (default 1: where it is the faster kernel)  */
+    int32_t row256_split, row4k_split, rowg_split;   /* 0: whole-sample LDS exchanges in k_row256r<PMD> / k_row4k / k_rowreg */
+    int32_t no_pmd_tab;      /* 1: PMD plans form one exponential per bin and trunk instead of the phasor tables       */
+    int32_t store_late;      /* fused sweep: a tile's stores after the next tile's landing (-1: multi-team launches)   */
+    int32_t row_rev;         /* 0: the row pass takes the listed frames in ascending order as well                     */
+    int32_t safe_landing;    /* 1: the fused sweep also waits for its staged tile with vmcnt(0)                        */
+    int32_t reserved_[4];
+    double barrier_timeout_ms;
+} plx_ssfm_tuning;
+int plx_ssfm_tuning_defaults(plx_ssfm_tuning *tuning);
+int plx_ssfm_tuning_override(const plx_ssfm_tuning *tuning);
+int plx_ssfm_create_tuned(plx_ssfm **plan, const plx_ssfm_desc *desc, uint32_t flags, const plx_ssfm_tuning *tuning);
 int plx_ssfm_destroy(plx_ssfm *plan);
 /* brf.db0/theta/epsilon (fiber.m:266-276): host arrays [nplates x nsets]; set s is
  * used by frame f = s (nsets == 1: shared by all frames).                          */
@@ -165,6 +194,12 @@ int plx_ssfm_utilisation(plx_ssfm *plan, int64_t *frame_steps, int64_t *slots_li
  * [7] 1 = one polarisation per row workgroup, 2 = the register form for rows of 512 / 1024 / 2048 points (k_rowreg: 256
  * threads on 8 / 4 / 2 row-polarisations), 0 = both polarisations of its rows in one workgroup.  8 entries. */
 int plx_ssfm_info(plx_ssfm *plan, int32_t *info);
+/* Frame-barrier time-outs of this plan so far (each one made a propagate call return PLX_ERR_TIMEOUT and switched the plan
+ * to the barrier-free three-sweep step); rearm != 0 switches a plan that was created with the fused step back to it (the
+ * caller knows that the other kernel has left the GPU).  The gateway tier does this for its cached plans by itself: after
+ * a fallback the next 16 spans take three sweeps, then the fused step is tried again (32, 64, ... 4096 after further
+ * time-outs).  count may be NULL.                                                                                     */
+int plx_ssfm_barrier_timeouts(plx_ssfm *plan, int32_t *count, int rearm);
 /* Per-kernel timing of the step loop: with profiling enabled an event is recorded between consecutive launches of
  * plx_ssfm_propagate_dev; plx_ssfm_kernel_times returns, per kernel class (0 the column sweep that starts a step, 1 the row
  * pass, 2 k_col_inv, 3 control), the milliseconds and the number of ACTIVE launches accumulated over all propagate calls

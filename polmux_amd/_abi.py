@@ -33,6 +33,15 @@ class SsfmDesc(C.Structure):
                 ("manakov", C.c_int32), ("gam", C.c_void_p), ("betat", C.c_void_p), ("db1", C.c_void_p)]
 
 
+class SsfmTuning(C.Structure):
+    """plx_ssfm_tuning (include/polmux_hip.h): fill with plx_ssfm_tuning_defaults first (Binding.tuning does)."""
+    _fields_ = [("size", C.c_uint32), ("no_fuse", C.c_int32), ("short_rows", C.c_int32), ("no_row_split", C.c_int32),
+                ("p1", C.c_int32), ("logW", C.c_int32), ("col_threads", C.c_int32), ("rowr", C.c_int32), ("rowsm", C.c_int32),
+                ("row256_split", C.c_int32), ("row4k_split", C.c_int32), ("rowg_split", C.c_int32), ("no_pmd_tab", C.c_int32),
+                ("store_late", C.c_int32), ("row_rev", C.c_int32), ("safe_landing", C.c_int32), ("reserved_", C.c_int32 * 4),
+                ("barrier_timeout_ms", C.c_double)]
+
+
 class DspParams(C.Structure):
     _fields_ = [("workatbaudrate", C.c_int32), ("applynlr", C.c_int32), ("nlralpha", C.c_double),
                 ("power_mw", C.c_double), ("applypol", C.c_int32), ("polmethod", C.c_int32),
@@ -66,6 +75,9 @@ SIGNATURES = {
     "plx_fastexp_dev": [_vp, _vp, _sz, _vp],
     "plx_ssfm_create": [C.POINTER(_vp), C.POINTER(SsfmDesc)],
     "plx_ssfm_create_ex": [C.POINTER(_vp), C.POINTER(SsfmDesc), C.c_uint32],
+    "plx_ssfm_tuning_defaults": [C.POINTER(SsfmTuning)],
+    "plx_ssfm_tuning_override": [C.POINTER(SsfmTuning)],
+    "plx_ssfm_create_tuned": [C.POINTER(_vp), C.POINTER(SsfmDesc), C.c_uint32, C.POINTER(SsfmTuning)],
     "plx_ssfm_destroy": [_vp],
     "plx_ssfm_set_step_sequence": [_vp, _vp, C.c_int],
     "plx_ssfm_log_steps": [_vp, C.c_int],
@@ -77,6 +89,7 @@ SIGNATURES = {
     "plx_ssfm_stats": [_vp, C.POINTER(_i64), C.POINTER(_i64)],
     "plx_ssfm_info": [_vp, _vp],
     "plx_ssfm_utilisation": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)],
+    "plx_ssfm_barrier_timeouts": [_vp, C.POINTER(_i32), C.c_int],
     "plx_ssfm_profile": [_vp, C.c_int],
     "plx_ssfm_kernel_times": [_vp, _vp, _vp],
     "plx_matrix_ssfm": [_vp, _vp, _vp, _vp, C.POINTER(SsfmDesc), _vp, _vp, _vp, C.POINTER(_dbl),
@@ -138,11 +151,22 @@ class Binding:
             # loading ours first would bind torch to a second, different copy).
             import torch  # noqa: F401
         self.lib = C.CDLL(path)
+        _BINDINGS.append(self)
         self.lib.plx_last_error.restype = C.c_char_p
         for name, args in SIGNATURES.items():
             fn = getattr(self.lib, name)          # AttributeError if a symbol is missing
             fn.argtypes = args
             fn.restype = _RESTYPES.get(name, C.c_int)
+
+    def tuning(self, **fields):
+        """A plx_ssfm_tuning holding the defaults with `fields` changed (for plx_ssfm_create_tuned / plx_ssfm_tuning_override)."""
+        t = SsfmTuning()
+        self.call("plx_ssfm_tuning_defaults", C.byref(t))
+        for k, v in fields.items():
+            if k not in dict(SsfmTuning._fields_) or k in ("size", "reserved_"):
+                raise KeyError("plx_ssfm_tuning has no field %r" % k)
+            setattr(t, k, v)
+        return t
 
     def last_error(self):
         return self.lib.plx_last_error().decode("utf-8", "replace")
@@ -155,6 +179,12 @@ class Binding:
 
 
 _default = None
+_BINDINGS = []
+
+
+def bindings():
+    """Every loaded copy of the library in this process (the tests' tuning override addresses them all)."""
+    return list(_BINDINGS)
 
 
 def get():

@@ -11,7 +11,7 @@ static thread_local std::string g_err;
 void plx_set_error(const std::string &msg) { g_err = msg; }
 
 extern "C" const char *plx_last_error(void) { return g_err.c_str(); }
-extern "C" int plx_abi_version(void) { return 1001; }
+extern "C" int plx_abi_version(void) { return 1002; }
 
 extern "C" int plx_device_count(int *count)
 {

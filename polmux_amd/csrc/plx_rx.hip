@@ -944,8 +944,7 @@ static int launch_demux(int method, DemuxArgs &a, void *stream)
     if (method == PLX_DEMUX_CMA && a.taps <= 8 && a.dontskip && a.L >= 16 && a.L < ((int64_t)1 << 30) && (!a.single_pass || a.L - a.taps + 1 >= 1)) {
         // big batches travel four waves to a workgroup (see k_cma16); a few frames keep a CU per wave (sharing one costs the
         // recurrence ~14 %: 16 frames of 2^20 samples, 148 -> 170 ms)
-        static const int pack_min = getenv("PLX_CMA_PACK_MIN") ? atoi(getenv("PLX_CMA_PACK_MIN")) : kCmaPackMin;   // (read once)
-        const int thr = a.nframes >= pack_min ? CMA16_THREADS : 64, fpw = thr / 16;
+        const int thr = a.nframes >= kCmaPackMin ? CMA16_THREADS : 64, fpw = thr / 16;
         const unsigned gx = (unsigned)((a.nframes + fpw - 1) / fpw);
         PLX_LAUNCH(k_cma16, dim3(gx), dim3(thr), 0, stream, a);
     } else if (method == PLX_DEMUX_CMA) {

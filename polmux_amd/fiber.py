@@ -95,17 +95,24 @@ def fiber_tables(x, fls, nfc, dgdrms_symbols):
 
 
 _plans = {}
+_rearm = {}       # plan key -> [time-outs seen, unfused spans since, patience] (see fiber())
 
 
 def _plan_for(desc_key, build):
     plan = _plans.get(desc_key)
     if plan is None:
         if len(_plans) > 8:
-            for k in list(_plans):
-                _abi.get().call("plx_ssfm_destroy", _plans.pop(k)[0])
+            release_plans()
         plan = build()
         _plans[desc_key] = plan
     return plan
+
+
+def release_plans():
+    """Destroy the propagator plans fiber() keeps between calls (one per fibre type and grid)."""
+    for k in list(_plans):
+        _abi.get().call("plx_ssfm_destroy", _plans.pop(k)[0])
+    _rearm.clear()
 
 
 def fiber(x, flag=None, rng=None):
@@ -205,31 +212,64 @@ def fiber(x, flag=None, rng=None):
     # diagnostics for parity work (include/polmux_hip.h, plx_ssfm_set_step_sequence): x["_replay_dz"] = the step lengths to use
     # instead of nextstep's (fiber.m:682-715), x["_log_dz"] = True returns the device's own sequence in fiber.last["dz"]
     replay = x.get("_replay_dz")
-    if replay is not None:
-        rz = np.ascontiguousarray(replay, dtype=float)
-        lib.call("plx_ssfm_set_step_sequence", plan, rz.ctypes.data, rz.size)
-    if x.get("_log_dz"):
-        lib.call("plx_ssfm_log_steps", plan, 1 << 14)
-    if fls[1] == 1:
-        a, b, c_ = (np.ascontiguousarray(v, dtype=float) for v in (db0, theta, eps))
-        lib.call("plx_ssfm_set_birefringence", plan, a.ctypes.data, b.ctypes.data, c_.ctypes.data, 1)
     stream = torch.cuda.current_stream().cuda_stream
     if not fx.is_contiguous():
         fx = GSTATE.FIELDX = fx.contiguous()
     fy = GSTATE.FIELDY if isv else None
     if fy is not None and not fy.is_contiguous():
         fy = GSTATE.FIELDY = fy.contiguous()
-    lib.call("plx_ssfm_propagate_dev", plan, fx.data_ptr(), fy.data_ptr() if fy is not None else None, 1, stream)
-    first, ncyc = C.c_double(), C.c_int32()
-    lib.call("plx_ssfm_results", plan, 1, C.byref(first), C.byref(ncyc))
-    info = dict(firstdz=first.value, ncycle=ncyc.value)
-    if replay is not None:
-        lib.call("plx_ssfm_set_step_sequence", plan, None, 0)
-    if x.get("_log_dz"):
-        dzs = np.zeros(min(ncyc.value, 1 << 14))
-        lib.call("plx_ssfm_step_sequence", plan, 0, dzs.ctypes.data, dzs.size)
-        lib.call("plx_ssfm_log_steps", plan, 0)
-        info["dz"] = dzs
+    # fiber.m:372-389 always returns a field.  The fused sweep's frame barrier times out when another kernel holds part of
+    # the GPU (PLX_ERR_TIMEOUT: the field of that call is invalid and the plan has switched itself to the three-sweep step),
+    # so a plan on the fused step keeps a copy of the input to repeat the span from, as the gateway tier does from its
+    # staging buffer.  The replay list and the step log are armed for THIS call only, whatever happens in it.
+    pinfo = (C.c_int32 * 8)()
+    lib.call("plx_ssfm_info", plan, pinfo)
+    if pinfo[0] == 0:
+        # a cached plan that fell back after a time-out tries the fused step again after 16 (32, 64, ... 4096) spans, as the
+        # gateway tier does (include/polmux_hip.h, plx_ssfm_barrier_timeouts): the stall that caused it is usually gone
+        nto = C.c_int32()
+        lib.call("plx_ssfm_barrier_timeouts", plan, C.byref(nto), 0)
+        if nto.value > 0:
+            st = _rearm.setdefault(hash(key), [0, 0, 16])          # [time-outs seen, unfused spans since, patience]
+            if nto.value > st[0]:
+                st[:] = [nto.value, 0, min(4096, st[2] * 2 if st[0] else 16)]
+            st[1] += 1
+            if st[1] >= st[2]:
+                lib.call("plx_ssfm_barrier_timeouts", plan, None, 1)
+                lib.call("plx_ssfm_info", plan, pinfo)
+                st[1] = 0
+    keep = (fx.clone(), fy.clone() if fy is not None else None) if pinfo[0] == 1 else None
+    info = None
+    try:
+        if replay is not None:
+            rz = np.ascontiguousarray(replay, dtype=float)
+            lib.call("plx_ssfm_set_step_sequence", plan, rz.ctypes.data, rz.size)
+        if x.get("_log_dz"):
+            lib.call("plx_ssfm_log_steps", plan, 1 << 14)
+        if fls[1] == 1:
+            a, b, c_ = (np.ascontiguousarray(v, dtype=float) for v in (db0, theta, eps))
+            lib.call("plx_ssfm_set_birefringence", plan, a.ctypes.data, b.ctypes.data, c_.ctypes.data, 1)
+        try:
+            lib.call("plx_ssfm_propagate_dev", plan, fx.data_ptr(), fy.data_ptr() if fy is not None else None, 1, stream)
+        except _abi.PolmuxError as exc:
+            if exc.code != _abi.PLX_ERR_TIMEOUT or keep is None:
+                raise
+            fx.copy_(keep[0])
+            if fy is not None:
+                fy.copy_(keep[1])
+            lib.call("plx_ssfm_propagate_dev", plan, fx.data_ptr(), fy.data_ptr() if fy is not None else None, 1, stream)
+        first, ncyc = C.c_double(), C.c_int32()
+        lib.call("plx_ssfm_results", plan, 1, C.byref(first), C.byref(ncyc))
+        info = dict(firstdz=first.value, ncycle=ncyc.value)
+        if x.get("_log_dz"):
+            dzs = np.zeros(min(ncyc.value, 1 << 14))
+            lib.call("plx_ssfm_step_sequence", plan, 0, dzs.ctypes.data, dzs.size)
+            info["dz"] = dzs
+    finally:
+        if replay is not None:
+            lib.call("plx_ssfm_set_step_sequence", plan, None, 0)
+        if x.get("_log_dz"):
+            lib.call("plx_ssfm_log_steps", plan, 0)
     fiber.last = info                                                         # fiber.m:431 prints these
     if brf is not None:
         brf.update(lcorr=x["length"] / nplates, betat=t["betat"], db1=t["db1"], **info)

@@ -86,7 +86,7 @@ draw(16, 19, nlarge)
 for (lg, ntl, dual, nfc, flag, npl, L, P) in [(16, 6, 1, 1, "g-s-", 1, 8e4, 2.0), (16, 6, 1, 1, "gps-", 100, 8e4, 2.0), (16, 6, 1, 16, "gps-", 20, 2e4, 2.0),
                                               (20, 6, 1, 1, "g-s-", 1, 2e4, 2.0), (20, 6, 1, 1, "gps-", 10, 1e4, 2.0), (20, 6, 0, 1, "g-s-", 1, 1e4, 2.0),
                                               (16, 6, 0, 3, "g-sx", 1, 2e4, 2.0), (18, 6, 1, 1, "gps-", 10, 2e4, 2.0), (18, 6, 1, 1, "g-s-", 1, 2e4, 4.0),
-                                              (14, 4, 1, 1, "g-s-", 1, 8e4, 2.0), (13, 4, 0, 1, "g-s-", 1, 8e4, 2.0), (12, 4, 1, 1, "gps-", 5, 8e4, 2.0)]:
+                                              (14, 4, 1, 1, "g-s-", 1, 8e4, 2.0), (13, 5, 0, 1, "g-s-", 1, 8e4, 2.0), (12, 4, 1, 1, "gps-", 5, 8e4, 2.0)]:
     print("2^%d nt %d dual %d nfc %d %s plates %d L %g P %g: %s" % (lg, 1 << ntl, dual, nfc, flag, npl, L, P, run(lg, ntl, bool(dual), nfc, flag, npl, False, L, P)))
 
 # batches through the resident tier (teams, frame barrier, active list, chunked enqueue): frames of very different step counts

@@ -8,6 +8,7 @@ thread_local BlockCtx *t_ctx = nullptr;
 thread_local dim3 t_threadIdx, t_blockIdx;
 thread_local unsigned t_linear;
 int g_concurrency = 1;
+bool starve_barriers() { return std::getenv("PLX_EMU_STARVE") != nullptr; }
 
 namespace {
 struct Pool {

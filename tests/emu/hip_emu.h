@@ -63,6 +63,7 @@ extern thread_local unsigned t_linear;
 // number of workgroups executed concurrently (default 1).  Kernels whose workgroups wait for each
 // other inside a launch (frame barrier of the fused SSFM column sweep) need their partners alive.
 extern int g_concurrency;
+bool starve_barriers();   // PLX_EMU_STARVE is set: a test keeps a frame's workgroups from being alive together (the barrier must time out)
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()> &body);
 inline char *dyn_lds() { return t_ctx->lds.data(); }
 } // namespace emu

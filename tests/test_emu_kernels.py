@@ -51,12 +51,12 @@ def _tables(n, nt, fls, nplates, nfc=1):
 
 
 @pytest.mark.parametrize("tables", [True, False])
-def test_emu_matrix_ssfm_batch_with_pmd(emu, oracle, monkeypatch, tables):
+def test_emu_matrix_ssfm_batch_with_pmd(emu, oracle, tune, tables):
     """two frames with their own PMD realisation and launch power advance in lock-step launches -- with the trunk phasors from
     the row / column tables of k_pmd_tab (db1 linear in the frequency index: the default) and with one exponential per bin and
     trunk (PLX_SSFM_NO_PMD_TAB=1, also what a plan with a non-linear db1 takes)"""
     if not tables:
-        monkeypatch.setenv("PLX_SSFM_NO_PMD_TAB", "1")
+        tune.setenv("PLX_SSFM_NO_PMD_TAB", "1")
     n, nt, nplates, L = 512, 8, 6, 2e4
     fls = [1, 1, 1, 0]
     betat, db1 = _tables(n, nt, fls, nplates)
@@ -307,7 +307,7 @@ def test_emu_evm(emu):
     np.testing.assert_allclose(out, (np.abs(sym - hat) ** 2).mean(axis=(1, 2)), rtol=1e-13)
 
 
-def test_emu_sweep_variants(emu, oracle, monkeypatch):
+def test_emu_sweep_variants(emu, oracle, tune):
     """The fused column sweep (default at this geometry: k_colx16 with its per-frame barrier), the barrier-free
     three-sweep step (PLX_SSFM_NO_FUSE) and a 16 x 256 split (PLX_SSFM_P1=4: 256-point rows through the general
     k_row) give the same fields and step counts."""
@@ -322,12 +322,12 @@ def test_emu_sweep_variants(emu, oracle, monkeypatch):
     for env in ({}, {"PLX_EMU_CUS": "1"}, {"PLX_SSFM_P1": "4"}):
         nf = 1 if ("PLX_SSFM_P1" in env or "PLX_SSFM_NO_FUSE" in env) else 3
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tune.setenv(k, v)
         d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=nf)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
         for k in env:
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         ux = _il(np.stack([f[0] for f in fields[:nf]])); uy = _il(np.stack([f[1] for f in fields[:nf]]))
         emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), nf, None)
         ncyc = np.zeros(nf, np.int32)
@@ -342,23 +342,23 @@ def test_emu_sweep_variants(emu, oracle, monkeypatch):
             assert np.abs(gy[f] - oy[:, 0]).max() < 1e-11 * np.abs(oy).max()
 
 
-def test_emu_register_form_row_pass(emu, oracle, monkeypatch):
+def test_emu_register_form_row_pass(emu, oracle, tune):
     """256 x 256 frames without PMD take the register form of the row pass (k_row256r: one wave per 2 rows x 2 polarisations,
     the multiplier shared between the wave's halves); PLX_SSFM_ROWR=0 keeps the LDS-resident k_row.  Both against the oracle,
     and against each other (they differ by the rounding of the inter-pass twiddles only)."""
     n, nt, L = 65536, 16, 7e2
     fls = [1, 0, 1, 0]
     betat, db1 = _tables(n, nt, fls, 1)
-    monkeypatch.setenv("PLX_SSFM_NO_FUSE", "1")    # (three-sweep step: the emulated frame barrier of the fused sweep is slow and not under test here)
+    tune.setenv("PLX_SSFM_NO_FUSE", "1")    # (three-sweep step: the emulated frame barrier of the fused sweep is slow and not under test here)
     fields = [_qpsk_field(n, nt, p)[:2] for p in (9.0,)]
     ref = [oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0]) for f in fields]
     got = {}
     for mode in ("1",):      # ("0", the same frame through k_row, is compared on the GPU: test_sentinel_landing_... 'ldsrow', test_register_form_row_pass_with_pmd_vs_oracle_three_ways)
-        monkeypatch.setenv("PLX_SSFM_ROWR", mode)
+        tune.setenv("PLX_SSFM_ROWR", mode)
         d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=1)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
-        monkeypatch.delenv("PLX_SSFM_ROWR")
+        tune.delenv("PLX_SSFM_ROWR")
         info = (C.c_int32 * 8)()
         emu.call("plx_ssfm_info", plan, info)
         assert info[6] == 64                                     # one wave per 2 rows x 2 polarisations: k_row256r
@@ -377,13 +377,13 @@ def test_emu_register_form_row_pass(emu, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("tables", [True])      # (False = one exponential per bin and trunk: on the GPU, test_register_form_row_pass_with_pmd_vs_oracle_three_ways)
-def test_emu_register_form_row_pass_with_pmd(emu, oracle, monkeypatch, tables):
+def test_emu_register_form_row_pass_with_pmd(emu, oracle, tune, tables):
     """k_row256r<PMD>: the wave's halves trade so that a lane holds both polarisations of eight bins, then the waveplate trunks
     of matrix_step (fiber.m:907-933) with the phasor tables of k_pmd_tab or one exponential per bin and trunk
     (PLX_SSFM_NO_PMD_TAB=1).  256 x 256 frame with its own waveplates, against the oracle and against k_row's PMD branch."""
     if not tables:
-        monkeypatch.setenv("PLX_SSFM_NO_PMD_TAB", "1")
-    monkeypatch.setenv("PLX_SSFM_NO_FUSE", "1")    # (three-sweep step, as in test_emu_register_form_row_pass)
+        tune.setenv("PLX_SSFM_NO_PMD_TAB", "1")
+    tune.setenv("PLX_SSFM_NO_FUSE", "1")    # (three-sweep step, as in test_emu_register_form_row_pass)
     n, nt, nplates, L = 65536, 16, 5, 8e2
     fls = [1, 1, 1, 0]
     betat, db1 = _tables(n, nt, fls, nplates)
@@ -394,11 +394,11 @@ def test_emu_register_form_row_pass_with_pmd(emu, oracle, monkeypatch, tables):
     assert rc == 0 and onc >= 2
     got = {}
     for mode in ("1",):      # ("0", k_row's PMD branch on the same frame: on the GPU, test_register_form_row_pass_with_pmd_vs_oracle_three_ways)
-        monkeypatch.setenv("PLX_SSFM_ROWR", mode)
+        tune.setenv("PLX_SSFM_ROWR", mode)
         d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 5e2, 5e-3, betat, db1, nplates=nplates, frames=1)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
-        monkeypatch.delenv("PLX_SSFM_ROWR")
+        tune.delenv("PLX_SSFM_ROWR")
         emu.call("plx_ssfm_set_birefringence", plan, _vp(brf[0]), _vp(brf[1]), _vp(brf[2]), 1)
         ux = _il(fx[None]); uy = _il(fy[None])
         emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 1, None)
@@ -412,7 +412,7 @@ def test_emu_register_form_row_pass_with_pmd(emu, oracle, monkeypatch, tables):
         got[mode] = (gx.copy(), gy.copy())
 
 
-def test_emu_fused_sweep_exact_nonlinear_step(emu, oracle, monkeypatch):
+def test_emu_fused_sweep_exact_nonlinear_step(emu, oracle, tune):
     """The fused sweep's rare path on a one-CU device (one team walks both frames): the '--s-' exact single step
     (fiber.m:172-174: nonlinear phases of radians, so the Kerr step takes the full-range sincos through the exchange buffer)
     and a stale frame list (a batch under 64 frames rebuilds it once per chunk: the second launch meets finished frames) --
@@ -425,12 +425,12 @@ def test_emu_fused_sweep_exact_nonlinear_step(emu, oracle, monkeypatch):
     got = []
     for env in ({"PLX_EMU_CUS": "1"}, {"PLX_SSFM_NO_FUSE": "1"}):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tune.setenv(k, v)
         d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-3], L, np.inf, betat, db1, frames=2)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
         for k in env:
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         ux = _il(np.stack([f[0] for f in fields])); uy = _il(np.stack([f[1] for f in fields]))
         emu.call("plx_ssfm_propagate_dev", plan, _vp(ux), _vp(uy), 2, None)
         ncyc = np.zeros(2, np.int32)
@@ -448,7 +448,7 @@ def test_emu_fused_sweep_exact_nonlinear_step(emu, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("flag", ["g-s-", "--s-"])
-def test_emu_fused_sweep_scalar_plan(emu, oracle, monkeypatch, flag):
+def test_emu_fused_sweep_scalar_plan(emu, oracle, tune, flag):
     """k_colx16<false>: scalar_ssfm (fiber.m:557-636) without XPM on the fused column sweep -- sixteen columns of the one field
     to a tile, max |u|^2 at the frame barrier, nl_step on the lane's own points; two 'sepfields' channels, three frames at
     different powers claimed by the teams of a one-CU device.  'g-s-': against oracle.scalar_ssfm and the three-sweep step;
@@ -464,12 +464,12 @@ def test_emu_fused_sweep_scalar_plan(emu, oracle, monkeypatch, flag):
     got = []
     for env in ({"PLX_EMU_CUS": "1"}, {"PLX_SSFM_NO_FUSE": "1"}):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tune.setenv(k, v)
         d = _desc(n, nfc, 0, fls, L, 4.6e-5, gam, dzmax, dph, betat, db1, frames=3)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
         for k in env:
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         info = (C.c_int32 * 8)()
         emu.call("plx_ssfm_info", plan, info)
         assert info[0] == (0 if "PLX_SSFM_NO_FUSE" in env else 1) and info[1] == 8 and info[4] == (0 if "PLX_SSFM_NO_FUSE" in env else nfc)
@@ -488,22 +488,22 @@ def test_emu_fused_sweep_scalar_plan(emu, oracle, monkeypatch, flag):
         assert np.abs(np.angle(got[0][0][2][0] * np.conj(frames[2][:, 0]))).max() > 0.5      # radians of nonlinear phase
 
 
-def test_emu_long_rows_compact_twiddles(emu, oracle, monkeypatch):
+def test_emu_long_rows_compact_twiddles(emu, oracle, tune):
     """4096-point rows (the row pass of 2^20-sample frames: one polarisation per workgroup, compact twiddle table W^{4k} +
     four fine factors, plx_fft.h row_tw) on a 4 x 4096 split of a 2^14 frame: field and step count against the oracle."""
     n, nt, L = 16384, 64, 6e2                       # 4 x 4096 split, two steps
     fls = [1, 0, 1, 0]
     betat, db1 = _tables(n, nt, fls, 1)
     f = _qpsk_field(n, nt, 6.0)
-    monkeypatch.setenv("PLX_SSFM_P1", "2")
-    monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")   # (fewer, wider column workgroups: fewer emulated threads)
-    monkeypatch.setenv("PLX_SSFM_LOGW", "6")
+    tune.setenv("PLX_SSFM_P1", "2")
+    tune.setenv("PLX_SSFM_COL_THREADS", "128")   # (fewer, wider column workgroups: fewer emulated threads)
+    tune.setenv("PLX_SSFM_LOGW", "6")
     d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=1)
     plan = C.c_void_p()
     emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
-    monkeypatch.delenv("PLX_SSFM_P1")
-    monkeypatch.delenv("PLX_SSFM_COL_THREADS")
-    monkeypatch.delenv("PLX_SSFM_LOGW")
+    tune.delenv("PLX_SSFM_P1")
+    tune.delenv("PLX_SSFM_COL_THREADS")
+    tune.delenv("PLX_SSFM_LOGW")
     info = (C.c_int32 * 8)()
     emu.call("plx_ssfm_info", plan, info)
     assert list(info)[:3] == [0, 2, 12] and info[7] == 1          # three sweeps, 4 x 4096, one polarisation per row workgroup
@@ -519,13 +519,13 @@ def test_emu_long_rows_compact_twiddles(emu, oracle, monkeypatch):
 
 
 @pytest.mark.parametrize("tables", [True, False])
-def test_emu_long_rows_both_polarisations_pmd(emu, oracle, monkeypatch, tables):
+def test_emu_long_rows_both_polarisations_pmd(emu, oracle, tune, tables):
     """k_row4k<true>: 4096-point rows of a PMD plan -- both polarisations of a row in one 512-thread workgroup, lanes i and
     i + 32 of a wave trade halves around the waveplate trunks of matrix_step (fiber.m:907-933), phasor tables of k_pmd_tab or
     one exponential per bin and trunk (PLX_SSFM_NO_PMD_TAB=1).  4 x 4096 split of a 2^14 frame with its own waveplates against
     the oracle, and against the 2048-point rows of k_row's PMD branch (PLX_SSFM_SHORT_ROWS=1)."""
     if not tables:
-        monkeypatch.setenv("PLX_SSFM_NO_PMD_TAB", "1")
+        tune.setenv("PLX_SSFM_NO_PMD_TAB", "1")
     n, nt, nplates, L = 16384, 64, 4, 9e2
     fls = [1, 1, 1, 0]
     betat, db1 = _tables(n, nt, fls, nplates)
@@ -536,14 +536,14 @@ def test_emu_long_rows_both_polarisations_pmd(emu, oracle, monkeypatch, tables):
     assert rc == 0 and onc >= 3
     got = {}
     for short in ((False, True) if tables else (False,)):      # (the 8 x 2048 comparison once: it doubles the emulated work)
-        monkeypatch.setenv("PLX_SSFM_P1", "3" if short else "2")
-        monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
-        monkeypatch.setenv("PLX_SSFM_LOGW", "6")
+        tune.setenv("PLX_SSFM_P1", "3" if short else "2")
+        tune.setenv("PLX_SSFM_COL_THREADS", "128")
+        tune.setenv("PLX_SSFM_LOGW", "6")
         d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, nplates=nplates, frames=1)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
         for k in ("PLX_SSFM_P1", "PLX_SSFM_COL_THREADS", "PLX_SSFM_LOGW"):
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         info = (C.c_int32 * 8)()
         emu.call("plx_ssfm_info", plan, info)
         assert list(info)[:3] == ([0, 3, 11] if short else [0, 2, 12])
@@ -564,7 +564,7 @@ def test_emu_long_rows_both_polarisations_pmd(emu, oracle, monkeypatch, tables):
 
 
 @pytest.mark.parametrize("nsymb,nt", [(256, 64), (64, 64), (256, 8)])
-def test_emu_inverse_pmd_long_rows(emu, oracle, monkeypatch, nsymb, nt):
+def test_emu_inverse_pmd_long_rows(emu, oracle, tune, nsymb, nt):
     """inverse_pmd's matrix tables (inverse_pmd.m:130-141) through the register-form row passes: the plan of plx_pmdinv is a
     PMD-type plan, so k_row4k<true> (4 x 4096 split) / k_rowreg<., true> (4 x 1024, 4 x 512) apply (Hgvd U)^H bin by bin after
     the halves' trade.  Against oracle/pmdinv.py."""
@@ -579,13 +579,13 @@ def test_emu_inverse_pmd_long_rows(emu, oracle, monkeypatch, nsymb, nt):
     db1 = dgd / nplates / 10.0 * omega
     ux, uy, _, _ = synth.pdm_qpsk_field(nsymb, nt, 2.0)
     fx = np.stack([ux]); fy = np.stack([1j * np.roll(uy, 7)])
-    monkeypatch.setenv("PLX_SSFM_P1", "2")
-    monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
-    monkeypatch.setenv("PLX_SSFM_LOGW", "6")
+    tune.setenv("PLX_SSFM_P1", "2")
+    tune.setenv("PLX_SSFM_COL_THREADS", "128")
+    tune.setenv("PLX_SSFM_LOGW", "6")
     plan = C.c_void_p()
     emu.call("plx_pmdinv_create", C.byref(plan), n, 1)
     for k in ("PLX_SSFM_P1", "PLX_SSFM_COL_THREADS", "PLX_SSFM_LOGW"):
-        monkeypatch.delenv(k)
+        tune.delenv(k)
     ntr = np.array([nplates], dtype=np.int32)
     db0, th, ep = (np.ascontiguousarray(v[None]) for v in sets)
     lc = np.array([L / nplates])
@@ -602,7 +602,7 @@ def test_emu_inverse_pmd_long_rows(emu, oracle, monkeypatch, nsymb, nt):
 
 
 @pytest.mark.parametrize("logm", [9, 10, 11])
-def test_emu_register_form_rows_512_to_2048(emu, oracle, monkeypatch, logm):
+def test_emu_register_form_rows_512_to_2048(emu, oracle, tune, logm):
     """k_rowreg<9 / 10 / 11>: rows of 512, 1024 and 2048 points (frames of 2^17 ... 2^19 samples on the 256-row split; 2^18 is the
     size Run_my_PDM_QPSK.m:21-24 ships with) as three register levels -- radix 16, radix 2 / 4 / 8 at stride 16, radix 16 -- on a
     4 x M split, against the oracle and against the LDS-resident k_row (PLX_SSFM_ROWR=0)."""
@@ -615,16 +615,16 @@ def test_emu_register_form_rows_512_to_2048(emu, oracle, monkeypatch, logm):
     assert rc == 0 and onc >= 3
     got = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("PLX_SSFM_ROWR", mode)
-        monkeypatch.setenv("PLX_SSFM_P1", "2")
-        monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
-        monkeypatch.setenv("PLX_SSFM_LOGW", "6")
+        tune.setenv("PLX_SSFM_ROWR", mode)
+        tune.setenv("PLX_SSFM_P1", "2")
+        tune.setenv("PLX_SSFM_COL_THREADS", "128")
+        tune.setenv("PLX_SSFM_LOGW", "6")
         nf = 2 if logm == 9 else 1                             # (a two-frame batch where the emulated work is small)
         d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=nf)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
         for k in ("PLX_SSFM_ROWR", "PLX_SSFM_P1", "PLX_SSFM_COL_THREADS", "PLX_SSFM_LOGW"):
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         info = (C.c_int32 * 8)()
         emu.call("plx_ssfm_info", plan, info)
         assert list(info)[:3] == [0, 2, logm] and (info[7] == 2) == (mode == "1")
@@ -643,7 +643,7 @@ def test_emu_register_form_rows_512_to_2048(emu, oracle, monkeypatch, logm):
 
 
 @pytest.mark.parametrize("logm,scalar", [(5, False), (6, False), (7, False), (5, True), (7, True)])
-def test_emu_register_form_small_rows(emu, oracle, monkeypatch, logm, scalar):
+def test_emu_register_form_small_rows(emu, oracle, tune, logm, scalar):
     """k_rowsm<5 / 6 / 7>: rows of 32, 64 and 128 points (frames of 2^13 ... 2^15 samples on the 256-row split: the sizes of the
     reference's own examples) -- R = 2 / 4 / 8 threads per row and polarisation, sixteen points each, one radix-R set per
     i = j + R par, one exchange in real / imaginary halves, r16 -- on a 32 x M split: a dual-polarisation batch of two frames
@@ -663,17 +663,17 @@ def test_emu_register_form_small_rows(emu, oracle, monkeypatch, logm, scalar):
         f = _qpsk_field(n, nt, 6.0)
         rc, fd, onc, ox, oy = oracle.matrix_ssfm(f[0], f[1], betat, db1, 4e2, 5e-3, [1.3e-6], 4.6e-5, L, 1, 0, fls, [0.0], [0.0], [0.0])
     assert onc >= 3
-    monkeypatch.setenv("PLX_SSFM_ROWSM", "2")              # (also for the short dual rows, which take k_row by default)
+    tune.setenv("PLX_SSFM_ROWSM", "2")              # (also for the short dual rows, which take k_row by default)
     for mode in ("1", "0"):
-        monkeypatch.setenv("PLX_SSFM_ROWR", mode)
-        monkeypatch.setenv("PLX_SSFM_P1", "5")
-        monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
+        tune.setenv("PLX_SSFM_ROWR", mode)
+        tune.setenv("PLX_SSFM_P1", "5")
+        tune.setenv("PLX_SSFM_COL_THREADS", "128")
         d = _desc(n, 2, 0, fls, L, 4.6e-5, gam, 4e2, 5e-3, betat, db1, frames=1) if scalar else \
             _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=2)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
         for k in ("PLX_SSFM_ROWR", "PLX_SSFM_P1", "PLX_SSFM_COL_THREADS"):
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         info = (C.c_int32 * 8)()
         emu.call("plx_ssfm_info", plan, info)
         assert list(info)[:3] == [0, 5, logm] and (info[7] == 2 and info[6] == 64) == (mode == "1")
@@ -701,7 +701,7 @@ def test_emu_register_form_small_rows(emu, oracle, monkeypatch, logm, scalar):
 
 
 @pytest.mark.parametrize("logm", [9, 11, 12])
-def test_emu_register_form_rows_scalar_plan(emu, oracle, monkeypatch, logm):
+def test_emu_register_form_rows_scalar_plan(emu, oracle, tune, logm):
     """k_rowreg<., false, true>: the scalar plan's rows of 512 / 2048 points (every row-polarisation of the workgroup is a row of
     the one field), two 'sepfields' channels with XPM, 4 x M split (8 x M for 512 points: eight rows to a workgroup) against
     oracle.scalar_ssfm.  4096 points: k_row4k<false> with one workgroup per row and frame-channel."""
@@ -716,14 +716,14 @@ def test_emu_register_form_rows_scalar_plan(emu, oracle, monkeypatch, logm):
     gam = [1.3e-6, 1.25e-6][:nfc]
     ofd, onc, ou = oracle.scalar_ssfm(u, betat, 4e2, 5e-3, gam, 4.6e-5, L, fls)
     assert onc >= 3
-    monkeypatch.setenv("PLX_SSFM_P1", str(p1))
-    monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
-    monkeypatch.setenv("PLX_SSFM_LOGW", "6")
+    tune.setenv("PLX_SSFM_P1", str(p1))
+    tune.setenv("PLX_SSFM_COL_THREADS", "128")
+    tune.setenv("PLX_SSFM_LOGW", "6")
     d = _desc(n, nfc, 0, fls, L, 4.6e-5, gam, 4e2, 5e-3, betat, db1, frames=1)
     plan = C.c_void_p()
     emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
     for k in ("PLX_SSFM_P1", "PLX_SSFM_COL_THREADS", "PLX_SSFM_LOGW"):
-        monkeypatch.delenv(k)
+        tune.delenv(k)
     info = (C.c_int32 * 8)()
     emu.call("plx_ssfm_info", plan, info)
     assert list(info)[:3] == [0, p1, logm] and info[7] == (2 if logm < 12 else 1)
@@ -738,12 +738,12 @@ def test_emu_register_form_rows_scalar_plan(emu, oracle, monkeypatch, logm):
 
 
 @pytest.mark.parametrize("logm,tables", [(9, True), (10, True), (10, False), (11, True)])
-def test_emu_register_form_rows_both_polarisations_pmd(emu, oracle, monkeypatch, logm, tables):
+def test_emu_register_form_rows_both_polarisations_pmd(emu, oracle, tune, logm, tables):
     """k_rowreg<., true>: rows of 512 / 1024 / 2048 points of a PMD plan -- lanes i and i + 32 of every wave hold the same thread
     of the X and the Y row and trade halves around the waveplate trunks (pair_multiplier, shared with k_row4k<true>).  4 x M
     split with its own waveplates against the oracle and against k_row's PMD branch (PLX_SSFM_ROWR=0)."""
     if not tables:
-        monkeypatch.setenv("PLX_SSFM_NO_PMD_TAB", "1")
+        tune.setenv("PLX_SSFM_NO_PMD_TAB", "1")
     M = 1 << logm
     n, nt, nplates, L = 4 * M, (16 if logm == 10 else 32), 4, 9e2
     fls = [1, 1, 1, 0]
@@ -755,15 +755,15 @@ def test_emu_register_form_rows_both_polarisations_pmd(emu, oracle, monkeypatch,
     assert rc == 0 and onc >= 3
     got = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("PLX_SSFM_ROWR", mode)
-        monkeypatch.setenv("PLX_SSFM_P1", "2")
-        monkeypatch.setenv("PLX_SSFM_COL_THREADS", "128")
-        monkeypatch.setenv("PLX_SSFM_LOGW", "6")
+        tune.setenv("PLX_SSFM_ROWR", mode)
+        tune.setenv("PLX_SSFM_P1", "2")
+        tune.setenv("PLX_SSFM_COL_THREADS", "128")
+        tune.setenv("PLX_SSFM_LOGW", "6")
         d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, nplates=nplates, frames=1)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
         for k in ("PLX_SSFM_ROWR", "PLX_SSFM_P1", "PLX_SSFM_COL_THREADS", "PLX_SSFM_LOGW"):
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         info = (C.c_int32 * 8)()
         emu.call("plx_ssfm_info", plan, info)
         assert list(info)[:3] == [0, 2, logm] and (info[7] == 2) == (mode == "1")
@@ -782,7 +782,7 @@ def test_emu_register_form_rows_both_polarisations_pmd(emu, oracle, monkeypatch,
     assert not np.array_equal(got["1"][0], got["0"][0])
 
 
-def test_emu_frame_barrier_timeout_aborts_cleanly(emu, monkeypatch):
+def test_emu_frame_barrier_timeout_aborts_cleanly(emu, tune):
     """A fused-sweep frame whose workgroups are not co-resident (here: the emulator runs ONE workgroup at a time) must
     end in a clean error, never a hang: the barrier times out (wall clock), raises the sticky abort word, nothing is
     stored or advanced after it, and propagate reports PLX_ERR_TIMEOUT.  The timeout hits in the first launch, before any
@@ -791,16 +791,16 @@ def test_emu_frame_barrier_timeout_aborts_cleanly(emu, monkeypatch):
     fls = [1, 0, 1, 0]
     betat, db1 = _tables(n, nt, fls, 1)
     f = _qpsk_field(n, nt, 6.0)
-    monkeypatch.setenv("PLX_SSFM_BARRIER_TIMEOUT_MS", "30")
+    tune.setenv("PLX_SSFM_BARRIER_TIMEOUT_MS", "30")
     d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 4e2, 5e-3, betat, db1, frames=2)
     plan = C.c_void_p()
     emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
-    monkeypatch.delenv("PLX_SSFM_BARRIER_TIMEOUT_MS")
+    tune.delenv("PLX_SSFM_BARRIER_TIMEOUT_MS")
     ux = _il(np.stack([f[0], f[0]])); uy = _il(np.stack([f[1], f[1]]))
     ux0, uy0 = ux.copy(), uy.copy()
-    monkeypatch.setenv("PLX_EMU_STARVE", "1")
+    tune.setenv("PLX_EMU_STARVE", "1")
     rc = emu.lib.plx_ssfm_propagate_dev(plan, _vp(ux), _vp(uy), 2, None)
-    monkeypatch.delenv("PLX_EMU_STARVE")
+    tune.delenv("PLX_EMU_STARVE")
     assert rc == -5                                     # PLX_ERR_TIMEOUT
     assert b"frame barrier timed out" in emu.lib.plx_last_error()
     np.testing.assert_array_equal(ux, ux0)
@@ -810,11 +810,24 @@ def test_emu_frame_barrier_timeout_aborts_cleanly(emu, monkeypatch):
     info = (C.c_int32 * 8)()
     emu.call("plx_ssfm_info", plan, info)
     assert info[0] == 0
-    monkeypatch.setenv("PLX_EMU_STARVE", "1")
+    tune.setenv("PLX_EMU_STARVE", "1")
     rc = emu.lib.plx_ssfm_propagate_dev(plan, _vp(ux), _vp(uy), 2, None)
-    monkeypatch.delenv("PLX_EMU_STARVE")
+    tune.delenv("PLX_EMU_STARVE")
     assert rc == 0 and np.abs(ux - ux0).max() > 0
     np.testing.assert_array_equal(ux[0], ux[1])
+    three = ux.copy()
+    # the time-out is on record, and the caller can switch the plan back once the GPU is its own again: the fused step then
+    # reproduces the three-sweep result (frames co-resident this time)
+    cnt = C.c_int32(-1)
+    emu.call("plx_ssfm_barrier_timeouts", plan, C.byref(cnt), 0)
+    emu.call("plx_ssfm_info", plan, info)
+    assert cnt.value == 1 and info[0] == 0
+    emu.call("plx_ssfm_barrier_timeouts", plan, None, 1)
+    emu.call("plx_ssfm_info", plan, info)
+    assert info[0] == 1
+    ux2, uy2 = ux0.copy(), uy0.copy()
+    emu.call("plx_ssfm_propagate_dev", plan, _vp(ux2), _vp(uy2), 2, None)
+    assert np.abs(ux2 - three).max() < 1e-12 * np.abs(three).max()
     emu.call("plx_ssfm_destroy", plan)
 
 
@@ -1086,7 +1099,7 @@ def test_emu_poldemux_driver_gateways(emu, oracle):
         np.testing.assert_allclose(yr + 1j * yi, oy, atol=1e-11)
 
 
-def test_emu_step_sequence_replay_and_log(emu, oracle, monkeypatch):
+def test_emu_step_sequence_replay_and_log(emu, oracle, tune):
     """plx_ssfm_set_step_sequence / plx_ssfm_log_steps (the diagnostics behind the config[2] parity test), fused sweep and
     three-sweep step: a plan that replays the oracle's list of step lengths makes the oracle's steps (same ncycle, first step
     bit-equal, field to 1e-12); left to itself it logs a sequence that agrees with the oracle's to 1e-12 on this
@@ -1100,12 +1113,12 @@ def test_emu_step_sequence_replay_and_log(emu, oracle, monkeypatch):
     assert rc == 0 and onc == len(odz) and 4 <= onc <= 12
     for env in ({"PLX_EMU_CUS": "1"}, {"PLX_SSFM_NO_FUSE": "1"}):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tune.setenv(k, v)
         d = _desc(n, 1, 1, fls, L, 4.6e-5, [1.3e-6], 2e3, 0.08, betat, db1)
         plan = C.c_void_p()
         emu.call("plx_ssfm_create", C.byref(plan), C.byref(d))
         for k in env:
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         nc, fd = np.zeros(1, np.int32), np.zeros(1)
 
         def run():

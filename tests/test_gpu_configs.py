@@ -291,7 +291,7 @@ def test_power_ladder_batch_every_frame_keeps_the_reference_step_count(lib, orac
 
 
 @pytest.mark.parametrize("nspans", [3, 40])
-def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monkeypatch, nspans):
+def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, tune, nspans):
     """Config[4]'s shape: 8 frames of 2^20 samples on a steep launch-power ladder, three spans -- and the FORTY spans
     config[4] states (the shape whose stale-list walk once stalled the fused sweep).  A 2^20 frame is ONE
     team of the fused column sweep (512 tiles = the whole grid), and batches under 64 frames rebuild the active list only once
@@ -307,11 +307,11 @@ def test_small_ladder_batch_of_2pow20_frames_fused_equals_three_sweeps(lib, monk
     # (the second plan also keeps k_row4k's whole-sample exchanges: the default splits them into real / imaginary halves)
     for env in ({}, {"PLX_SSFM_NO_FUSE": "1", "PLX_SSFM_ROW4K_SPLIT": "0"}):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tune.setenv(k, v)
         cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, nspans=nspans)
         hp = pipeline.HotPath(cfg, max_frames=F)
         for k in env:
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         assert hp.fused() == ("PLX_SSFM_NO_FUSE" not in env)
         scale = 10 ** (dbm / 10) / cfg.pavg_mw
         ux, uy = hp.make_batch(F, scale)
@@ -387,7 +387,7 @@ def test_front_end_at_2pow20_uses_the_long_row_filter_pass(lib, oracle, nsymb):
     hp.close()
 
 
-def test_sentinel_landing_of_the_staged_tile_equals_the_ordinary_wait(lib, monkeypatch):
+def test_sentinel_landing_of_the_staged_tile_equals_the_ordinary_wait(lib, tune):
     """k_colx16 lands its staged tile WITHOUT a vmcnt wait: the copies are issued from inline assembly, the frame record goes
     last and the wave spins on the record's last word in LDS (in-order return of a wave's loads).  PLX_SSFM_SAFE_LANDING=1
     adds the ordinary s_waitcnt vmcnt(0) in front of that spin: fields, step counts and first steps must agree to the bit, on
@@ -403,11 +403,11 @@ def test_sentinel_landing_of_the_staged_tile_equals_the_ordinary_wait(lib, monke
     for name, env in (("eager", {}), ("safe", {"PLX_SSFM_SAFE_LANDING": "1"}), ("early", {"PLX_SSFM_STORE_LATE": "0"}),
                       ("fwdrows", {"PLX_SSFM_ROW_REV": "0"}), ("ldsrow", {"PLX_SSFM_ROWR": "0"})):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tune.setenv(k, v)
         cfg = pipeline.HotPathConfig(nsymb=1024, nt=64, variants=2)
         hp = pipeline.HotPath(cfg, max_frames=F)
         for k in env:
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         assert hp.fused()
         scale = 10 ** (dbm / 10) / cfg.pavg_mw
         outs = []
@@ -469,7 +469,75 @@ def test_campaign_on_a_plan_that_cannot_share_the_gpu_keeps_one_stream(lib):
     camp.close()
 
 
-def test_gateway_falls_back_to_three_sweeps_when_another_kernel_holds_the_gpu(lib, oracle, monkeypatch):
+def _spin_helper():
+    """Source of a helper PROCESS that holds the LDS of half the CUs for 3 s (tests/gpuhelpers/spin.hip): 128 workgroups x 120 KiB,
+    so that no column workgroup (70 KiB) fits beside one and at most 2 x 128 of a one-team frame's 512 are resident.  It prints
+    'spinning' once its kernel is launched and exits when the kernel has finished."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = os.path.join(root, "tests", "gpuhelpers", "_build", "libplxspin.so")
+    if not os.path.exists(so):                          # (built by __graft_entry__.build(); a tree that skipped it builds it here)
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", os.path.join(root, "tests", "gpuhelpers", "spin.hip"), "-o", so])
+    return ("import ctypes as C, sys\n"
+            "s = C.CDLL(%r)\n"
+            "s.plx_test_spin.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]\n"
+            "rc = s.plx_test_spin(128, 256, 120 * 1024, 3.0, None)\n"
+            "print('spinning' if rc == 0 else 'failed %%d' %% rc, flush=True)\n"
+            "sys.exit(s.plx_test_spin_wait() if rc == 0 else 1)\n") % so
+
+
+def test_fiber_wrapper_repeats_the_span_when_another_kernel_holds_the_gpu(lib, tune):
+    """The Python fiber(x, flag) (fiber.m:372-389: a span ALWAYS returns a field) on a 16-channel 'sepfields' frame -- one team of
+    the fused sweep -- while another process holds half the CUs: the frame barrier times out, fiber() restores GSTATE's field from
+    its copy and repeats the span on the three-sweep step.  Same field (1e-12) and step count as the span on a quiet GPU with a
+    fresh, fused plan; the replay list and the step log are disarmed whatever happened; the time-out is on record."""
+    import subprocess
+    import sys
+    import torch
+    import polmux_amd as px
+    from polmux_amd import fiber as fibermod, synth
+    from polmux_amd.gstate import GSTATE, to_host_field
+    nsymb, nt, nch = 1024, 64, 16
+    x = dict(length=1.5e4, alphadB=0.2, aeff=80.0, n2=2.7e-20, disp=17.0, slope=0.0, dphimax=5e-3, dzmax=2e4)
+    x["lambda"] = 1550.0
+
+    def stage():
+        px.reset_all(nsymb, nt, nch)
+        GSTATE.SYMBOLRATE = 28.0
+        px.lasersource(np.full(nch, 1.0), 1550.0, 0.4)
+        cols = [synth.pdm_qpsk_field(nsymb, nt, 1.0, 2 + 2 * k, 3 + 2 * k) for k in range(nch)]
+        px.create_field("sepfields", np.stack([c[0] for c in cols], 1), np.stack([c[1] for c in cols], 1), dict(power="average"))
+    fibermod.release_plans()
+    tune.setenv("PLX_SSFM_BARRIER_TIMEOUT_MS", "150")
+    stage()
+    torch.cuda.synchronize()
+    proc = subprocess.Popen([sys.executable, "-c", _spin_helper()], stdout=subprocess.PIPE, text=True)
+    try:
+        assert proc.stdout.readline().strip() == "spinning"
+        px.fiber(dict(x, _log_dz=True), "g-s-")
+        busy = (to_host_field(GSTATE.FIELDX), to_host_field(GSTATE.FIELDY), dict(px.fiber.last))
+    finally:
+        assert proc.wait(timeout=60) == 0
+    (plan, _d), = fibermod._plans.values()
+    cnt, info = C.c_int32(), (C.c_int32 * 8)()
+    lib.call("plx_ssfm_barrier_timeouts", plan, C.byref(cnt), 0)
+    lib.call("plx_ssfm_info", plan, info)
+    assert cnt.value == 1 and info[0] == 0, "the span did not time out (was the frame co-resident after all?)"
+    assert len(busy[2]["dz"]) == busy[2]["ncycle"] > 3
+    fibermod.release_plans()
+    stage()
+    px.fiber(x, "g-s-")                                # a fresh plan on a quiet GPU: the fused step
+    (plan, _d), = fibermod._plans.values()
+    lib.call("plx_ssfm_info", plan, info)
+    assert info[0] == 1 and px.fiber.last["ncycle"] == busy[2]["ncycle"] and px.fiber.last["firstdz"] == busy[2]["firstdz"]
+    qx, qy = to_host_field(GSTATE.FIELDX), to_host_field(GSTATE.FIELDY)
+    assert np.abs(busy[0] - qx).max() <= 1e-12 * np.abs(qx).max() and np.abs(busy[1] - qy).max() <= 1e-12 * np.abs(qy).max()
+    fibermod.release_plans()
+
+
+def test_gateway_falls_back_to_three_sweeps_when_another_kernel_holds_the_gpu(lib, oracle, tune):
     """fiber.m:372-389 always returns a field.  A 16-channel frame is ONE team of the fused sweep (512 tiles = the whole grid):
     its workgroups must all be resident to meet at the frame barrier.  With a bounded spinning kernel of ANOTHER PROCESS holding
     the LDS of half the CUs (tests/gpuhelpers/spin.hip, launched by a helper process: streams of one process may share a
@@ -482,21 +550,9 @@ def test_gateway_falls_back_to_three_sweeps_when_another_kernel_holds_the_gpu(li
     import sys
     import torch
     from tests.test_gpu_parity import _desc, _fibre_case, _vp
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    so = os.path.join(root, "tests", "gpuhelpers", "_build", "libplxspin.so")
-    if not os.path.exists(so):                          # (built by __graft_entry__.build(); a tree that skipped it builds it here)
-        os.makedirs(os.path.dirname(so), exist_ok=True)
-        subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", os.path.join(root, "tests", "gpuhelpers", "spin.hip"), "-o", so])
-    # 128 workgroups x 120 KiB of LDS for 3 s: no column workgroup (70 KiB) fits beside one, so at most 2 x 128 of the 512 are
-    # resident.  The helper prints a line once its kernel is launched and exits when the kernel has finished.
-    helper = ("import ctypes as C, sys\n"
-              "s = C.CDLL(%r)\n"
-              "s.plx_test_spin.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]\n"
-              "rc = s.plx_test_spin(128, 256, 120 * 1024, 3.0, None)\n"
-              "print('spinning' if rc == 0 else 'failed %%d' %% rc, flush=True)\n"
-              "sys.exit(s.plx_test_spin_wait() if rc == 0 else 1)\n") % so
+    helper = _spin_helper()
     lib.call("plx_release_all")
-    monkeypatch.setenv("PLX_SSFM_BARRIER_TIMEOUT_MS", "150")
+    tune.setenv("PLX_SSFM_BARRIER_TIMEOUT_MS", "150")
     c = _fibre_case(1024, 64, "g-s-", 1.0, nfc=16, length=1.5e4)
     d = _desc(c)
     planes = [np.asfortranarray(v.copy()) for v in (c["ux"].real, c["ux"].imag, c["uy"].real, c["uy"].imag)]
@@ -574,7 +630,7 @@ def test_share_device_plan_runs_the_receiver_beside_the_next_fibre_bit_equal(lib
     hp.close()
 
 
-def test_two_channel_2pow20_frames_long_rows_equal_the_short_row_split(lib, monkeypatch):
+def test_two_channel_2pow20_frames_long_rows_equal_the_short_row_split(lib, tune):
     """A 'sepfields' field of two channels of 2^20 samples each (1024 column tiles per frame: more than the fused grid, so the
     plan takes the three-sweep step) on the 256 x 4096 split -- k_col_fwd / k_col_inv on 256-row tiles, k_row4k with the channel
     index in its workgroup map -- against the same frames on the 512 x 2048 split (PLX_SSFM_SHORT_ROWS=1: taller column tiles,
@@ -584,11 +640,11 @@ def test_two_channel_2pow20_frames_long_rows_equal_the_short_row_split(lib, monk
     out = []
     for env in ({}, {"PLX_SSFM_SHORT_ROWS": "1"}):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tune.setenv(k, v)
         cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, nch=2, flag="g-s-", length=3e4, pavg_mw=4.0, variants=3)
         hp = pipeline.HotPath(cfg, max_frames=2)
         for k in env:
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         info = hp.info()
         assert info[0] == 0 and info[2] == (11 if env else 12)
         ux, uy = hp.make_batch(2, np.array([1.0, 2.5]))
@@ -605,7 +661,7 @@ def test_two_channel_2pow20_frames_long_rows_equal_the_short_row_split(lib, monk
     assert np.abs(x0[0, 0] - x0[0, 1]).max() > 0.1 * np.abs(x0).max()          # the two channels really differ
 
 
-def test_pmd_2pow20_frames_fused_sweep_and_both_rows_in_one_workgroup_vs_oracle(lib, oracle, monkeypatch):
+def test_pmd_2pow20_frames_fused_sweep_and_both_rows_in_one_workgroup_vs_oracle(lib, oracle, tune):
     """fiber('gps-') has no size restriction (fiber.m:877-935).  2^20-sample frames with waveplates keep the 256 x 4096 split:
     the fused column sweep (one team = the whole grid) and k_row4k<true> -- both polarisations of a 4096-point row in one
     workgroup, the halves of every wave traded around the trunk loop.  Two frames with their own waveplate draws and launch
@@ -617,11 +673,11 @@ def test_pmd_2pow20_frames_fused_sweep_and_both_rows_in_one_workgroup_vs_oracle(
     scale = np.array([1.0, 2.0])
     for env in ({}, {"PLX_SSFM_NO_FUSE": "1"}, {"PLX_SSFM_SHORT_ROWS": "1"}):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tune.setenv(k, v)
         cfg = pipeline.HotPathConfig(nsymb=16384, nt=64, flag="gps-", nplates=50, dgd=0.1, length=4e4, dphimax=2e-2)
         hp = pipeline.HotPath(cfg, max_frames=2)
         for k in env:
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         info = hp.info()
         if not env:
             assert list(info[:3]) == [1, 8, 12] and info[4] == info[3] == 512 and info[6] == 512 and info[7] == 0
@@ -657,7 +713,7 @@ def test_pmd_2pow20_frames_fused_sweep_and_both_rows_in_one_workgroup_vs_oracle(
 
 
 @pytest.mark.parametrize("nsymb,nt", [(1024, 128), (4096, 64), (4096, 128), (256, 128)])
-def test_frames_of_2pow17_to_2pow19_register_form_rows_vs_oracle(lib, oracle, monkeypatch, nsymb, nt):
+def test_frames_of_2pow17_to_2pow19_register_form_rows_vs_oracle(lib, oracle, tune, nsymb, nt):
     """Frames between the BASELINE shapes -- 2^18 = 4096 symbols x 64 samples is what Run_my_PDM_QPSK.m:21-24 ships with -- on
     the 256-row split: fused column sweep + k_rowreg (rows of 512 / 1024 / 2048 points in registers).  Three frames at different
     launch powers (different step counts in one batch): the strongest against oracle.matrix_ssfm (field 1e-9, ncycle), all
@@ -668,11 +724,11 @@ def test_frames_of_2pow17_to_2pow19_register_form_rows_vs_oracle(lib, oracle, mo
     out = []
     for env in ({}, {"PLX_SSFM_ROWR": "0"}, {"PLX_SSFM_ROWG_SPLIT": "0"}):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tune.setenv(k, v)
         cfg = pipeline.HotPathConfig(nsymb=nsymb, nt=nt, length=4e4)
         hp = pipeline.HotPath(cfg, max_frames=3)
         for k in env:
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         info = hp.info()
         p2 = (nsymb * nt).bit_length() - 1 - 8
         assert list(info[:3]) == [1, 8, p2] and (info[7] == 2) == ("PLX_SSFM_ROWR" not in env)
@@ -701,7 +757,7 @@ def test_frames_of_2pow17_to_2pow19_register_form_rows_vs_oracle(lib, oracle, mo
 
 
 @pytest.mark.parametrize("nsymb,nt", [(4096, 64), (4096, 128)])
-def test_pmd_frames_of_2pow18_and_2pow19_register_form_rows_vs_oracle(lib, oracle, monkeypatch, nsymb, nt):
+def test_pmd_frames_of_2pow18_and_2pow19_register_form_rows_vs_oracle(lib, oracle, tune, nsymb, nt):
     """fiber('gps-') on frames of 2^18 and 2^19 samples: fused column sweep + k_rowreg<., true> (lanes i and i + 32 of a wave
     hold X and Y of the same bins and trade halves around the trunk loop).  Two frames with their own waveplate draws and
     launch powers: the stronger against oracle.matrix_ssfm (1e-9, ncycle), both against k_row's PMD branch (PLX_SSFM_ROWR=0)."""
@@ -711,11 +767,11 @@ def test_pmd_frames_of_2pow18_and_2pow19_register_form_rows_vs_oracle(lib, oracl
     scale = np.array([1.0, 2.0])
     for env in ({}, {"PLX_SSFM_ROWR": "0"}):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tune.setenv(k, v)
         cfg = pipeline.HotPathConfig(nsymb=nsymb, nt=nt, flag="gps-", nplates=50, dgd=0.1, length=4e4, dphimax=2e-2)
         hp = pipeline.HotPath(cfg, max_frames=2)
         for k in env:
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         info = hp.info()
         assert info[0] == 1 and info[1] == 8 and (info[7] == 2) == (not env)
         brf = hp.set_random_pmd([41, 42])

@@ -142,7 +142,7 @@ def test_scalar_ssfm_gateway_vs_oracle(lib, oracle, flag, nfc):
 @pytest.mark.parametrize("nsymb,nt,flag,nfc", [(1024, 64, "g-s-", 1), (1024, 64, "g-sx", 2), (1024, 128, "g-sx", 3), (4096, 64, "g-s-", 1),
                                                (4096, 128, "g-s-", 1), (16384, 64, "g-s-", 1), (256, 32, "g-sx", 2), (256, 64, "g-s-", 1),
                                                (256, 128, "g-sx", 3)])
-def test_scalar_ssfm_register_form_rows_vs_oracle(lib, oracle, monkeypatch, nsymb, nt, flag, nfc):
+def test_scalar_ssfm_register_form_rows_vs_oracle(lib, oracle, tune, nsymb, nt, flag, nfc):
     """scalar_ssfm (fiber.m:557-636) on frames of 2^16 ... 2^19 samples, one field or a 'sepfields' comb with XPM (the row
     sums of nl_step :795): the row pass of the scalar plan is the register form too (k_row256r<false, true>: four rows to a
     wave; k_rowreg<., false, true>: every row-polarisation of the workgroup a row; 2^20 samples: the 256 x 4096 split with
@@ -155,14 +155,14 @@ def test_scalar_ssfm_register_form_rows_vs_oracle(lib, oracle, monkeypatch, nsym
     got = []
     for env in ({}, {"PLX_SSFM_ROWR": "0", "PLX_SSFM_SHORT_ROWS": "1", "PLX_SSFM_NO_FUSE": "1"}):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tune.setenv(k, v)
         lib.call("plx_release_all")                    # (the gateway's cached plan was built under the other setting)
         d = _desc(c)
         ur, ui = np.asfortranarray(c["ux"].real.copy()), np.asfortranarray(c["ux"].imag.copy())
         fd, nc = C.c_double(), C.c_int32()
         lib.call("plx_scalar_ssfm", _vp(ur), _vp(ui), C.byref(d), C.byref(fd), C.byref(nc))
         for k in env:
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         assert nc.value == onc and onc > 5 and fd.value == pytest.approx(ofd, rel=1e-12)
         g = ur + 1j * ui
         assert np.abs(g - ou).max() <= FIELD_RTOL * np.abs(ou).max()
@@ -172,7 +172,7 @@ def test_scalar_ssfm_register_form_rows_vs_oracle(lib, oracle, monkeypatch, nsym
     assert not np.array_equal(got[0], got[1])                                       # (the switch really selects another kernel)
 
 
-def test_register_form_row_pass_with_pmd_vs_oracle_three_ways(lib, oracle, monkeypatch):
+def test_register_form_row_pass_with_pmd_vs_oracle_three_ways(lib, oracle, tune):
     """A 256 x 256 'gps-' frame (10 waveplates) takes the register form of the row pass with the waveplate trunks on traded
     wave halves (k_row256r<PMD>): with the trunk phasor tables (default), with one exponential per bin and trunk
     (PLX_SSFM_NO_PMD_TAB=1: what a non-linear db1 takes), and on the LDS-resident k_row (PLX_SSFM_ROWR=0) -- each against the
@@ -187,11 +187,11 @@ def test_register_form_row_pass_with_pmd_vs_oracle_three_ways(lib, oracle, monke
     got = {}
     for name, env in (("tab", {}), ("exp", {"PLX_SSFM_NO_PMD_TAB": "1"}), ("ldsrow", {"PLX_SSFM_ROWR": "0"})):
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            tune.setenv(k, v)
         plan = C.c_void_p()
         lib.call("plx_ssfm_create", C.byref(plan), C.byref(_desc(c)))
         for k in env:
-            monkeypatch.delenv(k)
+            tune.delenv(k)
         lib.call("plx_ssfm_set_birefringence", plan, _vp(db0), _vp(th), _vp(ep), 1)
         ux, uy = _dev(c["ux"][:, 0][None]), _dev(c["uy"][:, 0][None])
         lib.call("plx_ssfm_propagate_dev", plan, ux.data_ptr(), uy.data_ptr(), 1, st)
@@ -209,7 +209,7 @@ def test_register_form_row_pass_with_pmd_vs_oracle_three_ways(lib, oracle, monke
     assert not np.array_equal(got["ldsrow"][0], got["tab"][0])      # (the switch really selects another kernel)
 
 
-def test_long_rows_sixteen_frames_take_the_xcd_grouped_map_vs_oracle(lib, oracle, monkeypatch):
+def test_long_rows_sixteen_frames_take_the_xcd_grouped_map_vs_oracle(lib, oracle, tune):
     """From 16 frames up k_row4k deals the 2 x F users of a row's tables to one XCD, next to each other in time (its own decode
     of the workgroup index) and, like every row pass, walks the listed frames backwards.  18 frames on a power ladder on the
     4 x 4096 split of a 2^14 frame (PLX_SSFM_P1=2: the oracle is affordable at this size): every frame's field, step count and
@@ -220,12 +220,12 @@ def test_long_rows_sixteen_frames_take_the_xcd_grouped_map_vs_oracle(lib, oracle
     dbm = -3.0 + 10.0 * np.arange(F) / (F - 1)
     scale = np.sqrt(10 ** (dbm / 10))
     for k, v in (("PLX_SSFM_P1", "2"), ("PLX_SSFM_LOGW", "6")):
-        monkeypatch.setenv(k, v)
+        tune.setenv(k, v)
     d = _desc(c, frames=F)
     plan = C.c_void_p()
     lib.call("plx_ssfm_create", C.byref(plan), C.byref(d))
     for k in ("PLX_SSFM_P1", "PLX_SSFM_LOGW"):
-        monkeypatch.delenv(k)
+        tune.delenv(k)
     info = (C.c_int32 * 8)()
     lib.call("plx_ssfm_info", plan, info)
     assert list(info)[:3] == [0, 2, 12] and info[7] == 1          # three sweeps, 4 x 4096, one polarisation per row workgroup
@@ -728,18 +728,18 @@ def test_fiber_function_surface(lib, oracle):
 
 
 @pytest.mark.parametrize("env", [{}, {"PLX_SSFM_NO_FUSE": "1"}])
-def test_sweep_variants_match_oracle(lib, oracle, monkeypatch, env):
+def test_sweep_variants_match_oracle(lib, oracle, tune, env):
     """Both forms of the SSFM step -- the fused column sweep k_colx16 (default at this geometry) and the barrier-free
     three-sweep step (PLX_SSFM_NO_FUSE=1) -- reproduce the oracle on a batch whose frames have different step counts."""
     import torch
     F = 20                                           # > 16 frames: the fused grid walks more than one round
     c = _fibre_case(1024, 64, "g-s-", 2.0, length=2e4)
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        tune.setenv(k, v)
     plan = C.c_void_p()
     lib.call("plx_ssfm_create", C.byref(plan), C.byref(_desc(c, frames=F)))
     for k in env:
-        monkeypatch.delenv(k)
+        tune.delenv(k)
     scale = np.sqrt(np.linspace(0.5, 6.0, F))
     ux = _dev(np.stack([c["ux"][:, 0] * s for s in scale]))
     uy = _dev(np.stack([c["uy"][:, 0] * s for s in scale]))

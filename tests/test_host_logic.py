@@ -34,7 +34,7 @@ def test_abi_library_exports_every_declared_symbol():
     assert sorted(_abi.SIGNATURES) + ["plx_last_error"] == sorted(syms + []) or \
         sorted(list(_abi.SIGNATURES) + ["plx_last_error"]) == syms
     b = _abi.Binding()
-    assert b.lib.plx_abi_version() == 1001
+    assert b.lib.plx_abi_version() == 1002
     # no compute without a GPU, but argument validation works everywhere
     with pytest.raises(_abi.PolmuxError, match="null argument"):
         b.call("plx_ssfm_create", None, None)
