@@ -96,6 +96,15 @@ def parse():
     ap.add_argument("--no-cohmix-line", action="store_true", help="skip the short side measurement with the reference's own front end")
     ap.add_argument("--no-gateway", action="store_true", help="skip the per-call timing of the MEX-shaped gateway tier")
     ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the batch the one-core CPU baseline processes (~0.5 s each)")
+    ap.add_argument("--ladder-world", type=int, default=0,
+                    help="with --power-ladder: take the ladder points of rank 0 of THIS many GPUs (frame f at point (rank + W f) %% 64) "
+                         "whatever the real world size; 0 = the real world size.  8 gives a one-GPU run the share one GPU of BASELINE "
+                         "config[4]'s eight has: every 8th point of the ladder, -4 ... +6.7 dBm")
+    ap.add_argument("--configs", default="auto", choices=["auto", "yes", "no"],
+                    help="after the headline (BASELINE config[1]) also run bounded legs of config[2] (--nch 16 --spans 10 --nf 5 "
+                         "--frames 32) and config[4] (--nsymb 16384 --frames 8 --spans 40 --power-ladder --ladder-world 8) AS STATED, each "
+                         "with its own roofline and CPU baseline, into \"configs\" of the same JSON line; auto: when the headline is the "
+                         "default workload on one GPU")
     return ap.parse_args()
 
 
@@ -233,11 +242,24 @@ def cpu_params(cfg, hp, noise):
     return p
 
 
-def cpu_baseline(cfg, hp, nframes, noise):
+def cpu_baseline(cfg, hp, nframes, noise, frame_steps=None, scales=None):
     """The reference algorithm restated on the CPU (oracle/, kind 'port') on a bounded sample of the SAME workload
-    (frames of the batch, same receiver noise level): one core, then one frame stream per host core."""
+    (frames of the batch, same receiver noise level): one core, then one frame stream per host core.
+    frame_steps: SSFM steps per frame of the timed batch, all spans (the oracle takes the same steps: parity tests)."""
     from oracle import cpu_chain
     p = cpu_params(cfg, hp, noise)
+    if cfg.nch == 1 and cfg.nspans * (cfg.nfft / 65536.0) * 0.4 * nframes > 60.0:
+        # long-haul frames (BASELINE config[4]): ONE span of the batch's lowest launch power + one receiver pass are timed; the
+        # batch's CPU time is taken as (seconds per step of that span) x (the steps the timed GPU batch really made, all frames
+        # and spans) + (receiver seconds) x frames -- a step costs the same at every launch power
+        sc = float(np.min(scales)) if scales is not None else 1.0
+        tf, k, tr = cpu_chain.run_span_sample(p, sc, 999)
+        F = len(scales) if scales is not None else 1
+        steps_batch = float(frame_steps) if frame_steps else float(k * cfg.nspans * F)
+        est = tf / k * steps_batch + tr * F
+        return (F * cfg.nfft / est / 1e9, tf + tr, k, "one 2^%d-sample frame at the batch's lowest launch power through ONE of its %d spans "
+                "(%d steps, %.1f s) + one receiver pass (%.1f s); value = samples of the batch / (seconds per step x the %.0f steps the "
+                "timed batch made over all frames and spans + receiver seconds x %d frames)" % (int(np.log2(cfg.nfft)), cfg.nspans, k, tf, tr, steps_batch, F)), None
     if cfg.nch > 1:
         # a WDM frame of BASELINE config[2] is ~16 C1 frames x 10 spans of CPU work: the bounded sample is ONE frame through
         # the first `k` spans (with amplifiers) + all of its receivers; the spans being alike, the frame's time is taken
@@ -458,30 +480,113 @@ def offline_traffic(fused, F, n, nch=1, flag="g-s-"):
     return None, None
 
 
+class Env:
+    """What every line of a run shares: the rank's place in the job, the library binding, where collectives' tensors live."""
+
+
+# the bounded legs of the other BASELINE configurations AS STATED (arguments on top of the headline's)
+CONFIG_LEGS = {
+    "c2": dict(nch=16, spans=10, nf=5.0, frames=32, steps=2, warmup=1, flag=None),
+    "c4": dict(nsymb=16384, frames=8, spans=40, power_ladder=True, ladder_world=8, variants=1, steps=2, warmup=1, flag=None),
+}
+
+
+FP64_PEAK_TFLOPS = 78.6       # 256 CUs x 4 SIMDs x 16 FP64 lanes x 2 flop per FMA x 2.4 GHz (vector FP64, no MFMA on this path)
+
+
+def fused_mismatch(f64, names):
+    """the FP64 summary was taken on the fused step: it says nothing about the three-sweep kernels"""
+    return names[0] != "k_colx16" and "k_colx16" in f64["flop_per_sample_per_launch"] and "k_col_fwd" not in f64["flop_per_sample_per_launch"]
+
+
+def offline_fp64(n, nch, flag, mc):
+    """FP64 flop per dual-pol sample per launch of each step kernel, from the SQ instruction counters (scripts/fp64_pmc.sh: a
+    rocprofv3 --pmc pass of its own, so NOT measured in this run; committed summary of this round's build).  None when the
+    summary has no entry for this workload shape."""
+    for name in ("r05_fp64.json",):
+        fj = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(fj):
+            continue
+        tab = json.load(open(fj))
+        pmd = flag == "gps-"
+        if nch == 16 and n == 65536 and pmd:
+            tag = "c2_frame"
+        elif nch != 1:
+            return None
+        elif n == 65536:
+            tag = "c1_mc" if (pmd and mc) else (None if pmd else "c1")
+        elif n == 1 << 20:
+            tag = "big_pmd" if pmd else "big"
+        elif n == 1 << 18:
+            tag = "mid_pmd" if pmd else "mid"
+        else:
+            tag = None
+        w = tab.get("workloads", {}).get(tag) if tag else None
+        if not w:
+            return None
+        return {"file": "profiles/" + name, "workload": tag, "what": w["what"], "how": "offline rocprofv3 --pmc pass (not this run)",
+                "peak_TFLOPs": tab.get("peak_TFLOPs", FP64_PEAK_TFLOPS), "peak_source": tab.get("peak_source"),
+                "flop_per_sample_per_launch": {k: v["flop_per_sample_per_launch"] for k, v in w["kernels"].items()}}
+    return None
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(a))
     import torch
     import torch.distributed as dist
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    E = Env()
+    E.rank = int(os.environ.get("RANK", "0"))
+    E.world = int(os.environ.get("WORLD_SIZE", "1"))
+    E.local = int(os.environ.get("LOCAL_RANK", "0"))
     # rehearsal of the N > 1 path on a one-GPU box (dev only): every rank on cuda:0, collectives over gloo
-    rehearsal = os.environ.get("PLX_BENCH_REHEARSAL") == "1"
-    if rehearsal:
-        local = 0
+    E.rehearsal = os.environ.get("PLX_BENCH_REHEARSAL") == "1"
+    if E.rehearsal:
+        E.local = 0
         os.environ["PLX_SSFM_NO_FUSE"] = "1"     # several ranks share one GPU here: the fused sweep needs the chip to itself
-    torch.cuda.set_device(local)
-    if world > 1:
-        if rehearsal:
+    torch.cuda.set_device(E.local)
+    if E.world > 1:
+        if E.rehearsal:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    from polmux_amd import _abi, mc, pipeline
-    lib = _abi.get()
-    lib.call("plx_set_device", local)
-    cdev = "cpu" if (rehearsal or world == 1) else "cuda"        # where the collectives' tensors live
+            dist.init_process_group("nccl", device_id=torch.device("cuda", E.local))
+    from polmux_amd import _abi
+    E.lib = _abi.get()
+    E.lib.call("plx_set_device", E.local)
+    E.cdev = "cpu" if (E.rehearsal or E.world == 1) else "cuda"        # where the collectives' tensors live
+    headline_is_default = (a.nch == 1 and a.nsymb == 1024 and a.nt == 64 and a.spans == 1 and a.flag is None and not a.mc and
+                           not a.power_ladder and a.frontend == "pick")
+    out = run_line(a, E)
+    if E.world == 1 and (a.configs == "yes" or (a.configs == "auto" and headline_is_default)):
+        # BASELINE configs 2 and 4 as stated, bounded: a short timed region each (no Monte-Carlo, gateway or latency side legs)
+        out["configs"] = {}
+        for name, over in CONFIG_LEGS.items():
+            b = argparse.Namespace(**vars(a))
+            for k, v in over.items():
+                setattr(b, k, v)
+            b.mc_rounds, b.no_single_frame, b.no_gateway, b.no_cohmix_line, b.share_device = 0, True, True, True, "auto"
+            t0 = time.perf_counter()
+            leg = run_line(b, E)
+            for k in ("mc", "gateway", "n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "cpu_baseline_all_cores"):
+                leg.pop(k, None)
+            leg["leg_seconds"] = time.perf_counter() - t0
+            out["configs"][name] = leg
+    if E.rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if E.world > 1:
+        dist.destroy_process_group()
+
+
+def run_line(a, E):
+    """One bench line: the timed region for the workload the arguments describe, then the side legs they ask for.
+    Returns the line as a dict on rank 0 (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    from polmux_amd import mc, pipeline
+    rank, world, local, rehearsal, cdev, lib = E.rank, E.world, E.local, E.rehearsal, E.cdev, E.lib
+    a = argparse.Namespace(**vars(a))          # (defaults are filled in below: the caller's copy stays as parsed)
 
     if a.mc or (a.flag is None and a.nch > 1):
         a.flag = "gps-"
@@ -494,7 +599,8 @@ def main():
     cfg.share_device = a.share_device == "yes"
     hp = pipeline.HotPath(cfg, max_frames=F)
     n = cfg.nfft
-    scales = ladder_scales(F, a.pavg, rank, world) if a.power_ladder else None
+    lw = a.ladder_world if a.ladder_world > 0 else world
+    scales = ladder_scales(F, a.pavg, rank if a.ladder_world <= 0 else 0, lw) if a.power_ladder else None
     share_why = "asked for" if cfg.share_device else None
     if a.share_device == "auto" and not a.no_overlap and not hp.overlap_ok():
         # A frame of this plan is the whole grid of the fused sweep: its receiver cannot run beside the next fibre.  One
@@ -723,6 +829,38 @@ def main():
                                         "shape": "BASELINE config[3] as stated: %d realisations in total, realisation r on GPU r mod %d, "
                                                  "one round, one all_reduce(SUM) of int64[%d]" % (a.mc_total, world, a.mc_total)}
             camp2.close()
+            # ---- what ONE of eight ranks would do in that campaign, measured here on one GPU: its 1024 / 8 = 128 realisations
+            # (r = 0, 8, 16, ...) as one round of 128, and as two / four parts in flight (own plans, buffers and receiver streams:
+            # the receivers -- a latency, the CMA's 299 passes -- run beside each other) with still ONE exchange at the end.
+            # The 8-GPU figure DESIGN.md section 7 predicts is 1024 / (this time + the all-reduce).
+            if world == 1 and a.mc_total % 8 == 0 and a.mc_total >= 64:
+                share = a.mc_total // 8
+                shapes = {}
+                for parts in (1, 2, 4):
+                    pool = pipeline.McCampaignPool(mcfg, frames_per_call=share // parts, n=parts, split=True)
+                    view = pipeline.McRankShare(pool, 0, 8)
+                    view.simulate(list(range(3 * 10 ** 6, 3 * 10 ** 6 + share)))                    # warm-up, not counted
+                    sb3 = mc.ShardedBer(view.simulate, pool.bits_per_realisation, x, per_rank_per_round=share, device=cdev)
+                    best = None
+                    for rep_ in range(3):
+                        sb3 = mc.ShardedBer(view.simulate, pool.bits_per_realisation, x, per_rank_per_round=share, device=cdev)
+                        sync_all()
+                        t1 = time.perf_counter()
+                        res3 = sb3.run(max_realisations=share, depth=1)
+                        sync_all()
+                        dt3 = time.perf_counter() - t1
+                        best = dt3 if best is None else min(best, dt3)
+                    shapes["%dx%d" % (parts, share // parts)] = {"seconds": best, "realisations": len(sb3.counts), "exchanges": sb3.exchanges,
+                                                                "avgber": float(res3[1][0]), "errors": int(sum(sb3.counts))}
+                    pool.close()
+                ks = min(shapes, key=lambda k_: shapes[k_]["seconds"])
+                mc_out["strong_scaling_rank_share"] = {
+                    "what": "the share of rank 0 of 8 in BASELINE config[3] as stated (realisations 0, 8, ..., %d: %d of %d), on this one GPU; "
+                            "parts x size in flight, ONE exchange at the end; best of 3 repetitions" % (a.mc_total - 8, share, a.mc_total),
+                    "shapes": shapes, "identical_counts": len({v_["errors"] for v_ in shapes.values()}) == 1, "best_shape": ks,
+                    "predicted_8gpu_realisations_per_s": a.mc_total / shapes[ks]["seconds"],
+                    "prediction_note": "1024 realisations / the measured time of one rank's share (ranks are independent until the one "
+                                       "all-reduce of int64[%d], whose latency is not in this figure)" % a.mc_total}
 
     # SURVEY 8d's M1 read literally -- ONE frame through fibre + receiver, nothing else on the GPU (outside the timed region)
     single = None
@@ -784,6 +922,7 @@ def main():
     gateway = None
     if rank == 0 and world == 1 and not a.no_gateway:
         gateway = gateway_bench(cfg, hp)
+    out = None
     if rank == 0:
         samples = float(world) * a.steps * F * nch * n
         value = samples / dt / 1e9
@@ -803,11 +942,40 @@ def main():
                 kern[names[k]] = {"avg_launch_us": avg_ms * 1e3, "active_launches": int(k_n[k]), "achieved_GBs": gbs,
                                   "frac_of_8TBs": gbs / HBM_PEAK_GBS}
         dom = max(kern, key=lambda k_: kern[k_]["avg_launch_us"] * kern[k_]["active_launches"]) if kern else names[0]
+        # the FP64 side of the same launches: flop per launch (SQ instruction counters, offline) over the SAME live HIP-event
+        # durations, against the part's vector-FP64 peak -- beside the HBM fraction, for every kernel the summary covers
+        f64 = offline_fp64(n, nch, a.flag, a.mc)
+        fp64 = None
+        if f64 is not None and not fused_mismatch(f64, names):
+            fk = {}
+            for k_, v_ in kern.items():
+                fl = f64["flop_per_sample_per_launch"].get(k_)
+                if fl is None:
+                    continue
+                tf = fl * act * nch * n / (v_["avg_launch_us"] * 1e-6) / 1e12
+                fk[k_] = {"flop_per_sample_per_launch": fl, "flops_per_launch": fl * act * nch * n, "achieved_TFLOPs": tf,
+                          "frac": tf / f64["peak_TFLOPs"]}
+            if fk:
+                fp64 = {"peak": f64["peak_TFLOPs"], "unit": "TFLOP/s", "peak_source": f64["peak_source"], "source": {k_: f64[k_] for k_ in ("file", "workload", "what", "how")},
+                        "kernels": fk}
+                if dom in fk:
+                    fp64.update({"kernel": dom, "flops_per_launch": fk[dom]["flops_per_launch"], "achieved_TFLOPs": fk[dom]["achieved_TFLOPs"], "frac": fk[dom]["frac"]})
         sweeps = 2 if fused else 3
         group_bytes = SWEEP_BYTES * sweeps
         group_gbs = group_bytes * sample_steps / (fib * 1e-3) / 1e9
         traffic, traffic_src = offline_traffic(fused, F, n, nch, a.flag)
         active_frames = float(np.mean([(ncyc > s).sum() for s in range(int(ncyc.max()))])) if len(ncyc) else float(F)
+        # which roof is nearer: the larger of the two fractions names the bound; with both below one half the kernel is
+        # bound by neither rate but by the latency structure of a workgroup's life (occupancy, barriers, exchanges)
+        hbm_frac = kern.get(dom, {}).get("frac_of_8TBs") or 0.0
+        f64_frac = (fp64 or {}).get("frac")
+        if f64_frac is None:
+            roof_bound, roof_note = "hbm", "no FP64 instruction count on file for this workload shape: priced against the HBM roof only"
+        else:
+            roof_bound = "hbm" if hbm_frac >= f64_frac else "fp64-valu"
+            roof_note = ("HBM fraction %.3f, FP64 fraction %.3f of the dominant kernel: %s" % (hbm_frac, f64_frac,
+                         "the nearer roof is %s" % ("HBM" if hbm_frac >= f64_frac else "the FP64 VALU rate") if max(hbm_frac, f64_frac) >= 0.5 else
+                         "NEITHER roof is within a factor of two -- latency-bound (occupancy / barrier / exchange structure), see DESIGN.md"))
         out = {
             "metric": "dual-pol Gsample/s through SSFM+Rx-DSP", "value": value, "unit": "Gsample/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
@@ -815,6 +983,8 @@ def main():
             "config": {"workload": workload_label(a, n),
                        "frames_per_gpu_per_step": F, "channels_per_frame": nch, "nsymb": a.nsymb, "nt": a.nt, "pavg_mw": a.pavg,
                        "tx_variants": hp.nvar, "power_ladder": bool(a.power_ladder),
+                       "ladder_dbm": [float(v) for v in 10 * np.log10(scales * a.pavg)] if (scales is not None and F <= 64) else None,
+                       "ladder_share": ("rank 0's share of %d GPUs: frame f at ladder point (%d f) %% 64" % (lw, lw)) if (a.power_ladder and a.ladder_world > 0) else None,
                        "ssfm_steps_per_frame": sample_steps / (a.steps * F * nch * n),
                        "ssfm_steps_min_max": [int(ncyc.min()), int(ncyc.max())] if len(ncyc) else None,
                        # lock-step launches over frames with different trip counts (fiber.m:518): frame-steps with work / frame
@@ -839,7 +1009,7 @@ def main():
                        "with_reference_front_end": cohmix_line},
             # a PMD plan's row pass does one exponential + 20 multiply-adds per waveplate trunk and frequency: FP64-VALU-bound
             # (exception 1), still priced in bytes against the HBM peak
-            "roofline": {"bound": "fp64-valu" if (dom == row_kernel and hp.pmd) else "hbm", "kernel": dom,
+            "roofline": {"bound": roof_bound, "kernel": dom, "fp64": fp64, "bound_note": roof_note,
                          "achieved": kern.get(dom, {}).get("achieved_GBs"), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": kern.get(dom, {}).get("frac_of_8TBs"),
                          "algorithmic_bytes_per_launch": SWEEP_BYTES * active_frames * nch * n,
@@ -867,7 +1037,7 @@ def main():
             "gateway": gateway,
         }
         if not a.no_cpu_baseline and world == 1:      # a reported baseline, timed at N = 1 only
-            one, allc = cpu_baseline(cfg, hp, a.cpu_frames, a.noise)
+            one, allc = cpu_baseline(cfg, hp, a.cpu_frames, a.noise, frame_steps=sample_steps / (a.steps * nch * n), scales=scales)
             v, cdt, nc = one[:3]
             out["cpu_baseline"] = {"value": v, "unit": "Gsample/s", "cores": 1, "kind": "port",
                                    "sample": one[3] if len(one) > 3 else
@@ -879,11 +1049,10 @@ def main():
                                                  "frames_per_s": cores * per / busiest,     # (frames of THIS line's workload; the Monte-Carlo realisation is timed in mc.cpu_baseline)
                                                  "sample": "%d processes x %d frame(s) each, busiest process %.1f s (%.1f s "
                                                            "wall incl. process start)" % (cores, per, busiest, wall)}
-        print(json.dumps(out))
-        sys.stdout.flush()
     hp.close()
-    if world > 1:
-        dist.destroy_process_group()
+    del batches, pristine
+    torch.cuda.empty_cache()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

@@ -101,6 +101,30 @@ def run_wdm_frame(p, spans, seed):
     return t1 - t0, time.perf_counter() - t1, nc
 
 
+def run_span_sample(p, scale, seed):
+    """Bounded sample of a LONG-HAUL frame (BASELINE config[4]: 2^20 samples x 40 spans is minutes of CPU work per frame): the
+    Tx frame at launch-power scale `scale` through ONE span, then through the receiver chain once (a timing sample: the
+    receiver sees the field after one span).  Returns (seconds in the span, its ncycle, seconds in the receiver)."""
+    from oracle import plxo
+    r = np.random.default_rng(seed)
+    a = np.sqrt(scale)
+    t0 = time.perf_counter()
+    rc, fd, k, ox, oy = plxo.matrix_ssfm(p["tx_x"] * a, p["tx_y"] * a, p["betat"], p["db1"], p["dzmax"], p["dphimax"], p["gam"],
+                                         p["alphalin"], p["length"], 1, 0, p["fls"], [0.0], [0.0], [0.0])
+    t1 = time.perf_counter()
+    half = p["nt"] // 2
+    rx = np.stack([ox[::half, 0], oy[::half, 0]], 1) * (p["rx_scale"] / a)
+    if p["noise"]:
+        rx = rx + p["noise"] * (r.standard_normal(rx.shape) + 1j * r.standard_normal(rx.shape))
+    ex, ey, _ = plxo.cde_ofde(rx[:, 0], rx[:, 1], 2 * p["symbolrate"] * 1e9, p["lam"] * 1e-9, p["length"], p["disp"] * 1e-6,
+                              p["slope"] * 1e-6, p["fft_length"], p["cde_L"])
+    op = plxo.dsp_params(power_mw=p["power_mw"], applypol=True, polmethod="cma", cma_mu=p["cma_mu"], cma_taps=p["cma_taps"],
+                         freqavg=p["freqavg"], phasavg=p["phasavg"], poworder=p["poworder"])
+    sym = plxo.dsp_pdm_coh_qpsk(np.stack([ex, ey], 1), op)
+    plxo.samp2pat_coherent(np.angle(sym))
+    return t1 - t0, k, time.perf_counter() - t1
+
+
 def run_parallel(p, frames_per_core, cores, timeout_s=180.0):
     """One child process per core (`python -m oracle.cpu_chain params.npz n seed`: fresh interpreters that never see the
     parent's GPU state), each running frames_per_core frames.  Returns (wall seconds, busiest child's compute seconds)

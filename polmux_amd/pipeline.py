@@ -518,15 +518,39 @@ class McCampaign:
         self.hp.close()
 
 
+class McRankShare:
+    """The share ONE rank of `world` has in a campaign, run on its own: local index i stands for realisation rank + world * i
+    (realisation r on GPU r mod world).  launch / collect / simulate of the wrapped campaign or pool."""
+
+    def __init__(self, camp, rank, world):
+        self.camp, self.rank, self.world = camp, int(rank), int(world)
+
+    def _map(self, indices):
+        return [self.rank + self.world * int(i) for i in indices]
+
+    def launch(self, indices, keep=None):
+        return self.camp.launch(self._map(indices), keep)
+
+    def collect(self, handle, with_samples=False):
+        return self.camp.collect(handle, with_samples)
+
+    def simulate(self, indices, keep=None):
+        return self.collect(self.launch(indices, keep))
+
+
 class McCampaignPool:
     """`n` McCampaign instances taking the rounds of a campaign in turn, each with its own plans, receiver buffers and
     receiver stream: the receivers of up to n rounds are in flight at once (ShardedBer.run(depth=n - 1)).  A noise-loaded
     realisation's CMA runs all of its 299 passes -- ~58 ms of a serial recurrence whatever the batch size -- while its
     fibre takes a few ms: with one receiver in flight a round of 128 realisations is latency-bound on that."""
 
-    def __init__(self, cfg, frames_per_call, n=2, noise_sigma=0.0, noise_provider=None):
+    def __init__(self, cfg, frames_per_call, n=2, noise_sigma=0.0, noise_provider=None, split=False):
+        """split: ONE round is dealt over all n instances (contiguous parts, launched back to back, collected in order) instead
+        of the rounds taking turns: the receivers of a round's parts run beside each other and the round still ends in ONE
+        exchange -- what a rank of a strong-scaling run does with its fixed share (bench.py, mc.strong_scaling_rank_share)."""
         self.camps = [McCampaign(cfg, frames_per_call, noise_sigma, noise_provider) for _ in range(max(1, int(n)))]
         self._turn = 0
+        self.split = bool(split)
 
     @property
     def bits_per_realisation(self):
@@ -537,11 +561,21 @@ class McCampaignPool:
         return self.camps[0].hp
 
     def launch(self, indices, keep=None):
+        if self.split:
+            idx = list(indices)
+            per = -(-len(idx) // len(self.camps))
+            return [(i, c.launch(idx[i * per:(i + 1) * per], keep)) for i, c in enumerate(self.camps) if idx[i * per:(i + 1) * per]]
         i = self._turn % len(self.camps)
         self._turn += 1
         return i, self.camps[i].launch(indices, keep)
 
     def collect(self, handle, with_samples=False):
+        if self.split:
+            parts = [self.camps[i].collect(h, with_samples) for i, h in handle]
+            if with_samples:
+                return (np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.int64),
+                        np.concatenate([p[1] for p in parts]) if parts else np.zeros(0))
+            return np.concatenate(parts) if parts else np.zeros(0, np.int64)
         i, h = handle
         return self.camps[i].collect(h, with_samples)
 

@@ -497,7 +497,8 @@ def test_fiber_wrapper_repeats_the_span_when_another_kernel_holds_the_gpu(lib, t
     import sys
     import torch
     import polmux_amd as px
-    from polmux_amd import fiber as fibermod, synth
+    from polmux_amd import synth
+    fibermod = sys.modules["polmux_amd.fiber"]          # (the package re-exports the FUNCTION under the module's name)
     from polmux_amd.gstate import GSTATE, to_host_field
     nsymb, nt, nch = 1024, 64, 16
     x = dict(length=1.5e4, alphadB=0.2, aeff=80.0, n2=2.7e-20, disp=17.0, slope=0.0, dphimax=5e-3, dzmax=2e4)

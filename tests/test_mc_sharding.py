@@ -109,6 +109,44 @@ class _FakeCampaign:
         return self.collect(self.launch(idx))
 
 
+def test_split_pool_and_rank_share_keep_one_exchange_and_the_statistics(monkeypatch):
+    """bench.py's mc.strong_scaling_rank_share: a rank's fixed share of a campaign dealt over several campaign instances in
+    flight (McCampaignPool(split=True)) seen through McRankShare(rank, world).  Host logic only (the campaign is a fake): local
+    index i is realisation rank + world i, the parts are contiguous and collected in order, the round ends in ONE exchange, and
+    the statistics equal the undivided round's."""
+    sys.path.insert(0, ROOT)
+    from polmux_amd import mc, pipeline
+
+    class Fake(_FakeCampaign):
+        def __init__(self, cfg, frames_per_call, noise_sigma=0.0, noise_provider=None):
+            super().__init__()
+            self.F = frames_per_call
+
+        def launch(self, idx, keep=None):
+            assert len(idx) <= self.F
+            return super().launch(idx)
+
+        bits_per_realisation = 4096
+
+        def close(self):
+            pass
+    monkeypatch.setattr(pipeline, "McCampaign", Fake)
+    x = dict(stop=(1e-9, 95), nmin=10)
+    out = {}
+    for parts in (1, 2, 4):
+        pool = pipeline.McCampaignPool(None, frames_per_call=16 // parts, n=parts, split=True)
+        view = pipeline.McRankShare(pool, 3, 8)
+        sb = mc.ShardedBer(view.simulate, 4096, x, per_rank_per_round=16)
+        res = sb.run(max_realisations=16, depth=1)
+        assert sb.exchanges == 1 and sb.rounds == 1 and len(sb.counts) == 16
+        got = [c.launched for c in pool.camps]
+        assert [r for c in got for l in c for r in l] == [3 + 8 * i for i in range(16)]          # contiguous parts, in order
+        assert all(len(c) == 1 and len(c[0]) == 16 // parts for c in got)
+        out[parts] = (list(sb.counts), [np.asarray(v, dtype=float).tolist() for v in res])
+    assert out[1] == out[2] == out[4]
+    assert out[1][0] == list(_errors_of([3 + 8 * i for i in range(16)]))
+
+
 def test_pipelined_rounds_give_the_sequential_statistics():
     """With a simulator that offers launch()/collect(), ShardedBer enqueues round k+1 before it reduces round k; the round
     computed past the stop is discarded: avgber / nruns / stdber still equal the one-realisation-at-a-time loop bit for bit."""
