@@ -6,11 +6,12 @@ set -e
 cd "$(dirname "$0")/../.."
 if [ "$1" = build ]; then
   mkdir -p build_stamps
+  rm -f build_stamps/*.hip build_stamps/*.o
   python3 scripts/experiments/stamps_patch.py > /dev/null
   OBJS=""
   for f in polmux_amd/csrc/*.hip; do
     o=build_stamps/$(basename ${f%.hip}).o
-    [ $(basename $f) = plx_ssfm.hip ] && f=build_stamps/plx_ssfm.hip
+    [ -f build_stamps/$(basename $f) ] && f=build_stamps/$(basename $f)
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -I polmux_amd/csrc $PLX_EXTRA_HIPCC_FLAGS -c $f -o $o &
     OBJS="$OBJS $o"
   done

@@ -931,7 +931,11 @@ def test_wdm_16ch_multispan_chain_vs_oracle_c2(lib, oracle, nspans):
         ex = np.abs(gx_free - ox).max() / np.abs(ox).max()
         ey = np.abs(gy_free - oy).max() / np.abs(oy).max()
         worst.append((max(ex, ey), cond))
-        assert max(ex, ey) <= max(FIELD_RTOL, 1e4 * cond) and max(ex, ey) < 0.1, "span %d: field %.3g / %.3g, oracle conditioning %.3g" % (s, ex, ey, cond)
+        # (three spans: within 100 x the probe, the bar of rounds 1-3; the ten-span chain, whose late spans amplify every rounding
+        #  difference of ~150 steps in directions one probe does not sample, within 1e4 x -- the step-by-step gate (2) below is
+        #  what holds the step controller to account there)
+        assert max(ex, ey) <= max(FIELD_RTOL, (100 if nspans <= 3 else 1e4) * cond) and max(ex, ey) < 0.1, \
+            "span %d: field %.3g / %.3g, oracle conditioning %.3g" % (s, ex, ey, cond)
         # (1) the device's free-running result is what the ORACLE computes under the device's own step sequence, at every span
         #     (plxo_set_step_replay): same ncycle, field to the tight bar whatever the conditioning
         _, fd_b, nc_b, bx, by = oracle.matrix_ssfm(hx, hy, *args, replay_dz=dz_dev)
