@@ -452,7 +452,7 @@ def offline_traffic(fused, F, n, nch=1, flag="g-s-"):
     (FETCH_SIZE, WRITE_SIZE: MI355X_MICROARCH.md, HBM section), so this is NOT measured in this run: it is read from the
     summary of scripts/traffic_pmc.sh on this round's build, if one is committed (2^16- and 2^20-sample frames, and the
     16-channel WDM frame of BASELINE config[2])."""
-    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
+    for name in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         tj = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(tj):
             continue

@@ -8,13 +8,13 @@ export TMPDIR=/tmp
 R=$PWD
 if [ $part = lines ]; then
   timeout -k 10 600 python3 bench.py > $O/bench_default.json 2> $O/bench_default.err || { tail $O/bench_default.err; exit 1; }
-  timeout -k 10 300 python3 bench.py --no-overlap --no-cpu-baseline --mc-rounds 0 --no-gateway --no-cohmix-line > $O/bench_no_overlap.json 2>/dev/null || exit 1
+  timeout -k 10 300 python3 bench.py --no-overlap --no-cpu-baseline --mc-rounds 0 --no-gateway --no-cohmix-line --configs no > $O/bench_no_overlap.json 2>/dev/null || exit 1
   timeout -k 10 300 python3 bench.py --frontend cohmix --no-cpu-baseline --mc-rounds 0 --no-gateway > $O/bench_cohmix.json 2>/dev/null || exit 1
   timeout -k 10 300 python3 bench.py --power-ladder --no-cpu-baseline --mc-rounds 0 --no-gateway > $O/bench_ladder.json 2>/dev/null || exit 1
   timeout -k 10 300 python3 bench.py --mc --no-cpu-baseline --no-gateway > $O/bench_mc.json 2>/dev/null || exit 1
   timeout -k 10 300 python3 bench.py --nsymb 16384 --frames 16 --steps 4 --warmup 1 --variants 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_c4_frame.json 2>/dev/null || exit 1
   timeout -k 10 300 python3 bench.py --nsymb 16384 --frames 16 --steps 4 --warmup 1 --variants 1 --share-device no --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_c4_frame_fused.json 2>/dev/null || exit 1
-  timeout -k 10 600 python3 bench.py --nsymb 16384 --frames 8 --spans 40 --power-ladder --steps 2 --warmup 1 --variants 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_c4_40spans.json 2>/dev/null || exit 1
+  timeout -k 10 600 python3 bench.py --nsymb 16384 --frames 8 --spans 40 --power-ladder --ladder-world 8 --steps 2 --warmup 1 --variants 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_c4_40spans.json 2>/dev/null || exit 1
   timeout -k 10 600 python3 bench.py --nch 16 --spans 10 --nf 5 --frames 32 --steps 3 --warmup 1 --mc-rounds 0 --no-gateway > $O/bench_c2.json 2>/dev/null || exit 1
   timeout -k 10 300 python3 bench.py --nsymb 4096 --frames 256 --steps 4 --warmup 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_2pow18.json 2>/dev/null || exit 1
   timeout -k 10 300 python3 bench.py --nsymb 16384 --flag gps- --frames 16 --steps 3 --warmup 1 --variants 1 --share-device no --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway > $O/bench_2pow20_pmd.json 2>/dev/null || exit 1
@@ -29,14 +29,14 @@ for l in open("$O/bench.jsonl"):
 PY
 fi
 if [ $part = trace ]; then
-  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway --no-cohmix-line > /dev/null 2>&1 || exit 1
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway --no-cohmix-line --configs no > /dev/null 2>&1 || exit 1
   f=$(find $O/prof -name "*kernel_trace.csv" | head -1)
   python3 scripts/prof_summary.py $f > $O/kernel_trace_summary.md
   g=$(find $O/prof -name "*kernel_stats.csv" | head -1)
   [ -n "$g" ] && head -14 $g > $O/kernel_stats_head.csv
   head -8 $O/kernel_trace_summary.md
   rm -rf $O/prof
-  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof2 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-overlap --no-gateway --no-cohmix-line > /dev/null 2>&1 || exit 1
+  timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/prof2 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-single-frame --mc-rounds 0 --no-overlap --no-gateway --no-cohmix-line --configs no > /dev/null 2>&1 || exit 1
   f=$(find $O/prof2 -name "*kernel_trace.csv" | head -1)
   python3 scripts/prof_summary.py $f > $O/kernel_trace_no_overlap_summary.md
   g=$(find $O/prof2 -name "*kernel_stats.csv" | head -1)

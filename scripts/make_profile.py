@@ -1,11 +1,13 @@
-"""dev tool: turn gpurun_out/<tag>/* (scripts/final_round.sh lines|trace|traffic <tag>; default tag r04final) into the files of record under profiles/."""
+"""dev tool: turn gpurun_out/<tag>/* (scripts/final_round.sh lines|trace|traffic <tag>) into the files of record under profiles/.
+usage: make_profile.py <tag> <round, e.g. r05>"""
 import json
 import os
 import shutil
 import sys
 
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-F = os.path.join(R, "gpurun_out", sys.argv[1] if len(sys.argv) > 1 else "r04final")
+F = os.path.join(R, "gpurun_out", sys.argv[1])
+RN = sys.argv[2]
 P = os.path.join(R, "profiles")
 
 
@@ -13,9 +15,9 @@ def rd(name):
     return open(os.path.join(F, name)).read()
 
 
-out = ["# Round 4: rocprofv3 --kernel-trace --stats of the bench (F = 1024 C1 frames, 16 Tx sequences, MI355X)\n",
+out = ["# " + RN + ": rocprofv3 --kernel-trace --stats of the bench (F = 1024 C1 frames, 16 Tx sequences, MI355X)\n",
        "Commands (scripts/final_round.sh trace): `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python3 bench.py --steps 2 --warmup 1 "
-       "--no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway --no-cohmix-line` (default: receiver of batch i on a second stream beside the fibre of "
+       "--no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway --no-cohmix-line --configs no` (default: receiver of batch i on a second stream beside the fibre of "
        "batch i+1), the same with `--no-overlap`, and `--nsymb 16384 --frames 16 --variants 1 --no-overlap` (2^20-sample frames) and `--nch 16 --spans 2 --nf 5 --frames 32 --no-overlap` (16-channel WDM frames of BASELINE config[2]).  In rounds 1-2 the tracer kept the two streams "
        "from overlapping; with the receiver enqueued from its own host thread (round 3) they do overlap in the default trace (`k_cma16` 17 ms beside the "
        "fibre against 14 alone; the 'active launch' heuristic of the summary is confused by the row launches that run beside it: read the `--no-overlap` table for per-kernel times).  The bench line of record is the un-profiled run (`r04_bench.jsonl` line 1: "
@@ -34,16 +36,13 @@ out = ["# Round 4: rocprofv3 --kernel-trace --stats of the bench (F = 1024 C1 fr
 d = json.loads(rd("bench_default.json").strip().splitlines()[-1])
 r = d["roofline"]
 ROW = [k for k in r["kernels"] if k.startswith("k_row")][0]
-out.append("## Cross-check with bench.py's live HIP-event figures (separate, un-profiled run: `r04_bench.jsonl` line 1)\n")
+out.append("## Cross-check with bench.py's live HIP-event figures (separate, un-profiled run: `" + RN + "_bench.jsonl` line 1)\n")
 out.append("* `roofline`: kernel %s, avg active launch %.1f us, achieved %.0f GB/s, frac %.3f; `%s` %.1f us (%.3f); step group %.3f.  One active launch of a sweep "
            "= 64 B x %.1f frames x 65536 samples = %.3f GB." % (r["kernel"], r["avg_launch_us"], r["achieved"], r["frac"], ROW, r["kernels"][ROW]["avg_launch_us"],
                                                                  r["kernels"][ROW]["frac_of_8TBs"], r["step_group"]["frac_of_8TBs"],
                                                                  r["algorithmic_bytes_per_launch"] / 64 / 65536, r["algorithmic_bytes_per_launch"] / 1e9))
 out.append("* the `--no-overlap` trace is the fibre ALONE; the default trace and the bench line's figures are beside the receiver.\n")
-open(os.path.join(P, "r04_kernel_trace.md"), "w").write("\n".join(out))
-shutil.copy(os.path.join(F, "bench.jsonl"), os.path.join(P, "r04_bench.jsonl"))
-shutil.copy(os.path.join(F, "traffic.json"), os.path.join(P, "r04_traffic.json"))
-for src, dst in (("pmc_c1.txt", "r04_pmc_c1.txt"), ("pmc_c4.txt", "r04_pmc_2pow20.txt")):
-    if os.path.exists(os.path.join(F, src)):
-        shutil.copy(os.path.join(F, src), os.path.join(P, dst))
-print("profiles/r04_kernel_trace.md, r04_bench.jsonl, r04_traffic.json written")
+open(os.path.join(P, RN + "_kernel_trace.md"), "w").write("\n".join(out))
+shutil.copy(os.path.join(F, "bench.jsonl"), os.path.join(P, RN + "_bench.jsonl"))
+shutil.copy(os.path.join(F, "traffic.json"), os.path.join(P, RN + "_traffic.json"))
+print("profiles/%s_kernel_trace.md, %s_bench.jsonl, %s_traffic.json written" % (RN, RN, RN))
