@@ -11,6 +11,11 @@ from polmux_amd.gstate import GSTATE
 import polmux_amd as px
 lib = _abi.get()
 vp = lambda a: C.c_void_p(a.ctypes.data)
+# (trailing field=value arguments: a plan-time tuning for every plan of the run, e.g. colx_lite=1)
+_tune = {k: int(v) for k, v in (t.split("=") for t in sys.argv[1:] if "=" in t)}
+sys.argv = [t for t in sys.argv if "=" not in t]
+if _tune:
+    lib.call("plx_ssfm_tuning_override", C.byref(lib.tuning(**_tune)))
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 nsmall = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 nlarge = int(sys.argv[3]) if len(sys.argv) > 3 else 16

@@ -1,5 +1,6 @@
 """Summarise a rocprofv3 kernel_trace.csv: per-kernel totals, and for the SSFM kernels the average over
-ACTIVE launches (at least half as long as the kernel's longest launch; the chunked step loop also issues no-op launches)."""
+ACTIVE launches (at least half as long as the kernel's 90th-percentile launch: the chunked step loop also issues no-op
+launches, and a few launches that start beside the receiver's CMA waves run much longer than the rest)."""
 import csv, sys, collections, re
 
 
@@ -20,6 +21,7 @@ tot = sum(sum(v) for v in agg.values())
 print("| kernel | launches | total ms | active launches | avg active us | % of GPU time |")
 print("|---|---|---|---|---|---|")
 for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
-    act = [x for x in v if x >= 0.5 * max(v)] or v     # active launches: at least half as long as the longest (the chunked
+    ref = sorted(v)[min(len(v) - 1, int(0.9 * len(v)))]
+    act = [x for x in v if x >= 0.5 * ref] or v        # active launches: at least half as long as the 90th percentile (the chunked
                                                        # step loop also issues launches after every frame has finished)
     print("| `%s` | %d | %.2f | %d | %.1f | %.1f |" % (k, len(v), sum(v) / 1e3, len(act), sum(act) / len(act), 100 * sum(v) / tot))
