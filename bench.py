@@ -949,7 +949,7 @@ def run_line(a, E):
         if f64 is not None and not fused_mismatch(f64, names):
             fk = {}
             for k_, v_ in kern.items():
-                fl = f64["flop_per_sample_per_launch"].get(k_)
+                fl = f64["flop_per_sample_per_launch"].get(k_.split("<")[0])
                 if fl is None:
                     continue
                 tf = fl * act * nch * n / (v_["avg_launch_us"] * 1e-6) / 1e12
@@ -963,8 +963,9 @@ def run_line(a, E):
         sweeps = 2 if fused else 3
         group_bytes = SWEEP_BYTES * sweeps
         group_gbs = group_bytes * sample_steps / (fib * 1e-3) / 1e9
-        traffic, traffic_src = offline_traffic(fused, F, n, nch, a.flag)
         active_frames = float(np.mean([(ncyc > s).sum() for s in range(int(ncyc.max()))])) if len(ncyc) else float(F)
+        # (per launch like `achieved`: the frames a launch covers on average -- fewer than F once frames of a ladder have finished)
+        traffic, traffic_src = offline_traffic(fused, active_frames, n, nch, a.flag)
         # which roof is nearer: the larger of the two fractions names the bound; with both below one half the kernel is
         # bound by neither rate but by the latency structure of a workgroup's life (occupancy, barriers, exchanges)
         hbm_frac = kern.get(dom, {}).get("frac_of_8TBs") or 0.0
