@@ -256,8 +256,7 @@ __global__ __launch_bounds__(CMA16_THREADS) void k_cma16(DemuxArgs a)
     //  * the samples of the NEXT chunk are loaded unconditionally by every lane (a lane beyond the last tap keeps zero taps and
     //    a zero step size instead of a predicate per load: eight exec-masked blocks of 28 instructions per chunk before), from
     //    a position kept modulo L by one compare per sample instead of 64-bit wrap arithmetic;
-    //  * two chunks per trip, the second computing from the registers the first one's prefetch landed in (no register copies).
-    //    the samples of an INTERIOR chunk k (0 < k < nchunks - 2: no lane's window leaves [0, L)) sit at one per-lane pointer
+    //  * the samples of an INTERIOR chunk k (0 < k < nchunks - 2: no lane's window leaves [0, L)) sit at one per-lane pointer
     //    plus a wave-uniform offset and eight immediates; only the chunks at the two ends of a pass wrap around;
     //  * two chunks per trip, the second computing from the registers the first one's prefetch landed in (no register copies).
     const double mul_lane = tap_ok ? mu : 0.0;

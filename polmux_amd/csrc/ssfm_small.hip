@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_umax(SsfmArgs a)
     block_atomic_max(m, red, a.umax + fc, threadIdx.x, blockDim.x);
 }
 
-__global__ void k_ctrl(SsfmArgs a, int nframes)
+__global__ __launch_bounds__(64) void k_ctrl(SsfmArgs a, int nframes)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= nframes) return;

@@ -40,6 +40,36 @@ def test_abi_library_exports_every_declared_symbol():
         b.call("plx_ssfm_create", None, None)
 
 
+def test_plan_tuning_is_a_struct_not_the_environment(monkeypatch):
+    """include/polmux_hip.h, plx_ssfm_tuning (ABI 1002): the defaults consult exactly two environment variables -- the deployment
+    knobs PLX_SSFM_NO_FUSE and PLX_SSFM_BARRIER_TIMEOUT_MS -- and none of the seventeen A/B switches of ABI 1001; a struct that was
+    not filled by plx_ssfm_tuning_defaults (size 0) is refused; the library's sources read nothing else from the environment."""
+    from polmux_amd import _abi
+    b = _abi.Binding()
+    for k in ("PLX_SSFM_ROWR", "PLX_SSFM_P1", "PLX_SSFM_NO_PMD_TAB", "PLX_SSFM_ROW_REV", "PLX_SSFM_STORE_LATE", "PLX_SSFM_SHORT_ROWS"):
+        monkeypatch.setenv(k, "0" if k != "PLX_SSFM_P1" else "4")
+    t = b.tuning()
+    assert t.size == C.sizeof(_abi.SsfmTuning) and (t.rowr, t.p1, t.no_pmd_tab, t.row_rev, t.store_late, t.short_rows) == (1, -1, 0, 1, -1, 0)
+    assert t.no_fuse == 0 and t.barrier_timeout_ms == 500.0
+    monkeypatch.setenv("PLX_SSFM_NO_FUSE", "1")
+    monkeypatch.setenv("PLX_SSFM_BARRIER_TIMEOUT_MS", "125")
+    t = b.tuning()
+    assert t.no_fuse == 1 and t.barrier_timeout_ms == 125.0
+    with pytest.raises(KeyError):
+        b.tuning(no_such_switch=1)
+    bad = _abi.SsfmTuning()                                    # size 0: never went through plx_ssfm_tuning_defaults
+    with pytest.raises(_abi.PolmuxError, match="plx_ssfm_tuning_defaults first"):
+        b.call("plx_ssfm_tuning_override", C.byref(bad))
+    b.call("plx_ssfm_tuning_override", C.byref(b.tuning(rowr=0)))
+    b.call("plx_ssfm_tuning_override", None)
+    reads = []
+    for fn in sorted(os.listdir(os.path.join(ROOT, "polmux_amd", "csrc"))):
+        src = open(os.path.join(ROOT, "polmux_amd", "csrc", fn)).read()
+        reads += [(fn, ln.strip()) for ln in src.splitlines() if "getenv(" in ln]
+    assert len(reads) == 2 and all(fn == "ssfm_plan.hip" for fn, _ in reads), reads
+    assert "PLX_SSFM_NO_FUSE" in reads[0][1] and "PLX_SSFM_BARRIER_TIMEOUT_MS" in reads[1][1]
+
+
 def test_no_cpu_fallback_and_oracle_is_never_imported():
     """The product fails loudly when the HIP library is missing, and no module of polmux_amd touches oracle/."""
     from polmux_amd import _abi
