@@ -107,7 +107,7 @@ int plx_ssfm_create_ex(plx_ssfm **plan, const plx_ssfm_desc *desc, uint32_t flag
  * plx_ssfm_create_tuned(..., tuning) builds one plan with it (NULL: the process-wide override if one is set, else the
  * defaults); plx_ssfm_tuning_override(t) makes t the tuning of every plan created WITHOUT one from now on -- including
  * the plans the gateway tier builds and caches (call plx_release_all() to drop those built earlier) -- NULL ends it.
- * A test hook: deployments never call it.                                                                           */
+ * A test hook: deployments never call it (and it is not synchronised: set it while no other thread creates plans).   */
 typedef struct plx_ssfm_tuning {
     uint32_t size;           /* sizeof(plx_ssfm_tuning), set by plx_ssfm_tuning_defaults                              */
     int32_t no_fuse;         /* 1: three sweeps per step (k_col_fwd, row pass, k_col_inv) instead of the fused sweep   */
