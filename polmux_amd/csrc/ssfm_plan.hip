@@ -1,4 +1,6 @@
-// plx_ssfm.hip -- split-step Fourier propagator of fiber.m on gfx950.
+// ssfm_plan.hip -- the plan and the step loop of the split-step Fourier propagator of fiber.m on gfx950 (create / destroy,
+// waveplate tables, propagate, per-kernel timing, the FFT engine as a spectral filter).  The kernels live in ssfm_small.hip,
+// ssfm_col.hip, ssfm_colx.hip, ssfm_row*.hip (ssfm_kernels.h: what this file sees of them), the gateways in ssfm_gateway.hip.
 //
 // Reference: /root/reference/fiber.m:459-935 (matrix_ssfm, scalar_ssfm, nextstep,
 // checkstep, lin_step, nl_step, matrix_nl_step, matrix_step).

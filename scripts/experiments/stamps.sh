@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev experiment: where a k_colx16 workgroup's tile time goes (instrumented copy of the library, thread-0 wall-clock stamps).
-# usage: scripts/experiments/stamps.sh build   (here: instruments a COPY of plx_ssfm.hip with stamps_patch.py and cross-compiles polmux_amd/lib/libpolmux_hip_stamps.so)
+# usage: scripts/experiments/stamps.sh build   (here: instruments COPIES of ssfm_colx.hip / ssfm_plan.hip with stamps_patch.py and cross-compiles polmux_amd/lib/libpolmux_hip_stamps.so)
 #        gpurun -- bash scripts/experiments/stamps.sh run [frames]
 set -e
 cd "$(dirname "$0")/../.."
