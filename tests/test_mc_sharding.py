@@ -339,6 +339,40 @@ def test_bench_starts_its_own_ranks():
 
 
 @pytest.mark.gpu
+def test_default_bench_line_carries_configs_2_and_4_as_stated():
+    """The driver runs `python bench.py` with no workload flags: after the headline (BASELINE config[1]) the line must carry bounded
+    legs of config[2] (16 channels x 10 spans x 32 frames) and config[4] (2^20 samples x 40 spans, rank 0's share of the 64-point
+    ladder over 8 GPUs) AS STATED, each with value, roofline (HBM and FP64 fractions, offline traffic) and its own CPU baseline."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PLX_BENCH_REHEARSAL"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--mc-rounds", "0", "--no-gateway",
+                          "--no-single-frame", "--no-cohmix-line", "--cpu-frames", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert "BASELINE config[1]" in d["config"]["workload"] and set(d["configs"]) == {"c2", "c4"}
+    c2, c4 = d["configs"]["c2"], d["configs"]["c4"]
+    assert "BASELINE config[2]: 16 channels, 10x80 km" in c2["config"]["workload"] and c2["config"]["channels_per_frame"] == 16
+    assert c2["config"]["frames_per_gpu_per_step"] == 32 and c2["steps"] == 2
+    assert "BASELINE config[4]: 2^20-sample frame x 40 spans x 64-point ladder)" in c4["config"]["workload"]
+    assert c4["config"]["frames_per_gpu_per_step"] == 8 and len(c4["config"]["ladder_dbm"]) == 8
+    np.testing.assert_allclose(c4["config"]["ladder_dbm"], -4.0 + 12.0 * 8 * np.arange(8) / 63.0, atol=1e-9)      # every 8th point of the ladder
+    for leg in (c2, c4):
+        assert leg["value"] > 0 and leg["unit"] == "Gsample/s" and leg["dtype"] == "f64" and leg["ms_per_step"] > 0
+        r = leg["roofline"]
+        assert r["kernel"] == "k_colx16" and 0.05 < r["frac"] < 1.0 and r["bound"] in ("hbm", "fp64-valu")
+        assert r["fp64"] is not None and 0.0 < r["fp64"]["frac"] < 1.0 and r["fp64"]["peak"] == pytest.approx(78.6)
+        assert r["traffic"] is not None and 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.3
+        cb = leg["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] == 1 and 0 < cb["value"] < leg["value"]
+    assert d["roofline"]["fp64"]["frac"] > 0.05 and d["roofline"]["traffic"] is not None
+
+
+@pytest.mark.gpu
 def test_bench_line_carries_the_contract_fields():
     """One small `bench.py` run at N = 1: ONE JSON line with the driver's fields, the roofline object of the dominant
     kernel (real bytes per launch over a live HIP-event duration) and the CPU baseline timed beside it."""
