@@ -570,7 +570,7 @@ static int resolve_profiles(plx_ssfm *P)
 static int propagate_frames(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int nframes, hipStream_t st)
 {
     SsfmArgs a = P->a;
-    const int nfc = a.nfc, N1 = 1 << a.p1, N2 = 1 << a.p2;
+    const int nfc = a.nfc, N2 = 1 << a.p2;
     a.ux = d_ux;
     a.uy = d_uy;
     a.nframes = nframes;
@@ -590,7 +590,6 @@ static int propagate_frames(plx_ssfm *P, cplx *d_ux, cplx *d_uy, int nframes, hi
         launch_umax(dim3(gx, FC), st, a);
     }
     const dim3 blk(256);
-    const dim3 gctl((unsigned)((nframes + 63) / 64)), bctl(64);
     const dim3 bcol((unsigned)P->col_threads);
     // Data-dependent trip count (fiber.m:518): steps are enqueued in chunks; the completed-frame counter and the
     // abort word of chunk k are read back while chunk k+1 executes.
