@@ -18,10 +18,7 @@ def rd(name):
 out = ["# " + RN + ": rocprofv3 --kernel-trace --stats of the bench (F = 1024 C1 frames, 16 Tx sequences, MI355X)\n",
        "Commands (scripts/final_round.sh trace): `rocprofv3 --kernel-trace --stats --output-format csv -d ... -- python3 bench.py --steps 2 --warmup 1 "
        "--no-cpu-baseline --no-single-frame --mc-rounds 0 --no-gateway --no-cohmix-line --configs no` (default: receiver of batch i on a second stream beside the fibre of "
-       "batch i+1), the same with `--no-overlap`, and `--nsymb 16384 --frames 16 --variants 1 --no-overlap` (2^20-sample frames) and `--nch 16 --spans 2 --nf 5 --frames 32 --no-overlap` (16-channel WDM frames of BASELINE config[2]).  In rounds 1-2 the tracer kept the two streams "
-       "from overlapping; with the receiver enqueued from its own host thread (round 3) they do overlap in the default trace (`k_cma16` 17 ms beside the "
-       "fibre against 14 alone; the 'active launch' heuristic of the summary is confused by the row launches that run beside it: read the `--no-overlap` table for per-kernel times).  The bench line of record is the un-profiled run (`r04_bench.jsonl` line 1: "
-       "`roofline.kernels` from HIP events between the launches).\n",
+       "batch i+1), the same with `--no-overlap`, and `--nsymb 16384 --frames 16 --variants 1 --no-overlap` (2^20-sample frames) and `--nch 16 --spans 2 --nf 5 --frames 32 --no-overlap` (16-channel WDM frames of BASELINE config[2]).  The summaries count as ACTIVE the launches at least half as long as the kernel's 90th-percentile launch (the chunked step loop also issues launches that return at once; a few launches that start beside the receiver's CMA waves run much longer than the rest).  The bench line of record is the un-profiled run (`" + RN + "_bench.jsonl` line 1: `roofline.kernels` from HIP events between the launches).\n",
        "Default path: `k_compact` (active list) + fused column sweep `k_colx16` (inverse column pass of step s + step controller + forward column pass of "
        "step s+1; teams of 32 workgroups claim frames one at a time; next tile staged by LDS-DMA) + `k_row256r<false>` (the register form of the 256-point "
        "row pass: one wave per 2 rows x 2 polarisations): two HBM sweeps per SSFM step.\n",
