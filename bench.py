@@ -192,6 +192,56 @@ class HipEvents:
         self.live = []
 
 
+class PowerWatch:
+    """Core clock and socket power while the timed region runs (rocm-smi from a host thread, a sample every ~0.4 s): the SSFM
+    kernels run the part at its power cap with the core clock throttled below 2.4 GHz (profiles/r05_notes.md, section 3b), which
+    is part of what "peak" means for this line.  Best effort: any failure leaves the field null."""
+
+    def __init__(self):
+        import re
+        import shutil
+        import threading
+        self.rows, self.cap = [], None
+        self._stop = threading.Event()
+        self._re = re.compile(r"sclk clock level: \w+: \((\d+)Mhz\).*?Current Socket Graphics Package Power \(W\): ([\d.]+)", re.S)
+        self._recap = re.compile(r"Max Graphics Package Power \(W\): ([\d.]+)")
+        self._smi = shutil.which("rocm-smi")
+        # (not under a profiler: its preloaded library would travel into the child processes)
+        if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+            self._smi = None
+        self._t = threading.Thread(target=self._run, daemon=True) if self._smi else None
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run([self._smi, "--showclocks", "--showpower", "--showmaxpower"], capture_output=True, text=True, timeout=5).stdout
+                m = self._re.search(out)
+                if m:
+                    self.rows.append((time.perf_counter(), int(m.group(1)), float(m.group(2))))
+                c = self._recap.search(out)
+                if c:
+                    self.cap = float(c.group(1))
+            except Exception:
+                return
+            self._stop.wait(0.25)
+
+    def start(self):
+        if self._t:
+            self._t.start()
+        return self
+
+    def stop(self, t0, t1):
+        if not self._t:
+            return None
+        self._stop.set()
+        self._t.join(timeout=6)
+        rows = [r for r in self.rows if t0 + 0.3 <= r[0] <= t1]            # (inside the timed region, past the ramp)
+        if not rows:
+            return None
+        return {"sclk_mhz": sum(r[1] for r in rows) / len(rows), "socket_power_w": sum(r[2] for r in rows) / len(rows), "power_cap_w": self.cap,
+                "samples": len(rows), "how": "rocm-smi --showclocks --showpower from a host thread during the timed region"}
+
+
 def host_cores():
     """CPU cores this process may actually use: the smaller of the affinity mask and the cgroup CPU quota (a GPU box
     hands each GPU a share of the host, e.g. 16 of 256 logical CPUs), PLX_BENCH_CORES overrides."""
@@ -664,6 +714,7 @@ def run_line(a, E):
         hp.run(ux, uy, noise_sigma=a.noise, noise_seed=1000 * rank + i)
     sync_all()
     hp.kernel_times()                  # (drop the warm-up's kernel intervals)
+    pwatch = PowerWatch().start() if rank == 0 else None
     t0 = time.perf_counter()
     # The receiver of a batch is ENQUEUED by a second host thread (its kernels go to the receiver's stream either way): the
     # fibre call blocks its host thread until the step loop has ended, and the ~3 ms it takes to enqueue the receiver's dozen
@@ -736,6 +787,7 @@ def run_line(a, E):
             raise rx_fail[0]
     sync_all()
     dt = time.perf_counter() - t0
+    power_state = pwatch.stop(t0, t0 + dt) if pwatch is not None else None
     for e in errs:
         err_total += e
     res_total = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -1019,6 +1071,7 @@ def run_line(a, E):
                        "bit_errors_resolved": int(res_total.item()) if a.mc else None,
                        "bits": int(world) * a.steps * F * nch * 4 * a.nsymb, "restaged_batches": restaged,
                        "rehearsal_all_ranks_on_one_gpu": bool(rehearsal),
+                       "power_state": power_state,
                        "single_frame": single,
                        "with_reference_front_end": cohmix_line},
             # a PMD plan's row pass does one exponential + 20 multiply-adds per waveplate trunk and frequency: FP64-VALU-bound

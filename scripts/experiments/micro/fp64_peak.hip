@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 fp64_peak.hip -o fp64_peak && ./fp64_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 template <int CH> __global__ __launch_bounds__(256) void k_fma(double *out, double a, double b, int iters)
 {
     double x[CH];
@@ -31,10 +32,15 @@ template <int CH> static void run(double *d, int blocks, int iters)
     const double flops = 2.0 * CH * (double)iters * 256.0 * blocks;
     printf("chains %2d blocks %5d (%d waves per SIMD): %.2f ms  %.1f TFLOP/s FP64\n", CH, blocks, blocks / 256, ms, flops / ms * 1e-9);
 }
-int main()
+int main(int argc, char **argv)
 {
     double *d;
     hipMalloc(&d, sizeof(double) * 256 * 8192);
+    if (argc > 1) {       // sustained load for a clock / power reading: <seconds-ish> repetitions of the densest shape
+        for (int r = 0; r < atoi(argv[1]); r++) run<8>(d, 4096, 1 << 19);
+        hipFree(d);
+        return 0;
+    }
     for (int blocks : {256, 512, 1024, 2048, 4096}) { run<1>(d, blocks, 1 << 16); run<4>(d, blocks, 1 << 15); run<8>(d, blocks, 1 << 14); }
     hipFree(d);
     return 0;

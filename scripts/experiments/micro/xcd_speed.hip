@@ -4,6 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 xcd_speed.hip -o xcd_speed && ./xcd_speed
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 typedef double2 cplx;
 __global__ __launch_bounds__(256, 2) void k_probe(cplx *buf, long long *dur, int *xcc, int tiles, int mode, size_t frame_stride)
@@ -38,16 +39,17 @@ __global__ __launch_bounds__(256, 2) void k_probe(cplx *buf, long long *dur, int
     if (mode == 1 && acc.x == 12345.678) buf[0] = acc;
     if (tid == 0) { dur[blockIdx.x] = wall_clock64() - t0; xcc[blockIdx.x] = (int)__builtin_amdgcn_s_getreg(6164) & 15; }
 }
-int main()
+int main(int argc, char **argv)
 {
     const int tiles = 64;
+    const int sustain = argc > 1 ? atoi(argv[1]) : 0;      // repetitions of the read + write mode only (clock / power reading)
     const size_t frame = (size_t)256 * 8192;              // complex per frame: 32 MiB
     cplx *buf; long long *dur; int *xcc;
     hipMalloc(&buf, frame * tiles * sizeof(cplx)); hipMemset(buf, 0, frame * tiles * sizeof(cplx));
     hipMalloc(&dur, 512 * sizeof(long long)); hipMalloc(&xcc, 512 * sizeof(int));
     const char *names[3] = {"read + arithmetic + write", "arithmetic only", "read + write only"};
-    for (int mode = 0; mode < 3; mode++) {
-        for (int rep = 0; rep < 3; rep++) {
+    for (int mode = sustain ? 2 : 0; mode < 3; mode++) {
+        for (int rep = 0; rep < (sustain ? sustain : 3); rep++) {
             k_probe<<<512, 256>>>(buf, dur, xcc, tiles, mode, frame);
             hipDeviceSynchronize();
         }
