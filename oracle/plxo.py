@@ -17,11 +17,18 @@ _LIB = os.path.join(_HERE, "_build", "libplxo.so")
 
 
 def build(force=False):
+    import fcntl
     srcs = [os.path.join(_HERE, f) for f in ("plxo_fiber.c", "plxo_rx.c", "plxo_mc.c", "plxo.h")]
-    if (not force and os.path.exists(_LIB)
-            and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs)):
+
+    def fresh():
+        return os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs)
+    if not force and fresh():
         return _LIB
-    subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    os.makedirs(os.path.dirname(_LIB), exist_ok=True)
+    with open(_LIB + ".lock", "w") as lk:         # (parallel test workers: one builds, the others wait and find it fresh)
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if force or not fresh():
+            subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return _LIB
 
 

@@ -13,12 +13,20 @@ if os.environ.get("PLX_EMU_SAN") == "1":
 
 
 def build():
+    import fcntl
     srcs = glob.glob(os.path.join(ROOT, "polmux_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "tests", "emu", "hip_emu.*")) \
         + [os.path.join(ROOT, "include", "polmux_hip.h")]
-    if os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs):
+
+    def fresh():
+        return os.path.exists(LIB) and all(os.path.getmtime(LIB) >= os.path.getmtime(s) for s in srcs)
+    if fresh():
         return LIB
-    env = dict(os.environ, SAN="1") if LIB.endswith("_san.so") else None
-    subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build.sh")], stdout=subprocess.DEVNULL, env=env)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    with open(LIB + ".lock", "w") as lk:          # (pytest-xdist workers: one builds, the others wait and find it fresh)
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if not fresh():
+            env = dict(os.environ, SAN="1") if LIB.endswith("_san.so") else None
+            subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build.sh")], stdout=subprocess.DEVNULL, env=env)
     return LIB
 
 
