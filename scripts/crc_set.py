@@ -4,11 +4,15 @@
 import ctypes as C, os, sys, math, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
+import torch  # noqa: F401  (first: a development build of the library must find torch's HIP runtime already loaded)
 from polmux_amd import _abi, synth
 from polmux_amd._abi import SsfmDesc
 from polmux_amd.fiber import parse_flag, fiber_tables
 from polmux_amd.gstate import GSTATE
 import polmux_amd as px
+for _t in [t for t in sys.argv[1:] if t.startswith("lib=")]:       # lib=<name>: polmux_amd/lib/libpolmux_hip_<name>.so (a development build)
+    _abi.LIB_PATH = os.path.join(os.path.dirname(_abi.LIB_PATH), "libpolmux_hip_%s.so" % _t[4:])
+    sys.argv.remove(_t)
 lib = _abi.get()
 vp = lambda a: C.c_void_p(a.ctypes.data)
 # (trailing field=value arguments: a plan-time tuning for every plan of the run, e.g. colx_lite=1)
